@@ -1,0 +1,1001 @@
+// api.hip -- the C ABI (include/libbz3.h + include/bz3_hip.h) on top of the HIP stage pipelines.
+//
+// Mirrors the reference's orchestration exactly: bz3_encode_block (src/libbz3.c:585-654) and
+// bz3_decode_block (:656-809) are ping-pong pipelines over the caller's buffer and the state's swap
+// buffer; every size/flag decision and every error code is reproduced.  What changes is WHERE things
+// live: both buffers are in HBM, the stages are the kernels of crc32c/mrle/lzp/bwt/unbwt/cm.hip, the
+// suffix-sort workspace is one arena per GPU shared by all states, and each state owns a HIP stream so
+// that the long single-CU CM kernels of many blocks overlap with the whole-GPU stages of the next
+// block (bz3_encode_blocks / bz3_decode_blocks, :845-870, without pthreads).
+//
+// There is no CPU implementation of any stage in this library: without a usable HIP device
+// bz3_new() returns NULL and the stage hooks abort loudly.
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/bz3_hip.h"
+#include "prims.hpp"
+#include "sort.hpp"
+#include "stages.hpp"
+
+using namespace bz3;
+
+namespace {
+
+constexpr s32 KiB65 = 65 * 1024;
+constexpr s32 MiB511 = 511 * 1024 * 1024;
+
+inline double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+inline u32 rd_le32(const u8 * p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
+inline void wr_le32(u8 * p, u32 v) {
+    p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); p[3] = (u8)(v >> 24);
+}
+
+// ---- per-device context -----------------------------------------------------------------------
+struct DeviceCtx {
+    int device = 0;
+    std::mutex mu;          // serialises users of the shared workspace
+    CrcTables * d_crc = nullptr;
+    char * ws = nullptr;
+    size_t ws_cap = 0;
+
+    Arena arena_for(size_t bytes) {  // caller holds mu
+        if (bytes > ws_cap) {
+            if (ws) HIP_CHECK(hipFree(ws));
+            ws = nullptr;
+            ws_cap = 0;
+            size_t want = bytes + (bytes >> 4) + (1u << 20);
+            HIP_CHECK(hipMalloc((void **)&ws, want));
+            ws_cap = want;
+        }
+        Arena a;
+        a.base = ws;
+        a.cap = ws_cap;
+        a.used = 0;
+        return a;
+    }
+};
+
+std::mutex g_mu;
+std::vector<DeviceCtx *> g_ctx;
+int g_device_count = -1;
+std::atomic<int> g_bound_device{-2};  // -2 = not initialised from the environment yet, -1 = round robin
+std::atomic<unsigned> g_rr{0};
+
+int device_count() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_device_count < 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+        g_device_count = n;
+        g_ctx.assign((size_t)(n > 0 ? n : 0), nullptr);
+    }
+    return g_device_count;
+}
+
+DeviceCtx * get_ctx(int dev) {
+    const int n = device_count();
+    if (dev < 0 || dev >= n) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_ctx[dev]) {
+        HIP_CHECK(hipSetDevice(dev));
+        DeviceCtx * c = new DeviceCtx;
+        c->device = dev;
+        CrcTables t;
+        memset(&t, 0, sizeof t);
+        crc_build_tables(t);
+        HIP_CHECK(hipMalloc((void **)&c->d_crc, sizeof(CrcTables)));
+        HIP_CHECK(hipMemcpy(c->d_crc, &t, sizeof t, hipMemcpyHostToDevice));
+        g_ctx[dev] = c;
+    }
+    return g_ctx[dev];
+}
+
+int pick_device() {
+    const int n = device_count();
+    if (n <= 0) return -1;
+    int b = g_bound_device.load();
+    if (b == -2) {
+        const char * e = getenv("BZ3_HIP_DEVICE");
+        b = (e && *e) ? atoi(e) : -1;
+        if (b >= n) b = -1;
+        g_bound_device.store(b);
+    }
+    if (b >= 0) return b;
+    return (int)(g_rr.fetch_add(1) % (unsigned)n);
+}
+
+size_t workspace_bytes_for(u64 n) {
+    size_t a = bwt_workspace_bytes(n), b = unbwt_workspace_bytes(n);
+    size_t c = (size_t)n * 26 + radix_temp_bytes(n) + (4u << 20);  // LZP: prev, mlen, bitmap, sort buffers
+    size_t m = a > b ? a : b;
+    return m > c ? m : c;
+}
+
+// ---- small kernels of the orchestration layer ---------------------------------------------------
+__global__ void k_write_header(u8 * __restrict__ b, const u32 * __restrict__ crc, u32 idx, u32 model, u32 lzp_size, u32 rle_size) {
+    if (threadIdx.x != 0) return;
+    const u32 c = *crc;
+    b[0] = (u8)c; b[1] = (u8)(c >> 8); b[2] = (u8)(c >> 16); b[3] = (u8)(c >> 24);
+    b[4] = (u8)idx; b[5] = (u8)(idx >> 8); b[6] = (u8)(idx >> 16); b[7] = (u8)(idx >> 24);
+    b[8] = (u8)model;
+    u32 o = 9;
+    if (model & 2u) { b[o] = (u8)lzp_size; b[o + 1] = (u8)(lzp_size >> 8); b[o + 2] = (u8)(lzp_size >> 16); b[o + 3] = (u8)(lzp_size >> 24); o += 4; }
+    if (model & 4u) { b[o] = (u8)rle_size; b[o + 1] = (u8)(rle_size >> 8); b[o + 2] = (u8)(rle_size >> 16); b[o + 3] = (u8)(rle_size >> 24); }
+}
+
+// Blocks shorter than 64 bytes are stored: [crc][0xFFFFFFFF][bytes] (src/libbz3.c:596-601).
+__global__ void __launch_bounds__(64) k_store_small(u8 * __restrict__ b, u32 n, const u32 * __restrict__ crc) {
+    const u32 t = threadIdx.x;
+    const u8 v = t < n ? b[t] : (u8)0;
+    __syncthreads();
+    if (t < n) b[8 + t] = v;
+    if (t == 0) {
+        const u32 c = *crc;
+        b[0] = (u8)c; b[1] = (u8)(c >> 8); b[2] = (u8)(c >> 16); b[3] = (u8)(c >> 24);
+        b[4] = b[5] = b[6] = b[7] = 0xFF;
+    }
+}
+__global__ void __launch_bounds__(128) k_unstore_small(u8 * __restrict__ b, u32 n) {  // memmove(buffer, buffer + 8, n), :684
+    const u32 t = threadIdx.x;
+    const u8 v = t < n ? b[8 + t] : (u8)0;
+    __syncthreads();
+    if (t < n) b[t] = v;
+}
+
+}  // namespace
+
+// ---- the state ------------------------------------------------------------------------------------
+struct bz3_state {
+    s32 block_size = 0;
+    s8 last_error = BZ3_OK;
+    int device = 0;
+    DeviceCtx * ctx = nullptr;
+    hipStream_t stream = nullptr;
+    u8 * d_swap = nullptr;  // the reference's swap_buffer, in HBM
+    u8 * d_io = nullptr;    // staging for the host-buffer API (lazy)
+    size_t cap = 0;         // bz3_bound(block_size) rounded up
+    u32 * d_words = nullptr;  // [0..1] crc scratch/result, [2] cm coded size, [4..] spare
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float t[BZ3_HIP_T_COUNT] = {0};
+    BwtStats bwt;
+
+    // in-flight block between *_front and *_finish
+    enum Pending { NONE, ENC_STORED, ENC_CODED, DEC_STORED, DEC_CODED, FAILED } pending = NONE;
+    u8 * user = nullptr;  // caller's device buffer
+    u8 * b1 = nullptr;
+    s32 size = 0, overhead = 0;
+    // decode
+    size_t buffer_size = 0;
+    u32 crc = 0;
+    s32 bwt_idx = 0, model = 0, lzp_size = -1, rle_size = -1, orig_size = 0, size_before_bwt = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    explicit DeviceGuard(int d) { HIP_CHECK(hipSetDevice(d)); }
+};
+
+void state_release(bz3_state * st) {
+    if (!st) return;
+    (void)hipSetDevice(st->device);
+    if (st->stream) (void)hipStreamSynchronize(st->stream);
+    if (st->ev0) (void)hipEventDestroy(st->ev0);
+    if (st->ev1) (void)hipEventDestroy(st->ev1);
+    if (st->d_swap) (void)hipFree(st->d_swap);
+    if (st->d_io) (void)hipFree(st->d_io);
+    if (st->d_words) (void)hipFree(st->d_words);
+    if (st->stream) (void)hipStreamDestroy(st->stream);
+    delete st;
+}
+
+void ensure_io(bz3_state * st) {
+    if (!st->d_io) HIP_CHECK(hipMalloc((void **)&st->d_io, st->cap));
+}
+
+u32 read_word(bz3_state * st, const u32 * d) {
+    u32 v = 0;
+    HIP_CHECK(hipMemcpyAsync(&v, d, 4, hipMemcpyDeviceToHost, st->stream));
+    HIP_CHECK(hipStreamSynchronize(st->stream));
+    return v;
+}
+
+// ---- encode ------------------------------------------------------------------------------------
+// Front half: everything up to and including the launch of the CM kernel (asynchronous tail).
+void encode_front(bz3_state * st, u8 * buf, s32 data_size) {
+    st->pending = bz3_state::FAILED;
+    if (data_size > st->block_size) {  // :588-591
+        st->last_error = BZ3_ERR_DATA_TOO_BIG;
+        return;
+    }
+    if (data_size < 0) {  // the reference would walk off its buffer; refuse instead
+        st->last_error = BZ3_ERR_DATA_TOO_BIG;
+        return;
+    }
+    DeviceGuard g(st->device);
+    hipStream_t s = st->stream;
+    for (float & x : st->t) x = 0.f;
+    std::lock_guard<std::mutex> lk(st->ctx->mu);
+    double t0 = now_ms();
+    crc32c_device(buf, (u64)data_size, 1u, st->ctx->d_crc, st->d_words, s);  // :593
+    st->user = buf;
+    st->size = data_size;
+    if (data_size < 64) {  // :596-601 (last_error is left untouched on this path)
+        launch(k_store_small, dim3(1), dim3(64), 0, s, buf, (u32)data_size, (const u32 *)(st->d_words + 1));
+        st->pending = bz3_state::ENC_STORED;
+        return;
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    st->t[BZ3_HIP_T_CRC] = (float)(now_ms() - t0);
+
+    u32 n = (u32)data_size;
+    Arena arena = st->ctx->arena_for(workspace_bytes_for((u64)n + 64));
+    u8 *b1 = buf, *b2 = st->d_swap;
+    s32 model = 0, lzp_size = 0, rle_size = 0;
+
+    t0 = now_ms();
+    {  // :609-614
+        MrleEncScratch sc;
+        const size_t mk = arena.mark();
+        mrle_encode_size(b1, n, sc, arena, s);
+        rle_size = (s32)(32u + read_word(st, sc.total));
+        if (rle_size < (s32)n) {
+            mrle_encode_write(b1, n, sc, b2, s);
+            HIP_CHECK(hipStreamSynchronize(s));
+            u8 * tmp = b1; b1 = b2; b2 = tmp;
+            n = (u32)rle_size;
+            model |= 4;
+        }
+        arena.release(mk);
+    }
+    st->t[BZ3_HIP_T_RLE] = (float)(now_ms() - t0);
+
+    t0 = now_ms();
+    lzp_size = lzp_encode(b1, n, b2, arena, s);  // :616-621
+    if (lzp_size > 0 && lzp_size < (s32)n) {
+        HIP_CHECK(hipStreamSynchronize(s));
+        u8 * tmp = b1; b1 = b2; b2 = tmp;
+        n = (u32)lzp_size;
+        model |= 2;
+    }
+    st->t[BZ3_HIP_T_LZP] = (float)(now_ms() - t0);
+
+    t0 = now_ms();
+    const s32 bwt_idx = bwt_forward(b1, n, b2, arena, s, &st->bwt);  // :623-627
+    st->t[BZ3_HIP_T_BWT] = (float)(now_ms() - t0);
+    if (bwt_idx < 0) {
+        st->last_error = BZ3_ERR_BWT;
+        return;
+    }
+    s32 overhead = 2;  // :630-632
+    if (model & 2) overhead++;
+    if (model & 4) overhead++;
+    HIP_CHECK(hipEventRecord(st->ev0, s));
+    cm_encode(b2, n, b1 + overhead * 4 + 1, st->d_words + 2, s);  // :634-638
+    HIP_CHECK(hipEventRecord(st->ev1, s));
+    launch(k_write_header, dim3(1), dim3(64), 0, s, b1, (const u32 *)(st->d_words + 1), (u32)bwt_idx, (u32)model, (u32)lzp_size, (u32)rle_size);  // :641-647
+    st->b1 = b1;
+    st->overhead = overhead;
+    st->pending = bz3_state::ENC_CODED;
+}
+
+s32 encode_finish(bz3_state * st) {
+    const bz3_state::Pending p = st->pending;
+    st->pending = bz3_state::NONE;
+    if (p == bz3_state::FAILED || p == bz3_state::NONE) return -1;
+    DeviceGuard g(st->device);
+    HIP_CHECK(hipStreamSynchronize(st->stream));
+    if (p == bz3_state::ENC_STORED) return st->size + 8;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, st->ev0, st->ev1) == hipSuccess) st->t[BZ3_HIP_T_CM] = ms;
+    const u32 coded = read_word(st, st->d_words + 2);
+    const s32 total = (s32)coded + st->overhead * 4 + 1;
+    st->last_error = BZ3_OK;  // :649
+    if (st->b1 != st->user) {  // :651
+        double t0 = now_ms();
+        HIP_CHECK(hipMemcpyAsync(st->user, st->b1, (size_t)total, hipMemcpyDeviceToDevice, st->stream));
+        HIP_CHECK(hipStreamSynchronize(st->stream));
+        st->t[BZ3_HIP_T_COPY] += (float)(now_ms() - t0);
+    }
+    return total;
+}
+
+// ---- decode ------------------------------------------------------------------------------------
+inline bool sizes_fit(size_t buffer_size, s32 lzp_size, s32 rle_size, s32 orig_size) {  // bz3_check_buffer_size, :114-122
+    const size_t a = lzp_size < 0 ? 0 : (size_t)lzp_size, b = rle_size < 0 ? 0 : (size_t)rle_size, c = orig_size < 0 ? 0 : (size_t)orig_size;
+    return a <= buffer_size && b <= buffer_size && c <= buffer_size;
+}
+
+// hdr: host copy of the first min(17, buffer_size) bytes of the block.
+void decode_front(bz3_state * st, u8 * buf, size_t buffer_size, s32 compressed_size, s32 orig_size, const u8 * hdr) {
+    st->pending = bz3_state::FAILED;
+    if (buffer_size < 9 || buffer_size < (size_t)compressed_size) {  // :658-661 (s32 -> size_t as in the reference)
+        st->last_error = BZ3_ERR_DATA_SIZE_TOO_SMALL;
+        return;
+    }
+    const u32 crc = rd_le32(hdr);
+    const s32 bwt_idx = (s32)rd_le32(hdr + 4);
+    const size_t bound = bz3_bound((size_t)st->block_size);
+    if (compressed_size < 0 || (size_t)compressed_size > bound) {  // :667-670
+        st->last_error = BZ3_ERR_MALFORMED_HEADER;
+        return;
+    }
+    DeviceGuard g(st->device);
+    hipStream_t s = st->stream;
+    for (float & x : st->t) x = 0.f;
+    st->user = buf;
+    st->buffer_size = buffer_size;
+    st->crc = crc;
+    if (bwt_idx == -1) {  // stored block, :672-692
+        if (compressed_size - 8 > 64 || compressed_size < 8) {
+            st->last_error = BZ3_ERR_MALFORMED_HEADER;
+            return;
+        }
+        if ((size_t)(compressed_size - 8) > buffer_size) {
+            st->last_error = BZ3_ERR_DATA_SIZE_TOO_SMALL;
+            return;
+        }
+        st->size = compressed_size - 8;
+        launch(k_unstore_small, dim3(1), dim3(128), 0, s, buf, (u32)st->size);
+        crc32c_device(buf, (u64)st->size, 1u, st->ctx->d_crc, st->d_words, s);
+        st->pending = bz3_state::DEC_STORED;
+        return;
+    }
+    const s32 model = (s8)hdr[8];
+    const size_t need = 9 + (size_t)((model & 2) * 4) + (size_t)((model & 4) * 4);  // :697 (9 / 17 / 25 / 33)
+    if (buffer_size < need) {
+        st->last_error = BZ3_ERR_DATA_SIZE_TOO_SMALL;
+        return;
+    }
+    s32 lzp_size = -1, rle_size = -1, p = 0;
+    if (model & 2) lzp_size = (s32)rd_le32(hdr + 9 + 4 * p++);
+    if (model & 4) rle_size = (s32)rd_le32(hdr + 9 + 4 * p++);
+    p += 2;
+    compressed_size -= p * 4 + 1;
+    if (((model & 2) && (lzp_size < 0 || (size_t)lzp_size > bound)) || ((model & 4) && (rle_size < 0 || (size_t)rle_size > bound))) {  // :710-714
+        st->last_error = BZ3_ERR_MALFORMED_HEADER;
+        return;
+    }
+    if (orig_size < 0 || (size_t)orig_size > bound) {  // :716-719
+        st->last_error = BZ3_ERR_MALFORMED_HEADER;
+        return;
+    }
+    const s32 size_before_bwt = (model & 2) ? lzp_size : (model & 4) ? rle_size : orig_size;  // :724-729
+    if (!sizes_fit(buffer_size, lzp_size, rle_size, orig_size)) {  // :734-737
+        st->last_error = BZ3_ERR_DATA_SIZE_TOO_SMALL;
+        return;
+    }
+    st->bwt_idx = bwt_idx;
+    st->model = model;
+    st->lzp_size = lzp_size;
+    st->rle_size = rle_size;
+    st->orig_size = orig_size;
+    st->size_before_bwt = size_before_bwt;
+    // :742-747 -- the CM kernel runs alone on one CU; other blocks' work overlaps with it
+    HIP_CHECK(hipEventRecord(st->ev0, s));
+    cm_decode(buf + p * 4 + 1, (u32)(compressed_size < 0 ? 0 : compressed_size), st->d_swap, (u32)size_before_bwt, s);
+    HIP_CHECK(hipEventRecord(st->ev1, s));
+    st->pending = bz3_state::DEC_CODED;
+}
+
+s32 decode_finish(bz3_state * st) {
+    const bz3_state::Pending p = st->pending;
+    st->pending = bz3_state::NONE;
+    if (p == bz3_state::FAILED || p == bz3_state::NONE) return -1;
+    DeviceGuard g(st->device);
+    hipStream_t s = st->stream;
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (p == bz3_state::DEC_STORED) {
+        const u32 got = read_word(st, st->d_words + 1);
+        if (got != st->crc) {
+            st->last_error = BZ3_ERR_CRC;
+            return -1;
+        }
+        return st->size;  // last_error untouched (:691)
+    }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, st->ev0, st->ev1) == hipSuccess) st->t[BZ3_HIP_T_CM] = ms;
+    const s32 n = st->size_before_bwt;
+    if (st->bwt_idx > n) {  // :750-753
+        st->last_error = BZ3_ERR_MALFORMED_HEADER;
+        return -1;
+    }
+    std::lock_guard<std::mutex> lk(st->ctx->mu);
+    const size_t bound = bz3_bound((size_t)st->block_size);
+    Arena arena = st->ctx->arena_for(workspace_bytes_for(bound + 64));
+    u8 *b1 = st->d_swap, *b2 = st->user;  // after the swap of :748
+    double t0 = now_ms();
+    // libsais_unbwt's own argument checks (include/libsais.h:5210-5232)
+    if (n <= 1) {
+        if (st->bwt_idx != n) { st->last_error = BZ3_ERR_BWT; return -1; }
+        if (n == 1) HIP_CHECK(hipMemcpyAsync(b2, b1, 1, hipMemcpyDeviceToDevice, s));
+    } else {
+        if (st->bwt_idx <= 0) { st->last_error = BZ3_ERR_BWT; return -1; }
+        bwt_inverse(b1, (u32)n, (u32)st->bwt_idx, b2, arena, s);  // :758
+    }
+    { u8 * tmp = b1; b1 = b2; b2 = tmp; }
+    st->t[BZ3_HIP_T_BWT] = (float)(now_ms() - t0);
+    s32 size_src = n;
+    if (st->model & 2) {  // :767-781
+        t0 = now_ms();
+        size_src = lzp_decode(b1, (u32)st->lzp_size, b2, (u32)bound, arena, s);
+        st->t[BZ3_HIP_T_LZP] = (float)(now_ms() - t0);
+        if (size_src == -1) { st->last_error = BZ3_ERR_CRC; return -1; }
+        if ((size_t)size_src > st->buffer_size) { st->last_error = BZ3_ERR_DATA_SIZE_TOO_SMALL; return -1; }
+        u8 * tmp = b1; b1 = b2; b2 = tmp;
+    }
+    if (st->model & 4) {  // :783-792
+        t0 = now_ms();
+        bool bad = size_src < 32;  // mrled: `if (maxin < 32) return 1`
+        if (!bad) {
+            mrle_decode(b1, (u32)size_src, b2, (u32)st->orig_size, st->d_words + 4, arena, s);
+            bad = read_word(st, st->d_words + 4) != (u32)st->orig_size;
+        }
+        st->t[BZ3_HIP_T_RLE] = (float)(now_ms() - t0);
+        if (bad) { st->last_error = BZ3_ERR_CRC; return -1; }
+        size_src = st->orig_size;
+        u8 * tmp = b1; b1 = b2; b2 = tmp;
+    }
+    st->last_error = BZ3_OK;  // :794
+    if (size_src > st->block_size || size_src < 0) {  // :796-799
+        st->last_error = BZ3_ERR_MALFORMED_HEADER;
+        return -1;
+    }
+    if (b1 != st->user) {  // :801
+        t0 = now_ms();
+        HIP_CHECK(hipMemcpyAsync(st->user, b1, (size_t)size_src, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        st->t[BZ3_HIP_T_COPY] += (float)(now_ms() - t0);
+    }
+    t0 = now_ms();
+    crc32c_device(st->user, (u64)size_src, 1u, st->ctx->d_crc, st->d_words, s);  // :803
+    const u32 got = read_word(st, st->d_words + 1);
+    st->t[BZ3_HIP_T_CRC] = (float)(now_ms() - t0);
+    if (got != st->crc) {
+        st->last_error = BZ3_ERR_CRC;
+        return -1;
+    }
+    return size_src;
+}
+
+template <typename F>
+auto guarded(bz3_state * st, s32 fail_value, F && f) -> decltype(f()) {
+    try {
+        return f();
+    } catch (const HipError & e) {
+        fprintf(stderr, "bzip3_amd: HIP failure '%s' at %s:%d\n", e.what, e.file, e.line);
+        if (st) { st->last_error = BZ3_ERR_BWT; st->pending = bz3_state::NONE; }
+        return (decltype(f()))fail_value;
+    } catch (const std::bad_alloc &) {
+        if (st) { st->last_error = BZ3_ERR_BWT; st->pending = bz3_state::NONE; }
+        return (decltype(f()))fail_value;
+    }
+}
+
+}  // namespace
+
+// =====================================================================================================
+// libbz3.h
+// =====================================================================================================
+extern "C" {
+
+BZIP3_API const char * bz3_version(void) { return "1.5.2-mi355x"; }
+
+BZIP3_API int8_t bz3_last_error(struct bz3_state * state) { return state->last_error; }
+
+BZIP3_API size_t bz3_bound(size_t input_size) { return input_size + input_size / 50 + 32; }
+
+BZIP3_API const char * bz3_strerror(struct bz3_state * state) {  // messages: src/libbz3.c:512-533
+    switch (state->last_error) {
+        case BZ3_OK: return "No error";
+        case BZ3_ERR_OUT_OF_BOUNDS: return "Data index out of bounds";
+        case BZ3_ERR_BWT: return "Burrows-Wheeler transform failed";
+        case BZ3_ERR_CRC: return "CRC32 check failed";
+        case BZ3_ERR_MALFORMED_HEADER: return "Malformed header";
+        case BZ3_ERR_TRUNCATED_DATA: return "Truncated data";
+        case BZ3_ERR_DATA_TOO_BIG: return "Too much data";
+        case BZ3_ERR_DATA_SIZE_TOO_SMALL:
+            return "Size of buffer `buffer_size` passed to the block decoder (bz3_decode_block) is too small. See function docs for details.";
+        default: return "Unknown error";
+    }
+}
+
+BZIP3_API struct bz3_state * bz3_new(int32_t block_size) {
+    if (block_size < KiB65 || block_size > MiB511) return nullptr;  // :536
+    bz3_state * st = nullptr;
+    try {
+        const int dev = pick_device();
+        if (dev < 0) {
+            fprintf(stderr, "bzip3_amd: no HIP device available -- this library has no CPU code path\n");
+            return nullptr;
+        }
+        DeviceCtx * ctx = get_ctx(dev);
+        if (!ctx) return nullptr;
+        st = new bz3_state;
+        st->block_size = block_size;
+        st->device = dev;
+        st->ctx = ctx;
+        HIP_CHECK(hipSetDevice(dev));
+        HIP_CHECK(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreate(&st->ev0));
+        HIP_CHECK(hipEventCreate(&st->ev1));
+        st->cap = (bz3_bound((size_t)block_size) + 4096 + 255) & ~(size_t)255;
+        HIP_CHECK(hipMalloc((void **)&st->d_swap, st->cap));
+        HIP_CHECK(hipMalloc((void **)&st->d_words, 64 * sizeof(u32)));
+        st->last_error = BZ3_OK;
+        return st;
+    } catch (const HipError & e) {
+        fprintf(stderr, "bzip3_amd: bz3_new failed: %s (%s:%d)\n", e.what, e.file, e.line);
+        state_release(st);
+        return nullptr;
+    } catch (const std::bad_alloc &) {
+        state_release(st);
+        return nullptr;
+    }
+}
+
+BZIP3_API void bz3_free(struct bz3_state * state) { state_release(state); }
+
+BZIP3_API size_t bz3_min_memory_needed(int32_t block_size) {
+    if (block_size < KiB65 || block_size > MiB511) return 0;
+    const size_t cap = (bz3_bound((size_t)block_size) + 4096 + 255) & ~(size_t)255;
+    return sizeof(bz3_state) + cap + 64 * sizeof(u32);
+}
+
+// ---- device-resident entry points (bz3_hip.h) -----------------------------------------------------
+BZIP3_API int32_t bz3_hip_encode_block_device(struct bz3_state * st, void * buffer, int32_t size) {
+    return guarded(st, -1, [&]() -> s32 {
+        encode_front(st, (u8 *)buffer, size);
+        return encode_finish(st);
+    });
+}
+
+BZIP3_API int32_t bz3_hip_decode_block_device(struct bz3_state * st, void * buffer, size_t buffer_size, int32_t compressed_size,
+                                              int32_t orig_size) {
+    return guarded(st, -1, [&]() -> s32 {
+        u8 hdr[17] = {0};
+        const size_t take = buffer_size < sizeof hdr ? buffer_size : sizeof hdr;
+        if (take >= 9) {
+            HIP_CHECK(hipSetDevice(st->device));
+            HIP_CHECK(hipMemcpyAsync(hdr, buffer, take, hipMemcpyDeviceToHost, st->stream));
+            HIP_CHECK(hipStreamSynchronize(st->stream));
+        }
+        decode_front(st, (u8 *)buffer, buffer_size, compressed_size, orig_size, hdr);
+        return decode_finish(st);
+    });
+}
+
+BZIP3_API void bz3_hip_encode_blocks_device(struct bz3_state * states[], void * buffers[], int32_t sizes[], int32_t n) {
+    for (s32 i = 0; i < n; i++) guarded(states[i], 0, [&]() -> s32 { encode_front(states[i], (u8 *)buffers[i], sizes[i]); return 0; });
+    for (s32 i = 0; i < n; i++) sizes[i] = guarded(states[i], -1, [&]() -> s32 { return encode_finish(states[i]); });
+}
+
+BZIP3_API void bz3_hip_decode_blocks_device(struct bz3_state * states[], void * buffers[], size_t buffer_sizes[], int32_t sizes[],
+                                            int32_t orig_sizes[], int32_t n) {
+    for (s32 i = 0; i < n; i++)
+        guarded(states[i], 0, [&]() -> s32 {
+            bz3_state * st = states[i];
+            u8 hdr[17] = {0};
+            const size_t take = buffer_sizes[i] < sizeof hdr ? buffer_sizes[i] : sizeof hdr;
+            if (take >= 9) {
+                HIP_CHECK(hipSetDevice(st->device));
+                HIP_CHECK(hipMemcpyAsync(hdr, buffers[i], take, hipMemcpyDeviceToHost, st->stream));
+                HIP_CHECK(hipStreamSynchronize(st->stream));
+            }
+            decode_front(st, (u8 *)buffers[i], buffer_sizes[i], sizes[i], orig_sizes[i], hdr);
+            return 0;
+        });
+    for (s32 i = 0; i < n; i++) guarded(states[i], -1, [&]() -> s32 { return decode_finish(states[i]); });
+}
+
+// ---- host-buffer entry points (libbz3.h) ------------------------------------------------------------
+BZIP3_API int32_t bz3_encode_block(struct bz3_state * st, uint8_t * buffer, int32_t size) {
+    return guarded(st, -1, [&]() -> s32 {
+        if (size > st->block_size || size < 0) {
+            st->last_error = BZ3_ERR_DATA_TOO_BIG;
+            return -1;
+        }
+        HIP_CHECK(hipSetDevice(st->device));
+        ensure_io(st);
+        double t0 = now_ms();
+        HIP_CHECK(hipMemcpyAsync(st->d_io, buffer, (size_t)size, hipMemcpyHostToDevice, st->stream));
+        HIP_CHECK(hipStreamSynchronize(st->stream));
+        const float h2d = (float)(now_ms() - t0);
+        encode_front(st, st->d_io, size);
+        const s32 r = encode_finish(st);
+        if (r > 0) {
+            t0 = now_ms();
+            HIP_CHECK(hipMemcpyAsync(buffer, st->d_io, (size_t)r, hipMemcpyDeviceToHost, st->stream));
+            HIP_CHECK(hipStreamSynchronize(st->stream));
+            st->t[BZ3_HIP_T_COPY] += h2d + (float)(now_ms() - t0);
+        }
+        return r;
+    });
+}
+
+BZIP3_API int32_t bz3_decode_block(struct bz3_state * st, uint8_t * buffer, size_t buffer_size, int32_t compressed_size, int32_t orig_size) {
+    return guarded(st, -1, [&]() -> s32 {
+        // the size checks that protect the H2D copy are the reference's first two (:658, :667)
+        if (buffer_size < 9 || buffer_size < (size_t)compressed_size) {
+            st->last_error = BZ3_ERR_DATA_SIZE_TOO_SMALL;
+            return -1;
+        }
+        if (compressed_size < 0 || (size_t)compressed_size > bz3_bound((size_t)st->block_size)) {
+            st->last_error = BZ3_ERR_MALFORMED_HEADER;
+            return -1;
+        }
+        HIP_CHECK(hipSetDevice(st->device));
+        ensure_io(st);
+        u8 hdr[17] = {0};
+        memcpy(hdr, buffer, buffer_size < sizeof hdr ? buffer_size : sizeof hdr);
+        double t0 = now_ms();
+        HIP_CHECK(hipMemcpyAsync(st->d_io, buffer, (size_t)compressed_size, hipMemcpyHostToDevice, st->stream));
+        HIP_CHECK(hipStreamSynchronize(st->stream));
+        const float h2d = (float)(now_ms() - t0);
+        decode_front(st, st->d_io, buffer_size, compressed_size, orig_size, hdr);
+        const s32 r = decode_finish(st);
+        if (r > 0) {
+            t0 = now_ms();
+            HIP_CHECK(hipMemcpyAsync(buffer, st->d_io, (size_t)r, hipMemcpyDeviceToHost, st->stream));
+            HIP_CHECK(hipStreamSynchronize(st->stream));
+            st->t[BZ3_HIP_T_COPY] += h2d + (float)(now_ms() - t0);
+        }
+        return r;
+    });
+}
+
+BZIP3_API void bz3_encode_blocks(struct bz3_state * states[], uint8_t * buffers[], int32_t sizes[], int32_t n) {
+    // upload everything, run all front halves (CM kernels pile up on their streams), join, download
+    for (s32 i = 0; i < n; i++)
+        guarded(states[i], 0, [&]() -> s32 {
+            bz3_state * st = states[i];
+            st->pending = bz3_state::FAILED;
+            if (sizes[i] > st->block_size || sizes[i] < 0) { st->last_error = BZ3_ERR_DATA_TOO_BIG; return 0; }
+            HIP_CHECK(hipSetDevice(st->device));
+            ensure_io(st);
+            HIP_CHECK(hipMemcpyAsync(st->d_io, buffers[i], (size_t)sizes[i], hipMemcpyHostToDevice, st->stream));
+            HIP_CHECK(hipStreamSynchronize(st->stream));
+            encode_front(st, st->d_io, sizes[i]);
+            return 0;
+        });
+    for (s32 i = 0; i < n; i++)
+        sizes[i] = guarded(states[i], -1, [&]() -> s32 {
+            bz3_state * st = states[i];
+            const s32 r = encode_finish(st);
+            if (r > 0) {
+                HIP_CHECK(hipMemcpyAsync(buffers[i], st->d_io, (size_t)r, hipMemcpyDeviceToHost, st->stream));
+                HIP_CHECK(hipStreamSynchronize(st->stream));
+            }
+            return r;
+        });
+}
+
+BZIP3_API void bz3_decode_blocks(struct bz3_state * states[], uint8_t * buffers[], size_t buffer_sizes[], int32_t sizes[], int32_t orig_sizes[],
+                                 int32_t n) {
+    for (s32 i = 0; i < n; i++)
+        guarded(states[i], 0, [&]() -> s32 {
+            bz3_state * st = states[i];
+            st->pending = bz3_state::FAILED;
+            if (buffer_sizes[i] < 9 || buffer_sizes[i] < (size_t)sizes[i]) { st->last_error = BZ3_ERR_DATA_SIZE_TOO_SMALL; return 0; }
+            if (sizes[i] < 0 || (size_t)sizes[i] > bz3_bound((size_t)st->block_size)) { st->last_error = BZ3_ERR_MALFORMED_HEADER; return 0; }
+            HIP_CHECK(hipSetDevice(st->device));
+            ensure_io(st);
+            u8 hdr[17] = {0};
+            memcpy(hdr, buffers[i], buffer_sizes[i] < sizeof hdr ? buffer_sizes[i] : sizeof hdr);
+            HIP_CHECK(hipMemcpyAsync(st->d_io, buffers[i], (size_t)sizes[i], hipMemcpyHostToDevice, st->stream));
+            HIP_CHECK(hipStreamSynchronize(st->stream));
+            decode_front(st, st->d_io, buffer_sizes[i], sizes[i], orig_sizes[i], hdr);
+            return 0;
+        });
+    for (s32 i = 0; i < n; i++)
+        guarded(states[i], -1, [&]() -> s32 {
+            bz3_state * st = states[i];
+            const s32 r = decode_finish(st);
+            if (r > 0) {
+                HIP_CHECK(hipMemcpyAsync(buffers[i], st->d_io, (size_t)r, hipMemcpyDeviceToHost, st->stream));
+                HIP_CHECK(hipStreamSynchronize(st->stream));
+            }
+            return r;
+        });
+}
+
+// ---- frame API (src/libbz3.c:876-997): thin loops over the block API, same header and error codes ----
+BZIP3_API int bz3_compress(uint32_t block_size, const uint8_t * in, uint8_t * out, size_t in_size, size_t * out_size) {
+    if (block_size > in_size) block_size = (uint32_t)bz3_bound(in_size);  // :877
+    block_size = block_size <= (uint32_t)KiB65 ? (uint32_t)KiB65 : block_size;
+    struct bz3_state * state = bz3_new((int32_t)block_size);
+    if (!state) return BZ3_ERR_INIT;
+    u8 * cbuf = (u8 *)malloc(bz3_bound(block_size));
+    if (!cbuf) { bz3_free(state); return BZ3_ERR_INIT; }
+    const size_t buf_max = *out_size;
+    *out_size = 0;
+    u32 n_blocks = (u32)(in_size / block_size);
+    if (in_size % block_size) n_blocks++;
+    if (buf_max < 13 || buf_max < bz3_bound(in_size)) { bz3_free(state); free(cbuf); return BZ3_ERR_DATA_TOO_BIG; }
+    memcpy(out, "BZ3v1", 5);
+    wr_le32(out + 5, block_size);
+    wr_le32(out + 9, n_blocks);
+    *out_size += 13;
+    size_t in_off = 0;
+    for (u32 i = 0; i < n_blocks; i++) {
+        s32 size = (s32)block_size;
+        if (i == n_blocks - 1) size = (s32)(in_size % block_size);  // (sic) :914 -- 0 when in_size is a multiple
+        memcpy(cbuf, in + in_off, (size_t)size);
+        const s32 osz = bz3_encode_block(state, cbuf, size);
+        if (bz3_last_error(state) != BZ3_OK) {
+            const s8 e = state->last_error;
+            bz3_free(state); free(cbuf);
+            return e;
+        }
+        memcpy(out + *out_size + 8, cbuf, (size_t)osz);
+        wr_le32(out + *out_size, (u32)osz);
+        wr_le32(out + *out_size + 4, (u32)size);
+        *out_size += (size_t)osz + 8;
+        in_off += (size_t)size;
+    }
+    bz3_free(state);
+    free(cbuf);
+    return BZ3_OK;
+}
+
+BZIP3_API int bz3_decompress(const uint8_t * in, uint8_t * out, size_t in_size, size_t * out_size) {
+    if (in_size < 13) return BZ3_ERR_MALFORMED_HEADER;
+    if (memcmp(in, "BZ3v1", 5) != 0) return BZ3_ERR_MALFORMED_HEADER;
+    const u32 block_size = rd_le32(in + 5);
+    const u32 n_blocks = rd_le32(in + 9);
+    in_size -= 13;
+    in += 13;
+    struct bz3_state * state = bz3_new((int32_t)block_size);
+    if (!state) return BZ3_ERR_INIT;
+    const size_t cap = bz3_bound(block_size);
+    u8 * cbuf = (u8 *)malloc(cap);
+    if (!cbuf) { bz3_free(state); return BZ3_ERR_INIT; }
+    const size_t buf_max = *out_size;
+    *out_size = 0;
+    for (u32 i = 0; i < n_blocks; i++) {
+        if (in_size < 8) { bz3_free(state); free(cbuf); return BZ3_ERR_MALFORMED_HEADER; }
+        const s32 size = (s32)rd_le32(in);
+        if (size < 0 || (u32)size > block_size) { bz3_free(state); free(cbuf); return BZ3_ERR_MALFORMED_HEADER; }
+        if (in_size < (size_t)size + 8) { bz3_free(state); free(cbuf); return BZ3_ERR_TRUNCATED_DATA; }
+        const s32 orig_size = (s32)rd_le32(in + 4);
+        if (orig_size < 0) { bz3_free(state); free(cbuf); return BZ3_ERR_MALFORMED_HEADER; }
+        if (buf_max < *out_size + (size_t)orig_size) { bz3_free(state); free(cbuf); return BZ3_ERR_DATA_TOO_BIG; }
+        memcpy(cbuf, in + 8, (size_t)size);
+        bz3_decode_block(state, cbuf, cap, size, orig_size);
+        if (bz3_last_error(state) != BZ3_OK) {
+            const s8 e = state->last_error;
+            bz3_free(state); free(cbuf);
+            return e;
+        }
+        memcpy(out + *out_size, cbuf, (size_t)orig_size);
+        *out_size += (size_t)orig_size;
+        in += size + 8;
+        in_size -= (size_t)size + 8;
+    }
+    bz3_free(state);
+    free(cbuf);
+    return BZ3_OK;
+}
+
+BZIP3_API int bz3_orig_size_sufficient_for_decode(const uint8_t * block, size_t block_size, int32_t orig_size) {  // :1025-1055
+    if (block_size < 9) return -1;
+    const s32 bwt_idx = (s32)rd_le32(block + 4);
+    if (bwt_idx == -1) return 1;
+    const s32 model = (s8)block[8];
+    const size_t need = 9 + (size_t)((model & 2) * 4) + (size_t)((model & 4) * 4);
+    if (block_size < need) return -1;
+    s32 lzp_size = -1, rle_size = -1;
+    size_t off = 9;
+    if (model & 2) { lzp_size = (s32)rd_le32(block + off); off += 4; }
+    if (model & 4) rle_size = (s32)rd_le32(block + off);
+    return sizes_fit((size_t)orig_size, lzp_size, rle_size, orig_size) ? 1 : 0;
+}
+
+// ---- bz3_hip.h: device control, timings ----------------------------------------------------------------
+BZIP3_API int bz3_hip_device_count(void) { return device_count(); }
+
+BZIP3_API int bz3_hip_bind_device(int device) {
+    if (device < -1 || device >= device_count()) return -1;
+    g_bound_device.store(device);
+    return 0;
+}
+
+BZIP3_API int bz3_hip_state_device(struct bz3_state * st) { return st->device; }
+
+BZIP3_API void bz3_hip_last_timings(struct bz3_state * st, float ms[BZ3_HIP_T_COUNT]) {
+    for (int i = 0; i < BZ3_HIP_T_COUNT; i++) ms[i] = st->t[i];
+}
+
+BZIP3_API void bz3_hip_last_bwt_stats(struct bz3_state * st, int32_t * rounds, int32_t * radix_passes, uint64_t * sorted_elements) {
+    if (rounds) *rounds = st->bwt.rounds;
+    if (radix_passes) *radix_passes = st->bwt.radix_passes;
+    if (sorted_elements) *sorted_elements = st->bwt.sorted_elements;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// stage hooks on host buffers (tests / profiling)
+// =====================================================================================================
+namespace {
+
+struct StageEnv {
+    DeviceCtx * ctx = nullptr;
+    hipStream_t s = nullptr;
+    std::vector<void *> allocs;
+    std::unique_lock<std::mutex> lock;
+    StageEnv() {
+        int dev = pick_device();
+        if (dev < 0) {
+            fprintf(stderr, "bzip3_amd: no HIP device available -- this library has no CPU code path\n");
+            abort();
+        }
+        ctx = get_ctx(dev);
+        HIP_CHECK(hipSetDevice(dev));
+        HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        lock = std::unique_lock<std::mutex>(ctx->mu);
+    }
+    ~StageEnv() {
+        (void)hipStreamSynchronize(s);
+        for (void * p : allocs) (void)hipFree(p);
+        (void)hipStreamDestroy(s);
+    }
+    u8 * dev(size_t bytes, const void * init = nullptr, size_t init_bytes = 0) {
+        void * p = nullptr;
+        HIP_CHECK(hipMalloc(&p, bytes + 4096));
+        allocs.push_back(p);
+        if (init && init_bytes) HIP_CHECK(hipMemcpy(p, init, init_bytes, hipMemcpyHostToDevice));
+        return (u8 *)p;
+    }
+    void down(void * host, const void * d, size_t bytes) {
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (bytes) HIP_CHECK(hipMemcpy(host, d, bytes, hipMemcpyDeviceToHost));
+    }
+    u32 word(const u32 * d) {
+        u32 v = 0;
+        down(&v, d, 4);
+        return v;
+    }
+};
+
+template <typename F>
+auto stage_guard(F && f) -> decltype(f()) {
+    try {
+        return f();
+    } catch (const HipError & e) {
+        fprintf(stderr, "bzip3_amd: HIP failure '%s' at %s:%d\n", e.what, e.file, e.line);
+        abort();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+BZIP3_API uint32_t bz3_hip_stage_crc32c(const uint8_t * data, size_t n, uint32_t init) {
+    return stage_guard([&]() -> u32 {
+        StageEnv e;
+        u8 * d = e.dev(n + 16, data, n);
+        u32 * w = (u32 *)e.dev(64);
+        crc32c_device(d, n, init, e.ctx->d_crc, w, e.s);
+        return e.word(w + 1);
+    });
+}
+
+BZIP3_API int32_t bz3_hip_stage_mrle_encode(const uint8_t * in, int32_t n, uint8_t * out) {
+    return stage_guard([&]() -> s32 {
+        StageEnv e;
+        u8 * d = e.dev((size_t)n + 16, in, (size_t)n);
+        u8 * o = e.dev((size_t)n + 64);
+        Arena a = e.ctx->arena_for(workspace_bytes_for((u64)n + 64));
+        MrleEncScratch sc;
+        mrle_encode_size(d, (u32)n, sc, a, e.s);
+        const s32 size = (s32)(32u + e.word(sc.total));
+        mrle_encode_write(d, (u32)n, sc, o, e.s);
+        e.down(out, o, (size_t)size);
+        return size;
+    });
+}
+
+BZIP3_API int bz3_hip_stage_mrle_decode(const uint8_t * in, uint8_t * out, int32_t outlen, int32_t maxin) {
+    return stage_guard([&]() -> int {
+        if (maxin < 32) return 1;
+        StageEnv e;
+        u8 * d = e.dev((size_t)maxin + 16, in, (size_t)maxin);
+        u8 * o = e.dev((size_t)outlen + 64);
+        u32 * w = (u32 *)e.dev(64);
+        Arena a = e.ctx->arena_for(workspace_bytes_for((u64)maxin + 64));
+        mrle_decode(d, (u32)maxin, o, (u32)outlen, w, a, e.s);
+        const u32 got = e.word(w);
+        e.down(out, o, (size_t)(got < (u32)outlen ? got : (u32)outlen));
+        return got != (u32)outlen;
+    });
+}
+
+BZIP3_API int32_t bz3_hip_stage_lzp_encode(const uint8_t * in, int32_t n, uint8_t * out) {
+    return stage_guard([&]() -> s32 {
+        StageEnv e;
+        u8 * d = e.dev((size_t)n + 64, in, (size_t)n);
+        u8 * o = e.dev((size_t)n + 64);
+        Arena a = e.ctx->arena_for(workspace_bytes_for((u64)n + 64));
+        const s32 r = lzp_encode(d, (u32)n, o, a, e.s);
+        if (r > 0) e.down(out, o, (size_t)r);
+        return r;
+    });
+}
+
+BZIP3_API int32_t bz3_hip_stage_lzp_decode(const uint8_t * in, int32_t n, uint8_t * out, int32_t max) {
+    return stage_guard([&]() -> s32 {
+        StageEnv e;
+        u8 * d = e.dev((size_t)n + 64, in, (size_t)n);
+        u8 * o = e.dev((size_t)max + 64);
+        Arena a = e.ctx->arena_for(workspace_bytes_for((u64)n + 64));
+        const s32 r = lzp_decode(d, (u32)n, o, (u32)max, a, e.s);
+        if (r > 0) e.down(out, o, (size_t)r);
+        return r;
+    });
+}
+
+BZIP3_API int32_t bz3_hip_stage_bwt(const uint8_t * in, uint8_t * out, int32_t n) {
+    return stage_guard([&]() -> s32 {
+        StageEnv e;
+        u8 * d = e.dev((size_t)n + 64, in, (size_t)n);
+        u8 * o = e.dev((size_t)n + 64);
+        Arena a = e.ctx->arena_for(workspace_bytes_for((u64)n + 64));
+        const s32 idx = bwt_forward(d, (u32)n, o, a, e.s, nullptr);
+        e.down(out, o, (size_t)n);
+        return idx;
+    });
+}
+
+BZIP3_API int32_t bz3_hip_stage_unbwt(const uint8_t * in, uint8_t * out, int32_t n, int32_t idx) {
+    return stage_guard([&]() -> s32 {
+        if (n < 0) return -1;
+        if (n <= 1) {
+            if (idx != n) return -1;
+            if (n == 1) out[0] = in[0];
+            return 0;
+        }
+        if (idx <= 0 || idx > n) return -1;
+        StageEnv e;
+        u8 * d = e.dev((size_t)n + 64, in, (size_t)n);
+        u8 * o = e.dev((size_t)n + 64);
+        Arena a = e.ctx->arena_for(workspace_bytes_for((u64)n + 64));
+        bwt_inverse(d, (u32)n, (u32)idx, o, a, e.s);
+        e.down(out, o, (size_t)n);
+        return 0;
+    });
+}
+
+BZIP3_API int32_t bz3_hip_stage_cm_encode(const uint8_t * in, int32_t n, uint8_t * out) {
+    return stage_guard([&]() -> s32 {
+        StageEnv e;
+        u8 * d = e.dev((size_t)n + 64, in, (size_t)n);
+        u8 * o = e.dev(bz3_bound((size_t)n) + 64);
+        u32 * w = (u32 *)e.dev(64);
+        cm_encode(d, (u32)n, o, w, e.s);
+        const s32 size = (s32)e.word(w);
+        e.down(out, o, (size_t)size);
+        return size;
+    });
+}
+
+BZIP3_API void bz3_hip_stage_cm_decode(const uint8_t * in, int32_t in_size, uint8_t * out, int32_t n) {
+    stage_guard([&]() -> int {
+        StageEnv e;
+        u8 * d = e.dev((size_t)in_size + 64, in, (size_t)in_size);
+        u8 * o = e.dev((size_t)n + 64);
+        cm_decode(d, (u32)in_size, o, (u32)n, e.s);
+        e.down(out, o, (size_t)n);
+        return 0;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,218 @@
+// bwt.hip -- forward Burrows-Wheeler transform of one block on gfx950.
+// Replaces libsais_bwt (reference include/libsais.h:4095-4121, SA-IS: :3941-3983, :3740-3939), which
+// is a sequential induced-sorting algorithm whose inner scans carry a dependency through 256 bucket
+// cursors.  This is NOT a port of it: the suffix array is built by prefix doubling on top of the
+// stable LSD radix sorter of sort.hip, which is the HBM-streaming formulation the MI355X wants.
+//
+//   round 0 : key(i) = big-endian 8-byte prefix of suffix i (zero padded); sort all n (8 passes)
+//   round h : every suffix still sharing its h-prefix with another one ("active") gets the 64-bit key
+//             (group << 32) | rank(i + h); only the active elements are sorted, written back to their
+//             group's slots, re-grouped, and the now-unique ones are dropped.  h doubles: 8, 16, 32...
+//   rank(j) : position of the head of j's group in the current order, + h;   past-the-end suffixes
+//             get n-1-i (< h), so that a suffix that is a proper prefix of another sorts first and two
+//             such suffixes order by length -- exactly the order libsais produces.
+//   output  : U[0] = T[n-1]; U[i < i0 ? i+1 : i] = T[SA[i]-1] for i != i0 = rank of suffix 0; idx = i0+1.
+//
+// HBM layout per block of n bytes (carved from the per-device workspace):
+//   SA u32[n], ISA u32[n], 2 x key u64[m], 2 x suffix u32[m], 2 x slot u32[m], 2 x flag/scan u32[m]
+// Algorithmic traffic: 11 B per input byte; implementation traffic is
+// radix passes x 32 B per sorted element and is reported through BwtStats.
+#include "prims.hpp"
+#include "sort.hpp"
+#include "stages.hpp"
+
+namespace bz3 {
+
+constexpr int BW_BLOCK = 256;
+
+__device__ __forceinline__ u64 bswap64(u64 v) {
+    v = ((v & 0x00FF00FF00FF00FFull) << 8) | ((v >> 8) & 0x00FF00FF00FF00FFull);
+    v = ((v & 0x0000FFFF0000FFFFull) << 16) | ((v >> 16) & 0x0000FFFF0000FFFFull);
+    return (v << 32) | (v >> 32);
+}
+
+__device__ __forceinline__ u64 load_be64_padded(const u8 * __restrict__ t, u64 i, u64 n) {
+    if (i + 8 <= n && ((reinterpret_cast<uintptr_t>(t) + i) & 7) == 0) return bswap64(*reinterpret_cast<const u64 *>(t + i));
+    u64 v = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v = (v << 8) | (i + k < n ? (u64)t[i + k] : 0ull);
+    return v;
+}
+
+// 8 keys per thread from two aligned 8-byte loads.
+__global__ void __launch_bounds__(BW_BLOCK) k_bwt_prefix_keys(const u8 * __restrict__ t, u32 n, u64 * __restrict__ keys) {
+    const u64 base = ((u64)blockIdx.x * BW_BLOCK + threadIdx.x) * 8;
+    if (base >= n) return;
+    const u64 a = load_be64_padded(t, base, n);
+    const u64 b = load_be64_padded(t, base + 8, n);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (base + k < n) keys[base + k] = k == 0 ? a : ((a << (8 * k)) | (b >> (64 - 8 * k)));
+    }
+}
+
+// flags[k] = 1 if sorted element k starts a new group (its key differs from its predecessor's).
+__global__ void __launch_bounds__(BW_BLOCK) k_bwt_head_flags(const u64 * __restrict__ keys, u32 m, u32 * __restrict__ flags) {
+    const u32 k = blockIdx.x * BW_BLOCK + threadIdx.x;
+    if (k < m) flags[k] = (k == 0 || keys[k] != keys[k - 1]) ? 1u : 0u;
+}
+
+// headslot[dense group id] = slot of the group head.  `excl` = exclusive scan of the head flags.
+__global__ void __launch_bounds__(BW_BLOCK) k_bwt_head_slots(const u64 * __restrict__ keys, const u32 * __restrict__ excl, const u32 * __restrict__ slots, u32 m,
+                                                            u32 * __restrict__ headslot) {
+    const u32 k = blockIdx.x * BW_BLOCK + threadIdx.x;
+    if (k >= m) return;
+    if (k == 0 || keys[k] != keys[k - 1]) headslot[excl[k]] = slots ? slots[k] : k;
+}
+
+// Writes SA / ISA for every sorted element and flags the ones that stay active (group size > 1).
+__global__ void __launch_bounds__(BW_BLOCK) k_bwt_assign(const u64 * __restrict__ keys, const u32 * __restrict__ vals, const u32 * __restrict__ excl,
+                                                        const u32 * __restrict__ slots, const u32 * __restrict__ headslot, u32 m, u32 * __restrict__ sa,
+                                                        u32 * __restrict__ isa, u32 * __restrict__ keep) {
+    const u32 k = blockIdx.x * BW_BLOCK + threadIdx.x;
+    if (k >= m) return;
+    const u64 key = keys[k];
+    const bool head = (k == 0 || key != keys[k - 1]);
+    const bool next_head = (k + 1 == m) || keys[k + 1] != key;
+    const u32 gid = excl[k] + (head ? 1u : 0u) - 1u;
+    const u32 v = vals[k];
+    sa[slots ? slots[k] : k] = v;
+    isa[v] = headslot[gid];
+    keep[k] = (head && next_head) ? 0u : 1u;
+}
+
+// Stream compaction of the still-active elements.  `excl` = exclusive scan of keep flags, which are
+// re-derived from the keys (the scan overwrote them).
+__global__ void __launch_bounds__(BW_BLOCK) k_bwt_compact(const u64 * __restrict__ keys, const u32 * __restrict__ vals, const u32 * __restrict__ slots,
+                                                         const u32 * __restrict__ excl, u32 m, u32 * __restrict__ vals_out, u32 * __restrict__ slots_out) {
+    const u32 k = blockIdx.x * BW_BLOCK + threadIdx.x;
+    if (k >= m) return;
+    const u64 key = keys[k];
+    const bool head = (k == 0 || key != keys[k - 1]);
+    const bool next_head = (k + 1 == m) || keys[k + 1] != key;
+    if (head && next_head) return;
+    const u32 j = excl[k];
+    vals_out[j] = vals[k];
+    slots_out[j] = slots ? slots[k] : k;
+}
+
+// key(k) = (group of suffix s) << 32 | rank of suffix s + h   (s = vals[k])
+__global__ void __launch_bounds__(BW_BLOCK) k_bwt_doubling_keys(const u32 * __restrict__ vals, const u32 * __restrict__ isa, u32 m, u32 n, u32 h,
+                                                               u64 * __restrict__ keys) {
+    const u32 k = blockIdx.x * BW_BLOCK + threadIdx.x;
+    if (k >= m) return;
+    const u32 s = vals[k];
+    const u64 j = (u64)s + h;
+    const u32 lo = (j < n) ? isa[j] + h : (n - 1u - s);
+    keys[k] = ((u64)isa[s] << 32) | lo;
+}
+
+__global__ void __launch_bounds__(BW_BLOCK) k_bwt_emit(const u8 * __restrict__ t, const u32 * __restrict__ sa, const u32 * __restrict__ isa, u32 n,
+                                                      u8 * __restrict__ out, u32 * __restrict__ idx_out) {
+    const u32 i = blockIdx.x * BW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const u32 i0 = isa[0];
+    if (i == 0) {
+        out[0] = t[n - 1];
+        *idx_out = i0 + 1;
+    }
+    if (i != i0) out[i < i0 ? i + 1 : i] = t[sa[i] - 1];
+}
+
+static int bits_for(u64 x) {
+    int b = 0;
+    while (x) { b++; x >>= 1; }
+    return b ? b : 1;
+}
+
+size_t bwt_workspace_bytes(u64 n) {
+    // SA + ISA + 2 keys + 2 vals + 2 slots + 2 scan arrays + radix temp + slack
+    return n * (4 + 4 + 16 + 8 + 8 + 8) + radix_temp_bytes(n) + scan_temp_words(n) * 4 + (1u << 20);
+}
+
+s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, BwtStats * stats) {
+    if (n == 0) return 0;
+    if (n == 1) {
+        HIP_CHECK(hipMemcpyAsync(d_out, d_in, 1, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        return 1;
+    }
+    const size_t mk = tmp.mark();
+    u32 * sa = tmp.take<u32>(n);
+    u32 * isa = tmp.take<u32>(n);
+    u64 * key[2] = {tmp.take<u64>(n), tmp.take<u64>(n)};
+    u32 * val[2] = {tmp.take<u32>(n), tmp.take<u32>(n)};
+    u32 * slot[2] = {tmp.take<u32>(n), tmp.take<u32>(n)};
+    u32 * scanA = tmp.take<u32>(n);
+    u32 * headslot = tmp.take<u32>(n);
+    u32 * d_words = tmp.take<u32>(4);  // [0] = scan total, [1] = primary index
+    BwtStats st;
+
+    auto grid = [](u64 m) { return dim3((u32)((m + BW_BLOCK - 1) / BW_BLOCK)); };
+
+    // ---- round 0: all suffixes by their 8-byte prefix ------------------------------------------
+    launch(k_bwt_prefix_keys, grid(((u64)n + 7) / 8), dim3(BW_BLOCK), 0, s, d_in, n, key[0]);
+    int cur = 0;
+    {
+        // first pass generates the suffix numbers on the fly (iota), later passes carry them
+        radix_pass<u64>(key[0], key[1], (const u32 *)nullptr, val[1], n, 0, 0xFFFFFFFFu, 0u, tmp, s);
+        cur = 1;
+        for (int shift = 8; shift < 64; shift += 8) {
+            radix_pass<u64>(key[cur], key[cur ^ 1], (const u32 *)val[cur], val[cur ^ 1], n, shift, 0xFFFFFFFFu, 0u, tmp, s);
+            cur ^= 1;
+        }
+        st.radix_passes += 8;
+        st.sorted_elements += n;
+    }
+    u32 m = n;              // elements in the current (sorted) active list
+    const u32 * slots = nullptr;  // nullptr = identity (round 0 covers every slot)
+    int scur = 0;           // slot[scur] holds the slots of the active list (when slots != nullptr)
+    u32 h = 8;
+    for (;;) {
+        st.rounds++;
+        // ---- regroup the freshly sorted list, publish SA/ISA, drop the singletons ---------------
+        launch(k_bwt_head_flags, grid(m), dim3(BW_BLOCK), 0, s, (const u64 *)key[cur], m, scanA);
+        exclusive_scan_u32(scanA, m, nullptr, tmp, s);
+        launch(k_bwt_head_slots, grid(m), dim3(BW_BLOCK), 0, s, (const u64 *)key[cur], (const u32 *)scanA, slots, m, headslot);
+        u32 * keep = val[cur ^ 1];  // free buffer at this point
+        launch(k_bwt_assign, grid(m), dim3(BW_BLOCK), 0, s, (const u64 *)key[cur], (const u32 *)val[cur], (const u32 *)scanA, slots, (const u32 *)headslot, m,
+               sa, isa, keep);
+        exclusive_scan_u32(keep, m, d_words, tmp, s);
+        u32 m_next = 0;
+        HIP_CHECK(hipMemcpyAsync(&m_next, d_words, 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (m_next == 0) break;
+        // compact into (scanA as vals, slot[scur^1]) -- scanA is free again after k_bwt_assign
+        launch(k_bwt_compact, grid(m), dim3(BW_BLOCK), 0, s, (const u64 *)key[cur], (const u32 *)val[cur], slots, (const u32 *)keep, m, scanA,
+               slot[scur ^ 1]);
+        scur ^= 1;
+        slots = slot[scur];
+        m = m_next;
+        // active suffix list now lives in scanA; move it into val[0] and build the doubling keys in key[0]
+        HIP_CHECK(hipMemcpyAsync(val[0], scanA, (size_t)m * 4, hipMemcpyDeviceToDevice, s));
+        launch(k_bwt_doubling_keys, grid(m), dim3(BW_BLOCK), 0, s, (const u32 *)val[0], (const u32 *)isa, m, n, h, key[0]);
+        const int lo_bits = bits_for((u64)n + h);
+        const int hi_bits = bits_for(n);
+        cur = radix_sort_pairs<u64>(key[0], key[1], val[0], val[1], m, 0, lo_bits, tmp, s);
+        int passes = (lo_bits + 7) / 8;
+        {
+            // continue on the high word from whichever buffer holds the data
+            const int c2 = radix_sort_pairs<u64>(key[cur], key[cur ^ 1], val[cur], val[cur ^ 1], m, 32, 32 + hi_bits, tmp, s);
+            cur ^= c2;
+            passes += (hi_bits + 7) / 8;
+        }
+        st.radix_passes += passes;
+        st.sorted_elements += m;
+        if (h >= 0x40000000u) throw HipError{hipErrorUnknown, "suffix sort did not converge", __FILE__, __LINE__};
+        h *= 2;
+    }
+    launch(k_bwt_emit, grid(n), dim3(BW_BLOCK), 0, s, d_in, (const u32 *)sa, (const u32 *)isa, n, d_out, d_words + 1);
+    u32 idx = 0;
+    HIP_CHECK(hipMemcpyAsync(&idx, d_words + 1, 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    tmp.release(mk);
+    if (stats) *stats = st;
+    return (s32)idx;
+}
+
+}  // namespace bz3

@@ -1,0 +1,160 @@
+// prims.hpp -- wave64 / workgroup building blocks shared by every kernel file.
+// gfx950 wavefronts are 64 lanes wide; every constant below is written for that width.
+#pragma once
+#include "hipx.hpp"
+
+namespace bz3 {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// Ordering point between the lanes of ONE wave (e.g. "all lanes read, then leaders write" on LDS).
+// On the GPU a wave runs in lockstep and LDS operations of a wave complete in order, so this is only
+// a compiler scheduling fence; under the test emulation (independent fibers) it is a real rendezvous.
+__device__ __forceinline__ void wave_sync() {
+#ifdef BZ3_EMU
+    emu::wave_barrier();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_add(T v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        T t = __shfl_up(v, (unsigned)d);
+        if (l >= d) v += t;
+    }
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_max(T v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        T t = __shfl_up(v, (unsigned)d);
+        if (l >= d && t > v) v = t;
+    }
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        T t = __shfl_xor(v, d);
+        if (t > v) v = t;
+    }
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        T t = __shfl_xor(v, d);
+        if (t < v) v = t;
+    }
+    return v;
+}
+__device__ __forceinline__ u32 wave_xor(u32 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v ^= __shfl_xor(v, d);
+    return v;
+}
+
+// Workgroup exclusive prefix sum of one value per thread.  `lds` needs BLOCK/64 + 1 words.
+// Returns the exclusive prefix; `total` receives the workgroup sum.  Ends with a barrier so
+// `lds` may be reused immediately.
+template <int BLOCK, typename T>
+__device__ __forceinline__ T block_excl_add(T v, T * lds, T & total) {
+    constexpr int NW = BLOCK / WAVE;
+    const T incl = wave_incl_add(v);
+    if (lane_id() == WAVE - 1) lds[wave_id()] = incl;
+    __syncthreads();
+    if (wave_id() == 0) {
+        T x = lane_id() < NW ? lds[lane_id()] : (T)0;
+        T xs = wave_incl_add(x);
+        if (lane_id() < NW) lds[lane_id()] = xs - x;
+        if (lane_id() == NW - 1) lds[NW] = xs;
+    }
+    __syncthreads();
+    const T r = incl - v + lds[wave_id()];
+    total = lds[NW];
+    __syncthreads();
+    return r;
+}
+
+// Workgroup inclusive running maximum (one value per thread).  `lds` needs BLOCK/64 words.
+template <int BLOCK, typename T>
+__device__ __forceinline__ T block_incl_max(T v, T * lds) {
+    constexpr int NW = BLOCK / WAVE;
+    T incl = wave_incl_max(v);
+    if (lane_id() == WAVE - 1) lds[wave_id()] = incl;
+    __syncthreads();
+    T carry = 0;
+    for (int w = 0; w < wave_id(); w++) {
+        T t = lds[w];
+        if (t > carry) carry = t;
+    }
+    __syncthreads();
+    (void)NW;
+    return incl > carry ? incl : carry;
+}
+
+template <int BLOCK, typename T>
+__device__ __forceinline__ T block_sum(T v, T * lds) {
+    constexpr int NW = BLOCK / WAVE;
+    v = wave_sum(v);
+    if (lane_id() == 0) lds[wave_id()] = v;
+    __syncthreads();
+    T r = 0;
+    for (int w = 0; w < NW; w++) r += lds[w];
+    __syncthreads();
+    return r;
+}
+template <int BLOCK, typename T>
+__device__ __forceinline__ T block_min(T v, T * lds) {
+    constexpr int NW = BLOCK / WAVE;
+    v = wave_min(v);
+    if (lane_id() == 0) lds[wave_id()] = v;
+    __syncthreads();
+    T r = lds[0];
+    for (int w = 1; w < NW; w++) r = lds[w] < r ? lds[w] : r;
+    __syncthreads();
+    return r;
+}
+template <int BLOCK, typename T>
+__device__ __forceinline__ T block_max(T v, T * lds) {
+    constexpr int NW = BLOCK / WAVE;
+    v = wave_max(v);
+    if (lane_id() == 0) lds[wave_id()] = v;
+    __syncthreads();
+    T r = lds[0];
+    for (int w = 1; w < NW; w++) r = lds[w] > r ? lds[w] : r;
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ u32 load_le32(const u8 * p) {
+    return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24);
+}
+__device__ __forceinline__ u32 load_be32(const u8 * p) {
+    return ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3];
+}
+
+inline u32 ceil_div(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+
+}  // namespace bz3

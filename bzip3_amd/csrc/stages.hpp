@@ -1,0 +1,65 @@
+// stages.hpp -- host-side entry points of the per-stage HIP pipelines (all asynchronous on a stream
+// unless stated).  One function per reference stage; api.cpp strings them together exactly in the
+// order of bz3_encode_block / bz3_decode_block (reference src/libbz3.c:585-654, :656-809).
+#pragma once
+#include "hipx.hpp"
+#include "sort.hpp"
+
+namespace bz3 {
+
+// ---- CRC-32C (crc32c.hip) -- replaces crc32sum, src/libbz3.c:69-72 ---------------------------
+struct CrcTables {
+    u32 pow2[64];  // x^(2^b) mod P
+    u32 lane[64];  // x^(32*(63-l)) mod P
+    u32 row;       // x^2048 mod P
+    u32 pad[3];
+};
+void crc_build_tables(CrcTables & t);  // host
+// Result is left in d_scratch[1] (d_scratch: 2 words).
+void crc32c_device(const u8 * d_data, u64 n, u32 init, const CrcTables * d_tables, u32 * d_scratch, hipStream_t s);
+
+// ---- mRLE (mrle.hip) -- replaces mrlec / mrled, src/libbz3.c:264-329 -------------------------
+struct MrleEncScratch {
+    u32 tiles = 0;
+    u32 * carry = nullptr;
+    u32 * tile_sum = nullptr;
+    s32 * gain = nullptr;
+    u32 * total = nullptr;  // device word: encoded size - 32
+};
+// Pass 1: decides the flagged symbols and the encoded size (sc.total, device).  Scratch is carved from
+// `tmp` and stays valid until the caller releases it.
+void mrle_encode_size(const u8 * d_in, u32 n, MrleEncScratch & sc, Arena & tmp, hipStream_t s);
+// Pass 2: writes the 32-byte bitmap + encoded bytes.
+void mrle_encode_write(const u8 * d_in, u32 n, const MrleEncScratch & sc, u8 * d_out, hipStream_t s);
+// Decodes m stream bytes into at most outlen bytes; *d_total = bytes produced (capped at outlen).
+void mrle_decode(const u8 * d_enc, u32 m, u8 * d_out, u32 outlen, u32 * d_total, Arena & tmp, hipStream_t s);
+
+// ---- LZP (lzp.hip) -- replaces lzp_compress / lzp_decompress, src/libbz3.c:124-257 -----------
+// Synchronous (host reads match statistics between phases).  Returns the encoded size or -1.
+s32 lzp_encode(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s);
+// Returns the decoded size or -1.  d_out must hold `max_out` bytes.
+s32 lzp_decode(const u8 * d_in, u32 n, u8 * d_out, u32 max_out, Arena & tmp, hipStream_t s);
+
+// ---- BWT (bwt.hip) -- replaces libsais_bwt, include/libsais.h:4095-4121 ----------------------
+// Synchronous.  Returns the primary index (>= 1).  Rounds/active statistics are reported for profiling.
+struct BwtStats {
+    int rounds = 0;
+    u64 sorted_elements = 0;  // sum over rounds of elements that went through the radix sorter
+    int radix_passes = 0;
+};
+s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, BwtStats * stats);
+size_t bwt_workspace_bytes(u64 n);
+
+// ---- inverse BWT (unbwt.hip) -- replaces libsais_unbwt, include/libsais.h:5260-5262 ----------
+// Synchronous.  idx must already be validated (0 < idx <= n).
+void bwt_inverse(const u8 * d_in, u32 n, u32 idx, u8 * d_out, Arena & tmp, hipStream_t s);
+size_t unbwt_workspace_bytes(u64 n);
+
+// ---- CM coder (cm.hip) -- replaces begin/encode_bytes/decode_bytes, src/libbz3.c:333-494 -----
+// One workgroup per block, model resident in LDS.  Asynchronous.
+// encode: d_out receives the coded bytes, *d_out_size the byte count.
+void cm_encode(const u8 * d_in, u32 n, u8 * d_out, u32 * d_out_size, hipStream_t s);
+// decode: reads `in_size` coded bytes (reads past the end yield 0xFF.. like read_in, :345).
+void cm_decode(const u8 * d_in, u32 in_size, u8 * d_out, u32 n, hipStream_t s);
+
+}  // namespace bz3

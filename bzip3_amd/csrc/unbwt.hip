@@ -1,0 +1,174 @@
+// unbwt.hip -- inverse Burrows-Wheeler transform of one block on gfx950.
+// Replaces libsais_unbwt (reference include/libsais.h:5260-5262; init :4593-4617, decode :4618-4636),
+// which builds a bigram psi table and then follows ONE dependent pointer chain of n/2 steps.
+//
+// Here:
+//   1. psi is built by ONE stable radix pass (sort.hip) over the BWT bytes: the row of the k-th byte
+//      (rows are 1-based around a virtual sentinel row inserted at `idx`; row 0 is the empty suffix)
+//      is scattered to slot 1 + (stable rank by symbol); psi[0] = idx closes the cycle.
+//      T[i] = F[psi^i(idx)], where F[row] is recovered from the 257-entry cumulative symbol table.
+//   2. The single chain is cut at pseudo-random splitter rows (a multiplicative hash of the row
+//      number, plus rows idx and 0).  One lane per splitter walks to the next splitter and records
+//      the segment length (latency-bound, ~n/1024-way parallel random 4-byte reads).
+//   3. The ~n/1024-element splitter list is ranked by pointer jumping (log2 rounds, tiny).
+//   4. Each lane re-walks its segment and writes the text bytes at their now-known positions.
+// HBM layout: psi u32[n+1], splitter-id u32[n+1], a few arrays of n/1024 words.
+// Algorithmic traffic: 11 B per byte; the walks are random 4-byte reads.
+#include "prims.hpp"
+#include "sort.hpp"
+#include "stages.hpp"
+
+namespace bz3 {
+
+constexpr int UB_BLOCK = 256;
+
+__device__ __forceinline__ bool ub_is_splitter(u32 row, u32 idx, int log_stride) {
+    if (row == 0 || row == idx || log_stride == 0) return true;
+    return ((row * 0x9E3779B1u) >> (32 - log_stride)) == 0u;
+}
+
+__global__ void __launch_bounds__(UB_BLOCK) k_ub_hist(const u8 * __restrict__ in, u32 n, u32 * __restrict__ hist) {
+    __shared__ u32 bins[256];
+    bins[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 stride = (u64)gridDim.x * UB_BLOCK;
+    for (u64 i = (u64)blockIdx.x * UB_BLOCK + threadIdx.x; i < n; i += stride) atomicAdd(&bins[in[i]], 1u);
+    __syncthreads();
+    if (bins[threadIdx.x]) atomicAdd(&hist[threadIdx.x], bins[threadIdx.x]);
+}
+
+// cum[c] = 1 + number of bytes smaller than c; cum[256] = n + 1.  Also closes the cycle psi[0] = idx.
+__global__ void __launch_bounds__(256) k_ub_cum(const u32 * __restrict__ hist, u32 * __restrict__ cum, u32 * __restrict__ psi, u32 idx) {
+    __shared__ u32 lds[256 / WAVE + 1];
+    u32 tot;
+    u32 pre = block_excl_add<256>(hist[threadIdx.x], lds, tot);
+    cum[threadIdx.x] = pre + 1;
+    if (threadIdx.x == 0) {
+        cum[256] = tot + 1;
+        psi[0] = idx;
+    }
+}
+
+__global__ void __launch_bounds__(UB_BLOCK) k_ub_flags(u32 rows, u32 idx, int log_stride, u32 * __restrict__ flags) {
+    const u32 r = blockIdx.x * UB_BLOCK + threadIdx.x;
+    if (r < rows) flags[r] = ub_is_splitter(r, idx, log_stride) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(UB_BLOCK) k_ub_collect(u32 rows, u32 idx, int log_stride, const u32 * __restrict__ sid, u32 * __restrict__ split_row) {
+    const u32 r = blockIdx.x * UB_BLOCK + threadIdx.x;
+    if (r < rows && ub_is_splitter(r, idx, log_stride)) split_row[sid[r]] = r;
+}
+
+// Walk 1: segment length and successor splitter of every splitter.
+__global__ void __launch_bounds__(UB_BLOCK) k_ub_walk_len(const u32 * __restrict__ psi, const u32 * __restrict__ sid, const u32 * __restrict__ split_row, u32 nsplit,
+                                                         u32 idx, int log_stride, u32 rows, u32 * __restrict__ succ, u32 * __restrict__ dist) {
+    const u32 j = blockIdx.x * UB_BLOCK + threadIdx.x;
+    if (j >= nsplit) return;
+    u32 r = split_row[j];
+    if (r == 0) {  // terminal of the list: row 0 is the empty suffix, nothing is emitted for it
+        succ[j] = j;
+        dist[j] = 0;
+        return;
+    }
+    u32 len = 0;
+    do {
+        r = psi[r];
+        len++;
+    } while (!ub_is_splitter(r, idx, log_stride) && len <= rows);
+    succ[j] = sid[r];
+    dist[j] = len;
+}
+
+// One pointer-jumping round: dist = distance to the terminal, succ = 2^k-th successor.
+__global__ void __launch_bounds__(UB_BLOCK) k_ub_jump(const u32 * __restrict__ succ_in, const u32 * __restrict__ dist_in, u32 nsplit, u32 * __restrict__ succ_out,
+                                                     u32 * __restrict__ dist_out) {
+    const u32 j = blockIdx.x * UB_BLOCK + threadIdx.x;
+    if (j >= nsplit) return;
+    const u32 sj = succ_in[j];
+    u64 d = (u64)dist_in[j] + dist_in[sj];
+    dist_out[j] = d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)d;
+    succ_out[j] = succ_in[sj];
+}
+
+// Walk 2: emit the text of every segment.  seg_len was saved before the jumping rounds.
+__global__ void __launch_bounds__(UB_BLOCK) k_ub_walk_emit(const u32 * __restrict__ psi, const u32 * __restrict__ split_row, const u32 * __restrict__ seg_len,
+                                                          const u32 * __restrict__ dist, const u32 * __restrict__ cum, u32 nsplit, u32 n, u8 * __restrict__ out) {
+    __shared__ u32 c[257];
+    for (int k = threadIdx.x; k < 257; k += UB_BLOCK) c[k] = cum[k];
+    __syncthreads();
+    const u32 j = blockIdx.x * UB_BLOCK + threadIdx.x;
+    if (j >= nsplit) return;
+    u32 r = split_row[j];
+    const u32 len = seg_len[j];
+    const u32 d = dist[j];
+    if (d > n) return;  // not on the chain that reaches the terminal (only possible for corrupt input)
+    u64 pos = (u64)n - d;
+    for (u32 t = 0; t < len; t++) {
+        const u32 nr = psi[r];  // issue the dependent load first; the symbol search below overlaps it
+        // F[r]: largest symbol s with c[s] <= r   (r >= 1 here: row 0 is never emitted)
+        u32 lo = 0, hi = 256;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const u32 mid = (lo + hi) >> 1;
+            if (c[mid] <= r) lo = mid; else hi = mid;
+        }
+        if (pos < n) out[pos] = (u8)lo;
+        pos++;
+        r = nr;
+    }
+}
+
+size_t unbwt_workspace_bytes(u64 n) { return (n + 64) * 8 + radix_temp_bytes(n) + scan_temp_words(n + 1) * 4 + ((n >> 8) + 4096) * 32 + (1u << 20); }
+
+void bwt_inverse(const u8 * d_in, u32 n, u32 idx, u8 * d_out, Arena & tmp, hipStream_t s) {
+    if (n == 0) return;
+    if (n == 1) {
+        HIP_CHECK(hipMemcpyAsync(d_out, d_in, 1, hipMemcpyDeviceToDevice, s));
+        return;
+    }
+    const size_t mk = tmp.mark();
+    const u32 rows = n + 1;
+    u32 * psi = tmp.take<u32>(rows);
+    u32 * sid = tmp.take<u32>(rows);
+    u32 * hist = tmp.take<u32>(256);
+    u32 * cum = tmp.take<u32>(257);
+    u32 * d_total = tmp.take<u32>(1);
+
+    // 1. psi by one stable radix pass: value of byte k is its row k + (k >= idx), destination base 1
+    HIP_CHECK(hipMemsetAsync(hist, 0, 256 * 4, s));
+    launch(k_ub_hist, dim3(1024), dim3(UB_BLOCK), 0, s, d_in, n, hist);
+    launch(k_ub_cum, dim3(1), dim3(256), 0, s, (const u32 *)hist, cum, psi, idx);
+    radix_pass<u8>(d_in, (u8 *)nullptr, (const u32 *)nullptr, psi, n, 0, idx, 1u, tmp, s);
+
+    // 2. splitters
+    int log_stride = 0;
+    while (log_stride < 10 && ((u64)rows >> (log_stride + 1)) >= 65536) log_stride++;
+    const dim3 grows((rows + UB_BLOCK - 1) / UB_BLOCK);
+    launch(k_ub_flags, grows, dim3(UB_BLOCK), 0, s, rows, idx, log_stride, sid);
+    exclusive_scan_u32(sid, rows, d_total, tmp, s);
+    u32 nsplit = 0;
+    HIP_CHECK(hipMemcpyAsync(&nsplit, d_total, 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    u32 * split_row = tmp.take<u32>(nsplit);
+    u32 * seg_len = tmp.take<u32>(nsplit);
+    u32 * succ[2] = {tmp.take<u32>(nsplit), tmp.take<u32>(nsplit)};
+    u32 * dist[2] = {tmp.take<u32>(nsplit), tmp.take<u32>(nsplit)};
+    const dim3 gs((nsplit + UB_BLOCK - 1) / UB_BLOCK);
+    launch(k_ub_collect, grows, dim3(UB_BLOCK), 0, s, rows, idx, log_stride, (const u32 *)sid, split_row);
+    launch(k_ub_walk_len, gs, dim3(UB_BLOCK), 0, s, (const u32 *)psi, (const u32 *)sid, (const u32 *)split_row, nsplit, idx, log_stride, rows, succ[0], dist[0]);
+    HIP_CHECK(hipMemcpyAsync(seg_len, dist[0], (size_t)nsplit * 4, hipMemcpyDeviceToDevice, s));
+
+    // 3. rank the splitter list
+    int cur = 0;
+    for (u64 span = 1; span < nsplit; span <<= 1) {
+        launch(k_ub_jump, gs, dim3(UB_BLOCK), 0, s, (const u32 *)succ[cur], (const u32 *)dist[cur], nsplit, succ[cur ^ 1], dist[cur ^ 1]);
+        cur ^= 1;
+    }
+    // 4. emit
+    launch(k_ub_walk_emit, gs, dim3(UB_BLOCK), 0, s, (const u32 *)psi, (const u32 *)split_row, (const u32 *)seg_len, (const u32 *)dist[cur], (const u32 *)cum, nsplit, n,
+           d_out);
+    HIP_CHECK(hipStreamSynchronize(s));
+    tmp.release(mk);
+}
+
+}  // namespace bz3

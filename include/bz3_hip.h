@@ -1,0 +1,70 @@
+/*
+ * bz3_hip.h -- extensions of the libbz3.h C ABI that only make sense for a GPU backend.
+ * Plain C, plain pointers and sizes; no torch / HIP types in any signature (device memory is passed
+ * as void* addresses, e.g. torch.Tensor.data_ptr()).
+ *
+ *  - device-resident block entry points: same contract as bz3_encode_block(s)/bz3_decode_block(s)
+ *    (reference src/libbz3.c:585-654, :656-809, :845-870) but `buffer` is a DEVICE pointer, so a
+ *    pipeline that already has its data in HBM (or bench.py) skips the PCIe hops;
+ *  - device selection for the multi-GPU block sharding of SURVEY.md section 8e;
+ *  - per-stage entry points on host buffers, used by the parity tests to diff each HIP stage
+ *    against its reference stage (crc32sum, mrlec, mrled, lzp_compress, lzp_decompress,
+ *    libsais_bwt, libsais_unbwt, encode_bytes, decode_bytes);
+ *  - per-stage timings of the last block a state processed.
+ */
+#ifndef BZ3_HIP_H
+#define BZ3_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#include "libbz3.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Number of usable HIP devices (0 when the runtime finds none). */
+BZIP3_API int bz3_hip_device_count(void);
+/* Pin every state created afterwards BY THIS PROCESS to `device` (>= 0), or restore round-robin (-1).
+ * Returns 0, or -1 for an invalid device.  Environment BZ3_HIP_DEVICE=<n> has the same effect. */
+BZIP3_API int bz3_hip_bind_device(int device);
+/* Device a state is bound to. */
+BZIP3_API int bz3_hip_state_device(struct bz3_state * state);
+
+/* Device-resident variants: `buffer` / `buffers[i]` are device addresses on the state's GPU with the
+ * same capacities the host API requires (bz3_bound(size) for encode; buffer_size for decode). */
+BZIP3_API int32_t bz3_hip_encode_block_device(struct bz3_state * state, void * buffer, int32_t size);
+BZIP3_API int32_t bz3_hip_decode_block_device(struct bz3_state * state, void * buffer, size_t buffer_size, int32_t compressed_size,
+                                              int32_t orig_size);
+BZIP3_API void bz3_hip_encode_blocks_device(struct bz3_state * states[], void * buffers[], int32_t sizes[], int32_t n);
+BZIP3_API void bz3_hip_decode_blocks_device(struct bz3_state * states[], void * buffers[], size_t buffer_sizes[], int32_t sizes[],
+                                            int32_t orig_sizes[], int32_t n);
+
+/* Stage timings (milliseconds) of the last block processed by `state`. */
+enum {
+    BZ3_HIP_T_CRC = 0,
+    BZ3_HIP_T_RLE = 1,
+    BZ3_HIP_T_LZP = 2,
+    BZ3_HIP_T_BWT = 3,
+    BZ3_HIP_T_CM = 4,   /* CM kernel alone, measured with HIP events on the state's stream */
+    BZ3_HIP_T_COPY = 5, /* host<->device and device<->device block copies */
+    BZ3_HIP_T_COUNT = 8
+};
+BZIP3_API void bz3_hip_last_timings(struct bz3_state * state, float ms[BZ3_HIP_T_COUNT]);
+/* BWT statistics of the last encoded block: doubling rounds, radix passes, elements pushed through the sorter. */
+BZIP3_API void bz3_hip_last_bwt_stats(struct bz3_state * state, int32_t * rounds, int32_t * radix_passes, uint64_t * sorted_elements);
+
+/* ---- per-stage hooks on HOST buffers (tests / profiling).  Return values mirror the reference stage. */
+BZIP3_API uint32_t bz3_hip_stage_crc32c(const uint8_t * data, size_t n, uint32_t init);             /* crc32sum        */
+BZIP3_API int32_t bz3_hip_stage_mrle_encode(const uint8_t * in, int32_t n, uint8_t * out);          /* mrlec           */
+BZIP3_API int bz3_hip_stage_mrle_decode(const uint8_t * in, uint8_t * out, int32_t outlen, int32_t maxin); /* mrled    */
+BZIP3_API int32_t bz3_hip_stage_lzp_encode(const uint8_t * in, int32_t n, uint8_t * out);           /* lzp_compress    */
+BZIP3_API int32_t bz3_hip_stage_lzp_decode(const uint8_t * in, int32_t n, uint8_t * out, int32_t max); /* lzp_decompress */
+BZIP3_API int32_t bz3_hip_stage_bwt(const uint8_t * in, uint8_t * out, int32_t n);                  /* libsais_bwt     */
+BZIP3_API int32_t bz3_hip_stage_unbwt(const uint8_t * in, uint8_t * out, int32_t n, int32_t idx);   /* libsais_unbwt   */
+BZIP3_API int32_t bz3_hip_stage_cm_encode(const uint8_t * in, int32_t n, uint8_t * out);            /* encode_bytes    */
+BZIP3_API void bz3_hip_stage_cm_decode(const uint8_t * in, int32_t in_size, uint8_t * out, int32_t n); /* decode_bytes  */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

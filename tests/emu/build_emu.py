@@ -1,0 +1,45 @@
+"""TEST INFRASTRUCTURE ONLY.  Compiles the kernel sources of bzip3_amd/csrc with g++ against the fiber
+emulation of the HIP execution model (tests/emu/hip_emu.hpp, -DBZ3_EMU) into
+tests/emu/libbz3_emu_TESTONLY.so, so kernel logic can be diffed against the oracle on a machine
+without a GPU.  The bzip3_amd package never loads this library."""
+import hashlib
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "bzip3_amd", "csrc")
+OUT = os.path.join(HERE, "libbz3_emu_TESTONLY.so")
+SOURCES = ["sort.hip", "crc32c.hip", "mrle.hip", "lzp.hip", "bwt.hip", "unbwt.hip", "cm.hip", "api.hip"]
+
+
+def build():
+    srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "hip_emu.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(HERE, "hip_emu.hpp")]
+    deps += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    h = hashlib.sha256()
+    for p in sorted(deps):
+        h.update(open(p, "rb").read())
+    stamp = OUT + ".sha"
+    if os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == h.hexdigest():
+        return OUT
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for s in srcs:
+        o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
+        objs.append(o)
+        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DBZ3_EMU", "-I", HERE, "-I", CSRC, "-x", "c++", "-c", s, "-o", o,
+               "-Wno-unknown-pragmas", "-Wno-attributes"]
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"emu build failed for {s}:\n{out}")
+    subprocess.check_call(["g++", "-shared", "-o", OUT, *objs, "-lpthread"])
+    open(stamp, "w").write(h.hexdigest())
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build())
