@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_mrle_emit(const u8 * __restrict__ 
 }
 
 void mrle_encode_size(const u8 * d_in, u32 n, MrleEncScratch & sc, Arena & tmp, hipStream_t s) {
-    const u32 tiles = (n + MR_TILE - 1) / MR_TILE;
+    const u32 tiles = n ? (n + MR_TILE - 1) / MR_TILE : 1u;  // at least one workgroup: it writes the bitmap header
     sc.tiles = tiles;
     sc.carry = tmp.take<u32>(tiles + 1);
     sc.tile_sum = tmp.take<u32>(tiles + 1);

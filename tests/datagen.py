@@ -1,0 +1,173 @@
+"""Deterministic input generators shared by the tests and bench.py.
+
+  text(n, seed)     "enwik-style" stand-in: parallel word-bigram Markov chains over the tokens of
+                    shakespeare.txt (the plaintext of the reference's only fixture, recovered by decoding
+                    tests/golden/shakespeare.txt.bz3 with the oracle -- /root/reference is never read).
+  random_bytes      xorshift-free numpy PCG stream (incompressible: LZP declines, RLE declines).
+  low_entropy       skewed order-1 source over 16 symbols with short repeat units (LZP/RLE decline,
+                    BWT sees long LCPs): the cfg5 stand-in.
+  repeats           a 4 KiB paragraph repeated with a few random edits per copy (LZP collapses it).
+"""
+import hashlib
+import os
+import struct
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SHAKESPEARE_MD5 = "d2028225a89d8b0b3093dddb720da91f"
+_cache = {}
+
+
+def shakespeare():
+    """Plaintext of tests/golden/shakespeare.txt.bz3 decoded with the ORACLE (2 chunks, 4 MiB blocks)."""
+    if "txt" in _cache:
+        return _cache["txt"]
+    cache_file = "/tmp/bz3_shakespeare_%s.txt" % SHAKESPEARE_MD5[:8]
+    if os.path.exists(cache_file):
+        data = open(cache_file, "rb").read()
+        if hashlib.md5(data).hexdigest() == SHAKESPEARE_MD5:
+            _cache["txt"] = data
+            return data
+    from oracle_lib import Oracle
+
+    o = Oracle()
+    raw = open(os.path.join(GOLDEN, "shakespeare.txt.bz3"), "rb").read()
+    assert raw[:5] == b"BZ3v1"
+    (bs,) = struct.unpack("<I", raw[5:9])
+    pos, out = 9, []
+    while pos < len(raw):
+        comp, orig = struct.unpack("<II", raw[pos : pos + 8])
+        n, err, dec = o.decode_block(raw[pos + 8 : pos + 8 + comp], orig, bs)
+        assert n == orig and err == 0
+        out.append(dec)
+        pos += 8 + comp
+    data = b"".join(out)
+    assert hashlib.md5(data).hexdigest() == SHAKESPEARE_MD5
+    try:
+        open(cache_file, "wb").write(data)
+    except OSError:
+        pass
+    _cache["txt"] = data
+    return data
+
+
+def parse_chunks(raw):
+    """Split a .bz3 file (CLI format, doc/bzip3_format.md) into (block_size, [(comp, orig, block bytes)])."""
+    assert raw[:5] == b"BZ3v1"
+    (bs,) = struct.unpack("<I", raw[5:9])
+    pos, chunks = 9, []
+    while pos < len(raw):
+        comp, orig = struct.unpack("<II", raw[pos : pos + 8])
+        chunks.append((comp, orig, raw[pos + 8 : pos + 8 + comp]))
+        pos += 8 + comp
+    return bs, chunks
+
+
+def bigram_tables():
+    """Token table of shakespeare.txt for the Markov text generator (numpy arrays)."""
+    if "tab" in _cache:
+        return _cache["tab"]
+    words = shakespeare().split()
+    vocab, inv = np.unique(np.array(words, dtype=object), return_inverse=True)
+    inv = inv.astype(np.int64)
+    order = np.argsort(inv[:-1], kind="stable")  # successors grouped by predecessor token
+    succ = inv[1:][order]
+    counts = np.bincount(inv[:-1], minlength=len(vocab)).astype(np.int64)
+    start = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    # tokens without a successor (only the last word) restart from token 0
+    counts_safe = np.where(counts == 0, 1, counts)
+    lens = np.array([len(w) + 1 for w in vocab], dtype=np.int64)  # word + one space
+    blob = np.frombuffer(b"".join(w + b" " for w in vocab), dtype=np.uint8)
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    tab = dict(succ=succ, start=start, counts=counts_safe, lens=lens, blob=blob, off=off, nvocab=len(vocab))
+    _cache["tab"] = tab
+    return tab
+
+
+def text(n, seed=1, chains=2048):
+    """n bytes of Markov text.  `chains` independent chains are generated in lockstep and concatenated."""
+    t = bigram_tables()
+    rng = np.random.Generator(np.random.PCG64(seed))
+    avg = float(t["lens"].mean())
+    steps = int(n / (avg * chains) * 1.25) + 8
+    state = rng.integers(0, t["nvocab"], size=chains)
+    toks = np.empty((steps, chains), dtype=np.int64)
+    for s in range(steps):
+        r = rng.integers(0, 1 << 30, size=chains)
+        state = t["succ"][(t["start"][state] + r % t["counts"][state]) % len(t["succ"])]
+        toks[s] = state
+    toks = toks.T.reshape(-1)  # chain-major: each chain's words are contiguous
+    lens = t["lens"][toks]
+    ends = np.cumsum(lens)
+    total = int(ends[-1])
+    if total < n:
+        return (text(n, seed, chains) if False else (np.tile(_emit(t, toks, lens, ends), n // total + 1)[:n])).tobytes()
+    return _emit(t, toks, lens, ends)[:n].tobytes()
+
+
+def _emit(t, toks, lens, ends):
+    starts = ends - lens
+    total = int(ends[-1])
+    tok_of_byte = np.repeat(np.arange(len(toks)), lens)
+    within = np.arange(total) - starts[tok_of_byte]
+    return t["blob"][t["off"][toks[tok_of_byte]] + within]
+
+
+def random_bytes(n, seed=2):
+    return np.random.Generator(np.random.PCG64(seed)).integers(0, 256, size=n, dtype=np.uint8).tobytes()
+
+
+def low_entropy(n, seed=3):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    units = [bytes(rng.integers(97, 113, size=int(rng.integers(3, 24))).astype(np.uint8)) for _ in range(64)]
+    p = rng.dirichlet(np.full(64, 0.3))
+    out, size = [], 0
+    while size < n:
+        picks = rng.choice(64, size=4096, p=p)
+        chunk = b"".join(units[k] for k in picks)
+        out.append(chunk)
+        size += len(chunk)
+    return b"".join(out)[:n]
+
+
+def repeats(n, seed=4):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    para = bytearray(text(4096, seed=seed + 100, chains=4))
+    out, size = [], 0
+    while size < n:
+        p = bytearray(para)
+        for _ in range(4):
+            p[int(rng.integers(0, len(p)))] = int(rng.integers(97, 123))
+        out.append(bytes(p))
+        size += len(p)
+    return b"".join(out)[:n]
+
+
+def nasty_cases():
+    """Small adversarial inputs for the byte filters (runs around 255/256/510, 0xF2 escapes, near-misses)."""
+    rng = np.random.Generator(np.random.PCG64(7))
+    cases = {
+        "empty": b"",
+        "one": b"x",
+        "63": bytes(range(63)),
+        "64": bytes(range(64)),
+        "65": bytes(range(65)),
+        "zeros300": b"\0" * 300,
+        "runs": b"".join(bytes([65 + (i % 5)]) * L for i, L in enumerate([1, 2, 3, 254, 255, 256, 257, 509, 510, 511, 512, 765, 766, 1, 1, 2])),
+        "f2": (b"a" * 1000 + b"\xf2" * 600 + b"xyz" * 200) * 3,
+        "f2text": bytes(rng.choice(np.frombuffer(b"ab\xf2 \xf2cd", dtype=np.uint8), size=5000)),
+        "ab": bytes(rng.choice(np.frombuffer(b"ab", dtype=np.uint8), size=6000)),
+        "banana": b"banana" * 50,
+        "tailzeros": b"q" * 100 + b"\0" * 9,
+        "period7": b"abcdefg" * 900,
+    }
+    t = shakespeare()
+    cases["nearmiss"] = (t[:3000] * 5) + t[5000:9000] + t[:3000]
+    holes = bytearray(t[10000:14000] * 6)
+    for k in range(0, len(holes), 53):
+        holes[k] = 35 + (k % 7)
+    cases["holes"] = bytes(holes)
+    cases["ff"] = b"\xff" * 700 + b"\xfe" * 300 + b"\xff" * 255
+    return cases

@@ -1,0 +1,91 @@
+"""CPU tests of the drop-in boundary: the product .so loads, exports every symbol include/*.h declares,
+its pure host-side entry points behave like the reference's, and it refuses to work without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import bzip3_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = []
+    for h in ("libbz3.h", "bz3_hip.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names += re.findall(r"BZIP3_API\s+[^;(]*?\b(bz3_\w+)\s*\(", src)
+    return sorted(set(names))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from bzip3_amd.build import build
+
+    build()  # hipcc cross-compiles gfx950 without a GPU
+    return bzip3_amd.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    names = _declared_symbols()
+    ref14 = ["bz3_version", "bz3_last_error", "bz3_strerror", "bz3_new", "bz3_free", "bz3_bound", "bz3_compress", "bz3_decompress",
+             "bz3_min_memory_needed", "bz3_encode_block", "bz3_decode_block", "bz3_encode_blocks", "bz3_decode_blocks",
+             "bz3_orig_size_sufficient_for_decode"]  # include/libbz3.h:62-235 of the reference
+    assert set(ref14) <= set(names)
+    assert len(names) >= 14 + 15
+    raw = C.CDLL(bzip3_amd.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"libbzip3.so does not export {n}"
+
+
+def test_pure_host_entry_points(lib, ref_lib):
+    for n in (0, 1, 49, 50, 64, 65 * 1024, 1 << 20, (511 << 20)):
+        assert lib.bz3_bound(n) == n + n // 50 + 32 == ref_lib.lib.bz3_bound(n)
+    assert lib.bz3_version().startswith(b"1.5.2")
+    assert lib.bz3_min_memory_needed(1000) == 0 == ref_lib.lib.bz3_min_memory_needed(1000)
+    assert lib.bz3_min_memory_needed((511 << 20) + 1) == 0
+    assert lib.bz3_min_memory_needed(1 << 20) > lib.bz3_bound(1 << 20)
+    # bz3_orig_size_sufficient_for_decode: header-only logic (src/libbz3.c:1025-1055)
+    import struct
+    hdrs = [struct.pack("<IiB", 1, -1, 0), struct.pack("<IiBI", 1, 5, 2, 1000), struct.pack("<IiBII", 1, 5, 6, 900, 1200),
+            struct.pack("<IiBI", 1, 5, 4, 5000), b"\0" * 8, struct.pack("<IiB", 1, 5, 6) + b"\0" * 7]
+    for h in hdrs:
+        for orig in (0, 999, 1000, 1200, 10 ** 6):
+            buf = (C.c_uint8 * max(1, len(h))).from_buffer_copy(h)
+            assert lib.bz3_orig_size_sufficient_for_decode(buf, len(h), orig) == ref_lib.lib.bz3_orig_size_sufficient_for_decode(buf, len(h), orig)
+
+
+def test_block_size_validation_needs_no_device(lib):
+    assert not lib.bz3_new(65 * 1024 - 1)
+    assert not lib.bz3_new((511 << 20) + 1)
+
+
+def test_fails_loudly_without_gpu(lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert lib.bz3_hip_device_count() == 0
+    assert not lib.bz3_new(1 << 20)  # NULL, never a CPU fallback
+    with pytest.raises(RuntimeError):
+        bzip3_amd.State(1 << 20)
+    out = (C.c_size_t)(100)
+    src = (C.c_uint8 * 100)()
+    dst = (C.c_uint8 * 1000)()
+    assert lib.bz3_compress(1 << 20, src, dst, 100, C.byref(out)) == bzip3_amd.BZ3_ERR_INIT
+
+
+def test_missing_extension_raises(tmp_path):
+    with pytest.raises(RuntimeError):
+        bzip3_amd.load(str(tmp_path / "nope.so"))
+
+
+def test_product_never_touches_the_oracle():
+    # only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "bzip3_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                s = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in s and "oracle_lib" not in s and "libbz3ref" not in s and "libbz3_emu" not in s, f

@@ -1,0 +1,120 @@
+"""CPU tests of the kernel LOGIC: the sources of bzip3_amd/csrc compiled against the test-only fiber
+emulation of the HIP execution model (tests/emu), diffed against the oracle stage by stage and end to
+end.  This is test infrastructure for a GPU-less container; the product library has no CPU path and the
+real parity tests are the -m gpu ones."""
+import ctypes as C
+import os
+import sys
+
+import pytest
+
+import bzip3_amd
+import datagen
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    from build_emu import build
+
+    lib = bzip3_amd._declare(C.CDLL(build()))
+    return lib
+
+
+CASES = dict(datagen.nasty_cases())
+CASES["text20k"] = datagen.shakespeare()[300000:320000]
+CASES["rand9k"] = datagen.random_bytes(9000)
+CASES["lowent"] = datagen.low_entropy(12000)
+CASES["repeats"] = datagen.repeats(30000)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_stage_parity(emu, oracle, name):
+    d = CASES[name]
+    g = bzip3_amd.StageApi(emu)
+    for k in {len(d), max(0, len(d) - 1), max(0, len(d) - 3), min(len(d), 5)}:
+        assert g.crc32c(d[:k]) == oracle.crc32c(d[:k])
+    e = oracle.mrle_encode(d)
+    assert g.mrle_encode(d) == e
+    assert g.mrle_decode(e, len(d)) == (0, d)
+    for cut in (len(e) - 1, len(e) - 2, 40):
+        if 32 <= cut <= len(e):
+            a, b = g.mrle_decode(e, len(d), cut), oracle.mrle_decode(e, len(d), cut)
+            assert a[0] == b[0] and (a[0] != 0 or a[1] == b[1])
+    assert g.lzp_encode(d) == oracle.lzp_encode(d)
+    n, z = oracle.lzp_encode(d)
+    if n > 0:
+        assert g.lzp_decode(z, len(d) + 100) == (len(d), d)
+        assert g.lzp_decode(z, len(d) // 2) == oracle.lzp_decode(z, len(d) // 2)
+    if len(d) > 1:
+        assert g.bwt(d) == oracle.bwt(d)
+        idx, u = oracle.bwt(d)
+        assert g.unbwt(u, idx) == (0, d)
+        dd = u[:5000]
+        c = oracle.cm_encode(dd)
+        assert g.cm_encode(dd) == c
+        assert g.cm_decode(c, len(dd)) == dd
+        assert g.cm_decode(c[: len(c) // 2], len(dd)) == oracle.cm_decode(c[: len(c) // 2], len(dd))
+
+
+@pytest.mark.parametrize("name", ["empty", "one", "63", "64", "65", "runs", "f2", "nearmiss", "text20k", "rand9k", "repeats"])
+def test_block_parity(emu, oracle, name):
+    d = CASES[name]
+    bs = 65 * 1024
+    with bzip3_amd.State(bs, emu) as st:
+        a = st.encode_block(d)
+        assert a == oracle.encode_block(d, bs)
+        assert st.decode_block(a[2], len(d))[:2] == (len(d), 0) or len(d) == 0
+        assert st.decode_block(a[2], len(d))[2] == d
+
+
+def test_decoder_error_codes(emu, oracle):
+    bs = 65 * 1024
+    blk = oracle.encode_block(datagen.shakespeare()[:20000], bs)[2]
+    muts = [blk[: len(blk) // 2], blk[:4] + b"\0\0\0\0" + blk[8:], blk[:8] + b"\x7f" + blk[9:], blk[:20] + bytes([blk[20] ^ 1]) + blk[21:],
+            blk[:4] + b"\xff\xff\xff\x7f" + blk[8:], blk[:4] + b"\xfb\xff\xff\xff" + blk[8:], b"\0" * 9]
+    with bzip3_amd.State(bs, emu) as st:
+        for m in muts:
+            assert st.decode_block(m, 20000)[:2] == oracle.decode_block(m, 20000, bs)[:2]
+        for bsz, cs, osz in [(5, len(blk), 20000), (len(blk) - 1, len(blk), 20000), (70000, -5, 20000), (70000, len(blk), -1),
+                             (70000, len(blk), 10 ** 9), (10000, len(blk), 20000), (70000, len(blk), 19999)]:
+            assert st.decode_block(blk, osz, buffer_size=bsz, comp_size=cs)[:2] == oracle.decode_block(blk, osz, bs, buffer_size=bsz, comp_size=cs)[:2]
+        n, err, _ = st.encode_block(b"x" * (bs + 1))
+        assert (n, err) == (-1, bzip3_amd.BZ3_ERR_DATA_TOO_BIG)
+
+
+def test_batch_api_and_frame_api(emu, oracle):
+    bs = 65 * 1024
+    t = datagen.shakespeare()
+    blocks = [t[i * 9000 : (i + 1) * 9000] for i in range(3)] + [b"tiny"]
+    n = len(blocks)
+    states = (C.c_void_p * n)(*[emu.bz3_new(bs) for _ in range(n)])
+    cap = emu.bz3_bound(bs) + 64
+    bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+    for b, d in zip(bufs, blocks):
+        C.memmove(b, d, len(d))
+    ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+    emu.bz3_encode_blocks(states, ptrs, sizes, n)
+    for i, d in enumerate(blocks):
+        assert emu.bz3_last_error(states[i]) == 0
+        assert bytes(bufs[i][: sizes[i]]) == oracle.encode_block(d, bs)[2]
+    bsz = (C.c_size_t * n)(*[cap] * n)
+    orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+    emu.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+    for i, d in enumerate(blocks):
+        assert emu.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: len(d)]) == d
+    for s in states:
+        emu.bz3_free(s)
+    # frame API round trip (src/libbz3.c:876-997)
+    data = t[:150000]
+    out = (C.c_uint8 * (emu.bz3_bound(len(data)) + 64))()
+    osz = C.c_size_t(len(out))
+    assert emu.bz3_compress(bs, data, out, len(data), C.byref(osz)) == 0
+    assert bytes(out[:5]) == b"BZ3v1"
+    back = (C.c_uint8 * (len(data) + 16))()
+    bsz2 = C.c_size_t(len(back))
+    assert emu.bz3_decompress(out, back, osz.value, C.byref(bsz2)) == 0
+    assert bytes(back[: bsz2.value]) == data

@@ -1,0 +1,204 @@
+"""-m gpu: the parity tests proper.  Everything goes through the C ABI of bzip3_amd/lib/libbzip3.so on a
+real MI355X and is compared, bit for bit, with the oracle (and with oracle/_ref when it travelled)."""
+import ctypes as C
+import hashlib
+import os
+import struct
+
+import pytest
+
+import bzip3_amd
+import datagen
+
+pytestmark = pytest.mark.gpu
+GOLDEN = datagen.GOLDEN
+
+
+def _cases():
+    c = dict(datagen.nasty_cases())
+    t = datagen.shakespeare()
+    c["text1m"] = t[1000000 : 1000000 + (1 << 20)]
+    c["rand256k"] = datagen.random_bytes(256 * 1024)
+    c["lowent512k"] = datagen.low_entropy(512 * 1024)
+    c["repeats1m"] = datagen.repeats(1 << 20)
+    c["markov2m"] = datagen.text(2 << 20, seed=11, chains=256)
+    return c
+
+
+CASES = _cases()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_stage_parity(gpu_lib, oracle, name):
+    d = CASES[name]
+    g = bzip3_amd.StageApi(gpu_lib)
+    for k in {len(d), max(0, len(d) - 1), max(0, len(d) - 3), min(len(d), 5)}:
+        assert g.crc32c(d[:k]) == oracle.crc32c(d[:k])          # crc32sum
+    e = oracle.mrle_encode(d)
+    assert g.mrle_encode(d) == e                                 # mrlec
+    assert g.mrle_decode(e, len(d)) == (0, d)                    # mrled
+    for cut in (len(e) - 1, len(e) - 2, 40):
+        if 32 <= cut <= len(e):
+            a, b = g.mrle_decode(e, len(d), cut), oracle.mrle_decode(e, len(d), cut)
+            assert a[0] == b[0] and (a[0] != 0 or a[1] == b[1])
+    assert g.lzp_encode(d) == oracle.lzp_encode(d)               # lzp_compress
+    n, z = oracle.lzp_encode(d)
+    if n > 0:
+        assert g.lzp_decode(z, len(d) + 100) == (len(d), d)      # lzp_decompress
+        assert g.lzp_decode(z, len(d) // 2) == oracle.lzp_decode(z, len(d) // 2)
+    if len(d) > 1:
+        assert g.bwt(d) == oracle.bwt(d)                         # libsais_bwt
+        idx, u = oracle.bwt(d)
+        assert g.unbwt(u, idx) == (0, d)                         # libsais_unbwt
+        c = oracle.cm_encode(u)
+        assert g.cm_encode(u) == c                               # encode_bytes
+        assert g.cm_decode(c, len(u)) == u                       # decode_bytes
+        assert g.cm_decode(c[: len(c) // 2], len(u)) == oracle.cm_decode(c[: len(c) // 2], len(u))
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_block_parity(gpu_lib, oracle, name):
+    d = CASES[name]
+    bs = max(65 * 1024, len(d))
+    with bzip3_amd.State(bs, gpu_lib) as st:
+        a = st.encode_block(d)
+        assert a == oracle.encode_block(d, bs)
+        r = st.decode_block(a[2], len(d))
+        assert r[2] == d and (r[:2] == (len(d), 0) or len(d) == 0)
+
+
+def test_golden_fixture_decodes_on_gpu(gpu_lib):
+    # the reference's `make test` (Makefile.am:81-83) on the GPU path
+    raw = open(os.path.join(GOLDEN, "shakespeare.txt.bz3"), "rb").read()
+    bs, chunks = datagen.parse_chunks(raw)
+    out = b""
+    with bzip3_amd.State(bs, gpu_lib) as st:
+        for comp, orig, blk in chunks:
+            n, err, dec = st.decode_block(blk, orig)
+            assert (n, err) == (orig, 0)
+            out += dec
+    assert hashlib.md5(out).hexdigest() == datagen.SHAKESPEARE_MD5
+
+
+def test_cfg1_known_answer_on_gpu(gpu_lib, text):
+    # BASELINE config 1: shakespeare.txt -b 8 -> the oracle's / reference's exact file bytes
+    with bzip3_amd.State(8 << 20, gpu_lib) as st:
+        n, err, blk = st.encode_block(text)
+        assert (n, err) == (1229797, 0)
+        f = b"BZ3v1" + struct.pack("<I", 8 << 20) + struct.pack("<II", len(blk), len(text)) + blk
+        assert hashlib.md5(f).hexdigest() == "90bb3148f6a5bf00be8d682458dd15dd"
+        assert st.decode_block(blk, len(text)) == (len(text), 0, text)
+        t = st.timings()
+        assert t["cm"] > 0
+
+
+def test_decoder_error_codes(gpu_lib, oracle, text):
+    bs = 65 * 1024
+    blk = oracle.encode_block(text[:30000], bs)[2]
+    muts = [blk[: len(blk) // 2], blk[:4] + b"\0\0\0\0" + blk[8:], blk[:8] + b"\x7f" + blk[9:], blk[:20] + bytes([blk[20] ^ 1]) + blk[21:],
+            blk[:4] + b"\xff\xff\xff\x7f" + blk[8:], blk[:4] + b"\xfb\xff\xff\xff" + blk[8:], b"\0" * 9, blk[:9]]
+    with bzip3_amd.State(bs, gpu_lib) as st:
+        for m in muts:
+            assert st.decode_block(m, 30000)[:2] == oracle.decode_block(m, 30000, bs)[:2]
+        for bsz, cs, osz in [(5, len(blk), 30000), (len(blk) - 1, len(blk), 30000), (70000, -5, 30000), (70000, len(blk), -1),
+                             (70000, len(blk), 10 ** 9), (20000, len(blk), 30000), (70000, len(blk), 29999), (70000, len(blk), 30001)]:
+            assert st.decode_block(blk, osz, buffer_size=bsz, comp_size=cs)[:2] == oracle.decode_block(blk, osz, bs, buffer_size=bsz, comp_size=cs)[:2]
+        assert st.encode_block(b"x" * (bs + 1))[:2] == (-1, bzip3_amd.BZ3_ERR_DATA_TOO_BIG)
+        # a good block still decodes after failures (state reuse)
+        assert st.decode_block(blk, 30000) == (30000, 0, text[:30000])
+
+
+def test_batch_api_host_buffers(gpu_lib, oracle, text):
+    # bz3_encode_blocks / bz3_decode_blocks (src/libbz3.c:845-870): n independent (state, buffer) pairs
+    bs = 1 << 20
+    blocks = [text[i * 700000 : i * 700000 + 700000 - i * 1000] for i in range(5)] + [b"tiny", datagen.random_bytes(100000, seed=9)]
+    n = len(blocks)
+    states = (C.c_void_p * n)(*[gpu_lib.bz3_new(bs) for _ in range(n)])
+    assert all(states)
+    cap = gpu_lib.bz3_bound(bs) + 64
+    bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+    for b, d in zip(bufs, blocks):
+        C.memmove(b, d, len(d))
+    ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+    gpu_lib.bz3_encode_blocks(states, ptrs, sizes, n)
+    for i, d in enumerate(blocks):
+        assert gpu_lib.bz3_last_error(states[i]) == 0
+        assert bytes(bufs[i][: sizes[i]]) == oracle.encode_block(d, bs)[2]
+    bsz = (C.c_size_t * n)(*[cap] * n)
+    orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+    gpu_lib.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+    for i, d in enumerate(blocks):
+        assert gpu_lib.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: len(d)]) == d
+    for s in states:
+        gpu_lib.bz3_free(s)
+
+
+def test_device_resident_api(gpu_lib, oracle, text):
+    import torch
+
+    bs = 2 << 20
+    d = text[: 2 << 20]
+    cap = gpu_lib.bz3_bound(bs) + 64
+    buf = torch.zeros(cap, dtype=torch.uint8, device="cuda:0")
+    buf[: len(d)] = torch.frombuffer(bytearray(d), dtype=torch.uint8).to("cuda:0")
+    torch.cuda.synchronize()
+    gpu_lib.bz3_hip_bind_device(0)
+    with bzip3_amd.State(bs, gpu_lib) as st:
+        n = gpu_lib.bz3_hip_encode_block_device(st.ptr, buf.data_ptr(), len(d))
+        assert st.last_error == 0
+        assert bytes(buf[:n].cpu().numpy()) == oracle.encode_block(d, bs)[2]
+        m = gpu_lib.bz3_hip_decode_block_device(st.ptr, buf.data_ptr(), cap, n, len(d))
+        assert (m, st.last_error) == (len(d), 0)
+        assert bytes(buf[:m].cpu().numpy()) == d
+    gpu_lib.bz3_hip_bind_device(-1)
+
+
+def test_frame_api_round_trip_and_reference_interop(gpu_lib, text):
+    from oracle_lib import RefLib
+
+    data = text[:3000000]
+    out = (C.c_uint8 * (gpu_lib.bz3_bound(len(data)) + 64))()
+    osz = C.c_size_t(len(out))
+    assert gpu_lib.bz3_compress(1 << 20, data, out, len(data), C.byref(osz)) == 0
+    ref = RefLib()
+    if ref.available:  # byte-identical frame, and the reference decodes ours
+        out2 = (C.c_uint8 * len(out))()
+        osz2 = C.c_size_t(len(out2))
+        assert ref.lib.bz3_compress(1 << 20, data, out2, len(data), C.byref(osz2)) == 0
+        assert osz.value == osz2.value and bytes(out[: osz.value]) == bytes(out2[: osz2.value])
+    back = (C.c_uint8 * (len(data) + 16))()
+    bsz = C.c_size_t(len(back))
+    assert gpu_lib.bz3_decompress(out, back, osz.value, C.byref(bsz)) == 0
+    assert bytes(back[: bsz.value]) == data
+
+
+def test_large_block_round_trip_properties(gpu_lib, oracle):
+    # size-independent properties at a size the oracle's BWT would not finish quickly: decode(encode(x)) == x,
+    # the stored CRC is the oracle's CRC of x, header fields are self-consistent, and (when oracle/_ref
+    # travelled) the bytes equal the real reference's.
+    from oracle_lib import Bz3, RefLib
+
+    n = int(os.environ.get("BZ3_TEST_LARGE_MIB", "24")) << 20
+    d = datagen.text(n, seed=21, chains=4096)
+    with bzip3_amd.State(n, gpu_lib) as st:
+        m, err, blk = st.encode_block(d)
+        assert err == 0 and 0 < m < n // 3
+        assert struct.unpack("<I", blk[:4])[0] == oracle.crc32c(d)
+        ref = RefLib()
+        if ref.available:
+            assert Bz3(ref.lib).encode_block(d, n)[2] == blk
+        k, err, back = st.decode_block(blk, n)
+        assert (k, err) == (n, 0) and back == d
+        print("timings(decode, ms):", st.timings(), "bwt:", st.bwt_stats())
+
+
+@pytest.mark.skipif(os.environ.get("BZ3_TEST_FULL_SIZE") != "1", reason="256 MiB block: minutes of GPU time; set BZ3_TEST_FULL_SIZE=1")
+def test_full_size_256mib_block(gpu_lib, oracle):
+    n = 256 << 20
+    d = datagen.text(n, seed=31, chains=65536)
+    with bzip3_amd.State(n, gpu_lib) as st:
+        m, err, blk = st.encode_block(d)
+        assert err == 0 and struct.unpack("<I", blk[:4])[0] == oracle.crc32c(d)
+        k, err, back = st.decode_block(blk, n)
+        assert (k, err) == (n, 0) and back == d
