@@ -11,9 +11,9 @@
 //    disjoint counters, so 8 lanes evaluate and update them at once; the (low, high) recurrence of the
 //    coder is inherently serial and is kept wave-uniform (scalar registers).
 //  * decode: the bit is unknown until decoded, but the 255 nodes of the NEXT byte depend only on state
-//    that is fixed once the previous byte is known, so 64 lanes x 4 nodes pre-evaluate every node's
-//    18-bit probability; the 8 serial decisions then only pick values out of registers
-//    (v_readlane), and the 8 nodes on the decoded path are updated in parallel.
+//    that is fixed once the previous byte is known, so 256 lanes (one tree node each) pre-evaluate every
+//    node's 18-bit probability; the 8 serial decisions then only pick values out of registers
+//    (v_readlane), and the 8 lanes on the decoded path update their counters in parallel.
 // All arithmetic is integer and matches the reference bit for bit, including the signed interpolation
 // `x1 + (((x2 - x1) * (p & 4095)) >> 12)` with an arithmetic shift of a possibly negative product.
 #include "prims.hpp"
@@ -34,6 +34,16 @@ __device__ __forceinline__ u32 cm_readlane(u32 v, int lane) {
     return __shfl(v, lane);
 #else
     return (u32)__builtin_amdgcn_readlane((int)v, lane);
+#endif
+}
+
+// Tells the compiler a value is wave-uniform so that it lives in scalar registers and branches on it
+// are scalar branches (the serial coder recurrences run entirely on the scalar unit).
+__device__ __forceinline__ u32 cm_uniform(u32 v) {
+#ifdef BZ3_EMU
+    return v;
+#else
+    return (u32)__builtin_amdgcn_readfirstlane((int)v);
 #endif
 }
 
@@ -89,42 +99,93 @@ __device__ __forceinline__ void cm_learn(CmLds & m, const CmProbe & q, u32 node,
 }
 
 // ------------------------------------------------------------------------------------------------
-// encode: one wave.  Lanes 0..7 own the 8 tree levels of the current byte; the coder state is uniform.
+// encode: two waves.  Wave 1 ("model") walks the block: lanes 0..7 own the 8 tree levels of the current
+// byte, evaluate their node, update the counters and push the 18-bit probabilities into an LDS ring.
+// Wave 0 ("coder") drains the ring and runs the serial (low, range) recurrence in scalar registers.
+// The two overlap; the block finishes at the pace of the slower one (the coder: ~12 scalar
+// instructions per coded bit).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_cm_encode(const u8 * __restrict__ in, u32 n, u8 * __restrict__ out, u32 * __restrict__ out_size) {
+constexpr u32 CM_RING = 128;  // bytes of look-ahead between the model wave and the coder wave
+
+__device__ __forceinline__ u32 lds_peek(const u32 * p) { return *reinterpret_cast<const volatile u32 *>(p); }
+__device__ __forceinline__ void lds_poke(u32 * p, u32 v) { *reinterpret_cast<volatile u32 *>(p) = v; }
+
+__global__ void __launch_bounds__(128) k_cm_encode(const u8 * __restrict__ in, u32 n, u8 * __restrict__ out, u32 * __restrict__ out_size) {
     __shared__ CmLds m;
+    __shared__ u32 ring[CM_RING * 8];
+    __shared__ u32 s_prod, s_cons;
+    if (threadIdx.x == 0) { s_prod = 0; s_cons = 0; }
     cm_model_init(m);
     const int lane = lane_id();
-    const u32 k = (u32)lane & 7u;
-    u32 low = 0, high = 0xFFFFFFFFu, c1 = 0, c2 = 0, run = 0, op = 0;
+    if (cm_uniform((u32)wave_id()) == 1) {
+        // ---- model wave --------------------------------------------------------------------------
+        const u32 k = (u32)lane & 7u;
+        u32 c1 = 0, c2 = 0, run = 0, cons_seen = 0;
+        for (u32 base = 0; base < n; base += 64) {
+            const u32 mine = (base + lane < n) ? in[base + lane] : 0u;
+            const u32 cnt = (n - base < 64u) ? n - base : 64u;
+            for (u32 t = 0; t < cnt; t++) {
+                const u32 i = base + t;
+                while (i - cons_seen >= CM_RING) {  // ring full: wait for the coder
+                    cons_seen = lds_peek(&s_cons);
+                    if (i - cons_seen >= CM_RING) BZ3_SPIN_PAUSE();
+                }
+                const u32 c = cm_readlane(mine, (int)t);
+                run = (c1 == c2) ? run + 1 : 0;  // :367-372
+                const u32 f = run > 2 ? 1u : 0u;
+                const u32 node = (1u << k) | (c >> (8 - k));
+                const u32 bit = (c >> (7 - k)) & 1u;
+                CmProbe q = cm_probe(m, node, c1, c2, f);
+                wave_sync();
+                if (lane < 8) {
+                    cm_learn(m, q, node, c1, bit);
+                    ring[(i & (CM_RING - 1)) * 8 + k] = q.p18;
+                }
+                wave_sync();
+                c2 = c1;
+                c1 = c;
+                if ((i & 3u) == 3u || i + 1 == n) {
+                    lds_release();
+                    if (lane == 0) lds_poke(&s_prod, i + 1);
+                }
+            }
+        }
+        return;
+    }
+    // ---- coder wave: high == low + range throughout (:388-394 in (low, range) form) -----------------
+    u32 low = 0, range = 0xFFFFFFFFu, op = 0, prod_seen = 0;
     for (u32 base = 0; base < n; base += 64) {
         const u32 mine = (base + lane < n) ? in[base + lane] : 0u;
         const u32 cnt = (n - base < 64u) ? n - base : 64u;
         for (u32 t = 0; t < cnt; t++) {
+            const u32 i = base + t;
+            while (prod_seen <= i) {
+                prod_seen = lds_peek(&s_prod);
+                if (prod_seen <= i) BZ3_SPIN_PAUSE();
+            }
+            lds_acquire();
+            const u32 ev = ring[(i & (CM_RING - 1)) * 8 + ((u32)lane & 7u)];
             const u32 c = cm_readlane(mine, (int)t);
-            run = (c1 == c2) ? run + 1 : 0;  // :367-372
-            const u32 f = run > 2 ? 1u : 0u;
-            const u32 node = (1u << k) | (c >> (8 - k));
-            const u32 bit = (c >> (7 - k)) & 1u;
-            CmProbe q = cm_probe(m, node, c1, c2, f);
-            wave_sync();
-            if (lane < 8) cm_learn(m, q, node, c1, bit);
-            wave_sync();
 #pragma unroll
             for (int kk = 0; kk < 8; kk++) {
-                const u32 p18 = cm_readlane(q.p18, kk);
-                const u32 b = (c >> (7 - kk)) & 1u;
-                const u32 mid = low + (u32)(((u64)(high - low) * p18) >> 18);  // :388, :402
-                if (b) high = mid; else low = mid + 1;
-                while ((low ^ high) < (1u << 24)) {  // :390-394
-                    if (lane == 0) out[op] = (u8)(low >> 24);
-                    op++;
-                    low <<= 8;
-                    high = (high << 8) | 0xFFu;
+                const u32 p18 = cm_readlane(ev, kk);
+                const u32 tt = (u32)(((u64)range * p18) >> 18);
+                if ((c >> (7 - kk)) & 1u) {
+                    range = tt;  // high = mid
+                } else {
+                    low += tt + 1;  // low = mid + 1
+                    range -= tt + 1;
+                }
+                if (range < (1u << 24)) {  // necessary for (low ^ high) < 2^24; the exact test follows
+                    while ((low ^ (low + range)) < (1u << 24)) {
+                        if (lane == 0) out[op] = (u8)(low >> 24);
+                        op++;
+                        low <<= 8;
+                        range = (range << 8) | 0xFFu;
+                    }
                 }
             }
-            c2 = c1;
-            c1 = c;
+            if ((i & 15u) == 15u && lane == 0) lds_poke(&s_cons, i + 1);
         }
     }
     if (lane == 0) {  // flush (:425-432)
@@ -137,16 +198,22 @@ __global__ void __launch_bounds__(64) k_cm_encode(const u8 * __restrict__ in, u3
 }
 
 // ------------------------------------------------------------------------------------------------
-// decode: one wave.  Lane l owns tree nodes l, l+64, l+128, l+192.
+// decode: five waves.  Waves 1..4 hold one tree node per lane (node = thread - 64): before every byte
+// they evaluate all 255 probabilities into an LDS table; wave 0 loads the table into registers (4 per
+// lane), makes the 8 serial decisions with v_readlane + scalar arithmetic, and publishes the byte; the
+// 8 lanes whose node lies on the decoded path then update their counters.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_cm_decode(const u8 * __restrict__ in, u32 in_size, u8 * __restrict__ out, u32 n) {
+__global__ void __launch_bounds__(320) k_cm_decode(const u8 * __restrict__ in, u32 in_size, u8 * __restrict__ out, u32 n) {
     __shared__ CmLds m;
+    __shared__ u32 ptab[256];
+    __shared__ u32 s_byte;
     cm_model_init(m);
     const int lane = lane_id();
-    u32 low = 0, high = 0xFFFFFFFFu, code = 0, c1 = 0, c2 = 0, run = 0;
-    u32 ip = 0;       // next input byte index
-    u32 ibase = 0;    // input window [ibase, ibase + 64) is held one byte per lane
-    u32 window = (ibase + lane < in_size) ? in[ibase + lane] : 0xFFFFFFFFu;
+    const bool coder = cm_uniform((u32)wave_id()) == 0;
+    const u32 node = threadIdx.x - 64u;  // model lanes only
+    u32 low = 0, range = 0xFFFFFFFFu, x = 0, c1 = 0, c2 = 0, run = 0;  // x = code - low
+    u32 ip = 0, ibase = 0;
+    u32 window = (coder && ibase + lane < in_size) ? in[ibase + lane] : 0xFFFFFFFFu;
 #define CM_NEXT_BYTE(dst)                                                              \
     do {                                                                               \
         if (ip - ibase >= 64u) {                                                       \
@@ -156,81 +223,88 @@ __global__ void __launch_bounds__(64) k_cm_decode(const u8 * __restrict__ in, u3
         dst = cm_readlane(window, (int)(ip - ibase));                                  \
         ip++;                                                                          \
     } while (0)
-    for (int j = 0; j < 4; j++) {  // :438-441; bytes past the end read as -1 (:345)
-        u32 b;
-        CM_NEXT_BYTE(b);
-        code = (code << 8) + b;
+    if (coder) {
+        for (int j = 0; j < 4; j++) {  // :438-441; bytes past the end read as -1 (:345)
+            u32 b;
+            CM_NEXT_BYTE(b);
+            x = (x << 8) + b;
+        }
     }
     u32 staged = 0;
+    CmProbe q;
+    q.p0 = q.p1 = q.x1 = q.x2 = q.c2off = q.p18 = 0;
     for (u32 i = 0; i < n; i++) {
         run = (c1 == c2) ? run + 1 : 0;
         const u32 f = run > 2 ? 1u : 0u;
-        // phase 1: probabilities of all 255 nodes
-        CmProbe q0 = cm_probe(m, (u32)lane, c1, c2, f);
-        CmProbe q1 = cm_probe(m, (u32)lane + 64u, c1, c2, f);
-        CmProbe q2 = cm_probe(m, (u32)lane + 128u, c1, c2, f);
-        CmProbe q3 = cm_probe(m, (u32)lane + 192u, c1, c2, f);
-        // phase 2: 8 serial binary decisions (:453-489)
-        u32 ctx = 1;
+        if (!coder) {
+            q = cm_probe(m, node, c1, c2, f);
+            ptab[node] = q.p18;
+        }
+        __syncthreads();
+        if (coder) {
+            const u32 p0 = ptab[lane], p1 = ptab[lane + 64], p2 = ptab[lane + 128], p3 = ptab[lane + 192];
+            u32 ctx = 1;
 #pragma unroll
-        for (int lvl = 0; lvl < 8; lvl++) {
-            u32 p18;
-            const int src = (int)(ctx & 63u);
-            if (lvl < 6) p18 = cm_readlane(q0.p18, src);
-            else if (lvl == 6) p18 = cm_readlane(q1.p18, src);
-            else {
-                const u32 a = cm_readlane(q2.p18, src), b = cm_readlane(q3.p18, src);
-                p18 = (ctx & 64u) ? b : a;
+            for (int lvl = 0; lvl < 8; lvl++) {  // :453-489
+                u32 p18;
+                const int src = (int)(ctx & 63u);
+                if (lvl < 6) p18 = cm_readlane(p0, src);
+                else if (lvl == 6) p18 = cm_readlane(p1, src);
+                else {
+                    const u32 a = cm_readlane(p2, src), b = cm_readlane(p3, src);
+                    p18 = (ctx & 64u) ? b : a;
+                }
+                const u32 tt = (u32)(((u64)range * p18) >> 18);  // mid - low (:464)
+                const bool bit = x <= tt;                        // code <= mid
+#ifdef BZ3_EMU
+                ctx = ctx * 2 + (bit ? 1u : 0u);
+#else
+                // ctx = 2*ctx + bit on the scalar unit (keeps the node index out of vector registers)
+                asm volatile("s_cmp_le_u32 %1, %2\n\ts_addc_u32 %0, %0, %0" : "+s"(ctx) : "s"(x), "s"(tt) : "scc");
+#endif
+                if (bit) {
+                    range = tt;
+                } else {
+                    low += tt + 1;
+                    x -= tt + 1;
+                    range -= tt + 1;
+                }
+                if (range < (1u << 24)) {
+                    while ((low ^ (low + range)) < (1u << 24)) {  // :470-474
+                        low <<= 8;
+                        range = (range << 8) | 0xFFu;
+                        u32 b;
+                        CM_NEXT_BYTE(b);
+                        x = (x << 8) + b;
+                    }
+                }
             }
-            const u32 mid = low + (u32)(((u64)(high - low) * p18) >> 18);  // :464
-            const u32 bit = code <= mid ? 1u : 0u;
-            if (bit) high = mid; else low = mid + 1;
-            while ((low ^ high) < (1u << 24)) {  // :470-474
-                low <<= 8;
-                high = (high << 8) | 0xFFu;
-                u32 b;
-                CM_NEXT_BYTE(b);
-                code = (code << 8) + b;
+            const u32 c = ctx & 255u;
+            if (lane == 0) s_byte = c;
+            if ((u32)lane == (i & 63u)) staged = c;
+            if ((i & 63u) == 63u || i + 1 == n) {
+                const u32 first = i & ~63u;
+                if (first + lane <= i) out[first + lane] = (u8)staged;
             }
-            ctx = ctx * 2 + bit;
         }
-        const u32 c = ctx & 255u;
-        // phase 3: update the 8 nodes on the decoded path (one per tree level)
-        wave_sync();
-        {
-            const u32 full = 256u | c;
-#define CM_UPDATE_IF_ON_PATH(q, node_expr)                                   \
-    do {                                                                     \
-        const u32 node = (node_expr);                                        \
-        if (node != 0) {                                                     \
-            const int lvl = 31 - __clz(node);                                \
-            if ((full >> (8 - lvl)) == node) cm_learn(m, q, node, c1, (c >> (7 - lvl)) & 1u); \
-        }                                                                    \
-    } while (0)
-            CM_UPDATE_IF_ON_PATH(q0, (u32)lane);
-            CM_UPDATE_IF_ON_PATH(q1, (u32)lane + 64u);
-            CM_UPDATE_IF_ON_PATH(q2, (u32)lane + 128u);
-            CM_UPDATE_IF_ON_PATH(q3, (u32)lane + 192u);
-#undef CM_UPDATE_IF_ON_PATH
+        __syncthreads();
+        const u32 c = cm_uniform(s_byte);
+        if (!coder && node != 0) {
+            const int lvl = 31 - __clz((int)node);
+            if (((256u | c) >> (8 - lvl)) == node) cm_learn(m, q, node, c1, (c >> (7 - lvl)) & 1u);
         }
-        wave_sync();
         c2 = c1;
         c1 = c;
-        if ((u32)lane == (i & 63u)) staged = c;
-        if ((i & 63u) == 63u || i + 1 == n) {
-            const u32 first = i & ~63u;
-            if (first + lane <= i) out[first + lane] = (u8)staged;
-        }
     }
 #undef CM_NEXT_BYTE
 }
 
 void cm_encode(const u8 * d_in, u32 n, u8 * d_out, u32 * d_out_size, hipStream_t s) {
-    launch(k_cm_encode, dim3(1), dim3(64), 0, s, d_in, n, d_out, d_out_size);
+    launch(k_cm_encode, dim3(1), dim3(128), 0, s, d_in, n, d_out, d_out_size);
 }
 
 void cm_decode(const u8 * d_in, u32 in_size, u8 * d_out, u32 n, hipStream_t s) {
-    launch(k_cm_decode, dim3(1), dim3(64), 0, s, d_in, in_size, d_out, n);
+    launch(k_cm_decode, dim3(1), dim3(320), 0, s, d_in, in_size, d_out, n);
 }
 
 }  // namespace bz3

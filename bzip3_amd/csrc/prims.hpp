@@ -23,6 +23,19 @@ __device__ __forceinline__ void wave_sync() {
 #endif
 }
 
+// Workgroup-scope release / acquire around hand-offs through LDS between waves of one workgroup
+// (all waves of a workgroup share the CU's LDS; only ordering is needed, no cache maintenance).
+__device__ __forceinline__ void lds_release() {
+#ifndef BZ3_EMU
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#endif
+}
+__device__ __forceinline__ void lds_acquire() {
+#ifndef BZ3_EMU
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_incl_add(T v) {
     const int l = lane_id();
