@@ -73,11 +73,33 @@ def _declare(L):
 EXPORTED_SYMBOLS = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7; two HIP runtimes in one process do not both see
+    the GPU.  If torch is installed, load ITS runtime first (without importing torch) so that libbzip3.so --
+    which only asks for the soname libamdhip64.so.7 -- and a later `import torch` share one runtime.
+    Set BZ3_HIP_SYSTEM_RUNTIME=1 to keep the system ROCm runtime instead."""
+    if os.environ.get("BZ3_HIP_SYSTEM_RUNTIME") == "1":
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load(path=None):
     """Load libbzip3.so (building nothing, falling back to nothing)."""
     global _lib
     if _lib is not None and path is None:
         return _lib
+    if path is None:
+        _share_hip_runtime_with_torch()
     p = path or LIB_PATH
     if not os.path.exists(p):
         raise RuntimeError(

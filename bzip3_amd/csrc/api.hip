@@ -161,20 +161,23 @@ struct bz3_state {
     u8 * d_swap = nullptr;  // the reference's swap_buffer, in HBM
     u8 * d_io = nullptr;    // staging for the host-buffer API (lazy)
     size_t cap = 0;         // bz3_bound(block_size) rounded up
-    u32 * d_words = nullptr;  // [0..1] crc scratch/result, [2] cm coded size, [4..] spare
+    u32 * d_words = nullptr;  // [0..1] crc scratch/result, [2] cm coded size, [4] rle total, [5] lzp result
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float t[BZ3_HIP_T_COUNT] = {0};
     BwtStats bwt;
 
-    // in-flight block between *_front and *_finish
+    // block in flight inside one API call
     enum Pending { NONE, ENC_STORED, ENC_CODED, DEC_STORED, DEC_CODED, FAILED } pending = NONE;
     u8 * user = nullptr;  // caller's device buffer
-    u8 * b1 = nullptr;
-    s32 size = 0, overhead = 0;
+    u8 * b1 = nullptr, * b2 = nullptr;
+    s32 size = 0, overhead = 0, result = -1;
+    u32 n_cm = 0;         // bytes entering / leaving the CM stage
+    const u8 * cm_in = nullptr;
+    u32 cm_in_size = 0;
     // decode
     size_t buffer_size = 0;
     u32 crc = 0;
-    s32 bwt_idx = 0, model = 0, lzp_size = -1, rle_size = -1, orig_size = 0, size_before_bwt = 0;
+    s32 bwt_idx = 0, model = 0, lzp_size = -1, rle_size = -1, orig_size = 0, size_before_bwt = 0, size_src = 0;
 };
 
 namespace {
@@ -200,29 +203,33 @@ void ensure_io(bz3_state * st) {
     if (!st->d_io) HIP_CHECK(hipMalloc((void **)&st->d_io, st->cap));
 }
 
-u32 read_word(bz3_state * st, const u32 * d) {
+u32 read_word(hipStream_t s, const u32 * d) {
     u32 v = 0;
-    HIP_CHECK(hipMemcpyAsync(&v, d, 4, hipMemcpyDeviceToHost, st->stream));
-    HIP_CHECK(hipStreamSynchronize(st->stream));
+    HIP_CHECK(hipMemcpyAsync(&v, d, 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
     return v;
 }
 
-// ---- encode ------------------------------------------------------------------------------------
-// Front half: everything up to and including the launch of the CM kernel (asynchronous tail).
-void encode_front(bz3_state * st, u8 * buf, s32 data_size) {
+inline bool sizes_fit(size_t buffer_size, s32 lzp_size, s32 rle_size, s32 orig_size) {  // bz3_check_buffer_size, :114-122
+    const size_t a = lzp_size < 0 ? 0 : (size_t)lzp_size, b = rle_size < 0 ? 0 : (size_t)rle_size, c = orig_size < 0 ? 0 : (size_t)orig_size;
+    return a <= buffer_size && b <= buffer_size && c <= buffer_size;
+}
+
+// ======================================================================================================
+// encode.  A call (one block or a batch) runs in three phases per GPU:
+//   1. per block, whole-GPU kernels, one block after the other: CRC, mRLE, LZP, BWT        (encode_front)
+//   2. ONE launch of the CM kernel, one workgroup (= one CU) per block                      (cm_encode_batch)
+//   3. per block: header, copy back into the caller's buffer if the ping-pong ended there   (encode_finish)
+// ======================================================================================================
+void encode_front(bz3_state * st, u8 * buf, s32 data_size, Arena & arena) {
     st->pending = bz3_state::FAILED;
-    if (data_size > st->block_size) {  // :588-591
+    st->result = -1;
+    if (data_size > st->block_size || data_size < 0) {  // :588-591 (a negative size would walk off the buffer)
         st->last_error = BZ3_ERR_DATA_TOO_BIG;
         return;
     }
-    if (data_size < 0) {  // the reference would walk off its buffer; refuse instead
-        st->last_error = BZ3_ERR_DATA_TOO_BIG;
-        return;
-    }
-    DeviceGuard g(st->device);
     hipStream_t s = st->stream;
     for (float & x : st->t) x = 0.f;
-    std::lock_guard<std::mutex> lk(st->ctx->mu);
     double t0 = now_ms();
     crc32c_device(buf, (u64)data_size, 1u, st->ctx->d_crc, st->d_words, s);  // :593
     st->user = buf;
@@ -236,7 +243,6 @@ void encode_front(bz3_state * st, u8 * buf, s32 data_size) {
     st->t[BZ3_HIP_T_CRC] = (float)(now_ms() - t0);
 
     u32 n = (u32)data_size;
-    Arena arena = st->ctx->arena_for(workspace_bytes_for((u64)n + 64));
     u8 *b1 = buf, *b2 = st->d_swap;
     s32 model = 0, lzp_size = 0, rle_size = 0;
 
@@ -245,7 +251,7 @@ void encode_front(bz3_state * st, u8 * buf, s32 data_size) {
         MrleEncScratch sc;
         const size_t mk = arena.mark();
         mrle_encode_size(b1, n, sc, arena, s);
-        rle_size = (s32)(32u + read_word(st, sc.total));
+        rle_size = (s32)(32u + read_word(s, sc.total));
         if (rle_size < (s32)n) {
             mrle_encode_write(b1, n, sc, b2, s);
             HIP_CHECK(hipStreamSynchronize(s));
@@ -277,25 +283,25 @@ void encode_front(bz3_state * st, u8 * buf, s32 data_size) {
     s32 overhead = 2;  // :630-632
     if (model & 2) overhead++;
     if (model & 4) overhead++;
-    HIP_CHECK(hipEventRecord(st->ev0, s));
-    cm_encode(b2, n, b1 + overhead * 4 + 1, st->d_words + 2, s);  // :634-638
-    HIP_CHECK(hipEventRecord(st->ev1, s));
     launch(k_write_header, dim3(1), dim3(64), 0, s, b1, (const u32 *)(st->d_words + 1), (u32)bwt_idx, (u32)model, (u32)lzp_size, (u32)rle_size);  // :641-647
     st->b1 = b1;
+    st->b2 = b2;
+    st->n_cm = n;
     st->overhead = overhead;
     st->pending = bz3_state::ENC_CODED;
 }
 
-s32 encode_finish(bz3_state * st) {
+void encode_finish(bz3_state * st, float cm_ms) {
     const bz3_state::Pending p = st->pending;
     st->pending = bz3_state::NONE;
-    if (p == bz3_state::FAILED || p == bz3_state::NONE) return -1;
-    DeviceGuard g(st->device);
+    if (p == bz3_state::FAILED || p == bz3_state::NONE) return;
     HIP_CHECK(hipStreamSynchronize(st->stream));
-    if (p == bz3_state::ENC_STORED) return st->size + 8;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, st->ev0, st->ev1) == hipSuccess) st->t[BZ3_HIP_T_CM] = ms;
-    const u32 coded = read_word(st, st->d_words + 2);
+    if (p == bz3_state::ENC_STORED) {
+        st->result = st->size + 8;
+        return;
+    }
+    st->t[BZ3_HIP_T_CM] = cm_ms;
+    const u32 coded = read_word(st->stream, st->d_words + 2);
     const s32 total = (s32)coded + st->overhead * 4 + 1;
     st->last_error = BZ3_OK;  // :649
     if (st->b1 != st->user) {  // :651
@@ -304,18 +310,49 @@ s32 encode_finish(bz3_state * st) {
         HIP_CHECK(hipStreamSynchronize(st->stream));
         st->t[BZ3_HIP_T_COPY] += (float)(now_ms() - t0);
     }
-    return total;
+    st->result = total;
 }
 
-// ---- decode ------------------------------------------------------------------------------------
-inline bool sizes_fit(size_t buffer_size, s32 lzp_size, s32 rle_size, s32 orig_size) {  // bz3_check_buffer_size, :114-122
-    const size_t a = lzp_size < 0 ? 0 : (size_t)lzp_size, b = rle_size < 0 ? 0 : (size_t)rle_size, c = orig_size < 0 ? 0 : (size_t)orig_size;
-    return a <= buffer_size && b <= buffer_size && c <= buffer_size;
+// Runs `n` blocks whose states live on ONE device.  bufs are device pointers.
+void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
+    if (n <= 0) return;
+    bz3_state * lead = sts[0];
+    DeviceGuard g(lead->device);
+    std::lock_guard<std::mutex> lk(lead->ctx->mu);
+    size_t need = 0;
+    for (s32 i = 0; i < n; i++) {
+        const size_t w = workspace_bytes_for((u64)(sizes[i] > 0 ? sizes[i] : 0) + 64);
+        if (w > need) need = w;
+    }
+    Arena arena = lead->ctx->arena_for(need + (size_t)n * sizeof(CmEncodeJob) + 4096);
+    CmEncodeJob * d_jobs = arena.take<CmEncodeJob>((size_t)n);
+    std::vector<CmEncodeJob> jobs;
+    for (s32 i = 0; i < n; i++) {
+        encode_front(sts[i], bufs[i], sizes[i], arena);
+        if (sts[i]->pending == bz3_state::ENC_CODED)
+            jobs.push_back(CmEncodeJob{sts[i]->b2, sts[i]->n_cm, sts[i]->b1 + sts[i]->overhead * 4 + 1, sts[i]->d_words + 2});  // :634-638
+    }
+    float cm_ms = 0.f;
+    if (!jobs.empty()) {
+        hipStream_t s = lead->stream;
+        HIP_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(CmEncodeJob) * jobs.size(), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipEventRecord(lead->ev0, s));
+        cm_encode_batch(d_jobs, (u32)jobs.size(), s);
+        HIP_CHECK(hipEventRecord(lead->ev1, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        (void)hipEventElapsedTime(&cm_ms, lead->ev0, lead->ev1);
+    }
+    for (s32 i = 0; i < n; i++) encode_finish(sts[i], cm_ms);
 }
 
+// ======================================================================================================
+// decode.  Phases per GPU: validate headers -> ONE CM launch (one CU per block) -> per block inverse BWT
+// (whole GPU) -> ONE LZP-decode launch (one workgroup per block) -> per block mRLE decode + CRC check.
+// ======================================================================================================
 // hdr: host copy of the first min(17, buffer_size) bytes of the block.
 void decode_front(bz3_state * st, u8 * buf, size_t buffer_size, s32 compressed_size, s32 orig_size, const u8 * hdr) {
     st->pending = bz3_state::FAILED;
+    st->result = -1;
     if (buffer_size < 9 || buffer_size < (size_t)compressed_size) {  // :658-661 (s32 -> size_t as in the reference)
         st->last_error = BZ3_ERR_DATA_SIZE_TOO_SMALL;
         return;
@@ -327,7 +364,6 @@ void decode_front(bz3_state * st, u8 * buf, size_t buffer_size, s32 compressed_s
         st->last_error = BZ3_ERR_MALFORMED_HEADER;
         return;
     }
-    DeviceGuard g(st->device);
     hipStream_t s = st->stream;
     for (float & x : st->t) x = 0.f;
     st->user = buf;
@@ -378,104 +414,226 @@ void decode_front(bz3_state * st, u8 * buf, size_t buffer_size, s32 compressed_s
     st->rle_size = rle_size;
     st->orig_size = orig_size;
     st->size_before_bwt = size_before_bwt;
-    // :742-747 -- the CM kernel runs alone on one CU; other blocks' work overlaps with it
-    HIP_CHECK(hipEventRecord(st->ev0, s));
-    cm_decode(buf + p * 4 + 1, (u32)(compressed_size < 0 ? 0 : compressed_size), st->d_swap, (u32)size_before_bwt, s);
-    HIP_CHECK(hipEventRecord(st->ev1, s));
+    st->cm_in = buf + p * 4 + 1;  // :742-747
+    st->cm_in_size = (u32)(compressed_size < 0 ? 0 : compressed_size);
     st->pending = bz3_state::DEC_CODED;
 }
 
-s32 decode_finish(bz3_state * st) {
-    const bz3_state::Pending p = st->pending;
-    st->pending = bz3_state::NONE;
-    if (p == bz3_state::FAILED || p == bz3_state::NONE) return -1;
-    DeviceGuard g(st->device);
+// After the CM kernel: index checks and inverse BWT.  Leaves the data in st->b1, the free buffer in st->b2.
+// Returns false when the block failed.
+bool decode_unbwt(bz3_state * st, Arena & arena, float cm_ms) {
     hipStream_t s = st->stream;
-    HIP_CHECK(hipStreamSynchronize(s));
-    if (p == bz3_state::DEC_STORED) {
-        const u32 got = read_word(st, st->d_words + 1);
-        if (got != st->crc) {
-            st->last_error = BZ3_ERR_CRC;
-            return -1;
-        }
-        return st->size;  // last_error untouched (:691)
-    }
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, st->ev0, st->ev1) == hipSuccess) st->t[BZ3_HIP_T_CM] = ms;
+    st->t[BZ3_HIP_T_CM] = cm_ms;
     const s32 n = st->size_before_bwt;
     if (st->bwt_idx > n) {  // :750-753
         st->last_error = BZ3_ERR_MALFORMED_HEADER;
-        return -1;
+        return false;
     }
-    std::lock_guard<std::mutex> lk(st->ctx->mu);
-    const size_t bound = bz3_bound((size_t)st->block_size);
-    Arena arena = st->ctx->arena_for(workspace_bytes_for(bound + 64));
     u8 *b1 = st->d_swap, *b2 = st->user;  // after the swap of :748
-    double t0 = now_ms();
+    const double t0 = now_ms();
     // libsais_unbwt's own argument checks (include/libsais.h:5210-5232)
     if (n <= 1) {
-        if (st->bwt_idx != n) { st->last_error = BZ3_ERR_BWT; return -1; }
+        if (st->bwt_idx != n) { st->last_error = BZ3_ERR_BWT; return false; }
         if (n == 1) HIP_CHECK(hipMemcpyAsync(b2, b1, 1, hipMemcpyDeviceToDevice, s));
     } else {
-        if (st->bwt_idx <= 0) { st->last_error = BZ3_ERR_BWT; return -1; }
+        if (st->bwt_idx <= 0) { st->last_error = BZ3_ERR_BWT; return false; }
         bwt_inverse(b1, (u32)n, (u32)st->bwt_idx, b2, arena, s);  // :758
     }
-    { u8 * tmp = b1; b1 = b2; b2 = tmp; }
+    st->b1 = b2;
+    st->b2 = b1;
+    st->size_src = n;
     st->t[BZ3_HIP_T_BWT] = (float)(now_ms() - t0);
-    s32 size_src = n;
-    if (st->model & 2) {  // :767-781
-        t0 = now_ms();
-        size_src = lzp_decode(b1, (u32)st->lzp_size, b2, (u32)bound, arena, s);
-        st->t[BZ3_HIP_T_LZP] = (float)(now_ms() - t0);
-        if (size_src == -1) { st->last_error = BZ3_ERR_CRC; return -1; }
-        if ((size_t)size_src > st->buffer_size) { st->last_error = BZ3_ERR_DATA_SIZE_TOO_SMALL; return -1; }
+    return true;
+}
+
+// After the LZP kernel (if any): mRLE decode, size checks, copy back, CRC.
+void decode_finish(bz3_state * st, Arena & arena) {
+    hipStream_t s = st->stream;
+    const size_t bound = bz3_bound((size_t)st->block_size);
+    (void)bound;
+    u8 *b1 = st->b1, *b2 = st->b2;
+    s32 size_src = st->size_src;
+    if (st->model & 2) {  // :767-781 (the kernel already ran; its result is in d_words[5])
+        size_src = (s32)read_word(s, st->d_words + 5);
+        if (size_src == -1) { st->last_error = BZ3_ERR_CRC; return; }
+        if ((size_t)size_src > st->buffer_size) { st->last_error = BZ3_ERR_DATA_SIZE_TOO_SMALL; return; }
         u8 * tmp = b1; b1 = b2; b2 = tmp;
     }
     if (st->model & 4) {  // :783-792
-        t0 = now_ms();
+        const double t0 = now_ms();
         bool bad = size_src < 32;  // mrled: `if (maxin < 32) return 1`
         if (!bad) {
             mrle_decode(b1, (u32)size_src, b2, (u32)st->orig_size, st->d_words + 4, arena, s);
-            bad = read_word(st, st->d_words + 4) != (u32)st->orig_size;
+            bad = read_word(s, st->d_words + 4) != (u32)st->orig_size;
         }
         st->t[BZ3_HIP_T_RLE] = (float)(now_ms() - t0);
-        if (bad) { st->last_error = BZ3_ERR_CRC; return -1; }
+        if (bad) { st->last_error = BZ3_ERR_CRC; return; }
         size_src = st->orig_size;
         u8 * tmp = b1; b1 = b2; b2 = tmp;
     }
     st->last_error = BZ3_OK;  // :794
     if (size_src > st->block_size || size_src < 0) {  // :796-799
         st->last_error = BZ3_ERR_MALFORMED_HEADER;
-        return -1;
+        return;
     }
     if (b1 != st->user) {  // :801
-        t0 = now_ms();
+        const double t0 = now_ms();
         HIP_CHECK(hipMemcpyAsync(st->user, b1, (size_t)size_src, hipMemcpyDeviceToDevice, s));
         HIP_CHECK(hipStreamSynchronize(s));
         st->t[BZ3_HIP_T_COPY] += (float)(now_ms() - t0);
     }
-    t0 = now_ms();
+    const double t0 = now_ms();
     crc32c_device(st->user, (u64)size_src, 1u, st->ctx->d_crc, st->d_words, s);  // :803
-    const u32 got = read_word(st, st->d_words + 1);
+    const u32 got = read_word(s, st->d_words + 1);
     st->t[BZ3_HIP_T_CRC] = (float)(now_ms() - t0);
     if (got != st->crc) {
         st->last_error = BZ3_ERR_CRC;
-        return -1;
+        return;
     }
-    return size_src;
+    st->result = size_src;
 }
 
+// hdrs: n x 17 bytes (host copies of the block headers).
+void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, const s32 * sizes, const s32 * orig_sizes, const u8 * hdrs, s32 n) {
+    if (n <= 0) return;
+    bz3_state * lead = sts[0];
+    DeviceGuard g(lead->device);
+    std::lock_guard<std::mutex> lk(lead->ctx->mu);
+    hipStream_t s = lead->stream;
+    size_t need = 0;
+    for (s32 i = 0; i < n; i++) {
+        const size_t w = workspace_bytes_for(bz3_bound((size_t)sts[i]->block_size) + 64);
+        if (w > need) need = w;
+    }
+    // ---- phase 1: headers, then ONE CM launch ------------------------------------------------------------
+    std::vector<CmDecodeJob> cm_jobs;
+    for (s32 i = 0; i < n; i++) {
+        decode_front(sts[i], bufs[i], buffer_sizes[i], sizes[i], orig_sizes[i], hdrs + 17 * (size_t)i);
+        if (sts[i]->pending == bz3_state::DEC_CODED)
+            cm_jobs.push_back(CmDecodeJob{sts[i]->cm_in, sts[i]->cm_in_size, sts[i]->d_swap, (u32)sts[i]->size_before_bwt});
+    }
+    size_t n_lzp = 0;
+    for (s32 i = 0; i < n; i++)
+        if (sts[i]->pending == bz3_state::DEC_CODED && (sts[i]->model & 2)) n_lzp++;
+    Arena arena = lead->ctx->arena_for(need + n_lzp * LZP_LUT_WORDS * 4 + (size_t)n * 256 + 4096);
+    float cm_ms = 0.f;
+    if (!cm_jobs.empty()) {
+        CmDecodeJob * d_jobs = arena.take<CmDecodeJob>(cm_jobs.size());
+        HIP_CHECK(hipMemcpyAsync(d_jobs, cm_jobs.data(), sizeof(CmDecodeJob) * cm_jobs.size(), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipEventRecord(lead->ev0, s));
+        cm_decode_batch(d_jobs, (u32)cm_jobs.size(), s);
+        HIP_CHECK(hipEventRecord(lead->ev1, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        (void)hipEventElapsedTime(&cm_ms, lead->ev0, lead->ev1);
+    }
+    // ---- phase 2: inverse BWT per block; collect the LZP jobs --------------------------------------------
+    std::vector<LzpDecodeJob> lz_jobs;
+    LzpDecodeJob * d_lz = n_lzp ? arena.take<LzpDecodeJob>(n_lzp) : nullptr;
+    u32 * luts = n_lzp ? arena.take<u32>(n_lzp * LZP_LUT_WORDS) : nullptr;
+    std::vector<char> alive((size_t)n, 0);
+    for (s32 i = 0; i < n; i++) {
+        bz3_state * st = sts[i];
+        if (st->pending == bz3_state::DEC_STORED) {  // :686-691
+            HIP_CHECK(hipStreamSynchronize(st->stream));
+            if (read_word(st->stream, st->d_words + 1) != st->crc) st->last_error = BZ3_ERR_CRC;
+            else st->result = st->size;  // last_error untouched (:691)
+            continue;
+        }
+        if (st->pending != bz3_state::DEC_CODED) continue;
+        if (!decode_unbwt(st, arena, cm_ms)) continue;
+        alive[(size_t)i] = 1;
+        if (st->model & 2) {
+            if (st->lzp_size < 4) {  // lzp_decompress: `if (n < 4) return -1` (:252) -> BZ3_ERR_CRC (:769-771)
+                st->last_error = BZ3_ERR_CRC;
+                alive[(size_t)i] = 0;
+                continue;
+            }
+            const size_t bound = bz3_bound((size_t)st->block_size);
+            lz_jobs.push_back(LzpDecodeJob{st->b1, (u32)st->lzp_size, st->b2, (u32)bound, luts + lz_jobs.size() * LZP_LUT_WORDS,
+                                           reinterpret_cast<s32 *>(st->d_words + 5)});
+        }
+    }
+    // ---- phase 3: ONE LZP-decode launch (one workgroup per block) -----------------------------------------
+    if (!lz_jobs.empty()) {
+        const double t0 = now_ms();
+        lzp_decode_batch(lz_jobs.data(), d_lz, (u32)lz_jobs.size(), s);
+        HIP_CHECK(hipStreamSynchronize(s));
+        const float ms = (float)(now_ms() - t0);
+        for (s32 i = 0; i < n; i++)
+            if (alive[(size_t)i] && (sts[i]->model & 2)) sts[i]->t[BZ3_HIP_T_LZP] = ms;
+    }
+    // ---- phase 4: mRLE, CRC ---------------------------------------------------------------------------------
+    for (s32 i = 0; i < n; i++)
+        if (alive[(size_t)i]) decode_finish(sts[i], arena);
+    for (s32 i = 0; i < n; i++) sts[i]->pending = bz3_state::NONE;
+}
+
+void on_failure(bz3_state * st) {
+    if (st) {
+        st->last_error = BZ3_ERR_BWT;
+        st->pending = bz3_state::NONE;
+        st->result = -1;
+    }
+}
+
+// Splits a batch by device (states may live on different GPUs) and runs each group.
 template <typename F>
-auto guarded(bz3_state * st, s32 fail_value, F && f) -> decltype(f()) {
-    try {
-        return f();
-    } catch (const HipError & e) {
-        fprintf(stderr, "bzip3_amd: HIP failure '%s' at %s:%d\n", e.what, e.file, e.line);
-        if (st) { st->last_error = BZ3_ERR_BWT; st->pending = bz3_state::NONE; }
-        return (decltype(f()))fail_value;
-    } catch (const std::bad_alloc &) {
-        if (st) { st->last_error = BZ3_ERR_BWT; st->pending = bz3_state::NONE; }
-        return (decltype(f()))fail_value;
+void for_each_device_group(bz3_state ** states, s32 n, F && f) {
+    std::vector<char> done((size_t)n, 0);
+    for (s32 i = 0; i < n; i++) {
+        if (done[(size_t)i]) continue;
+        std::vector<s32> idx;
+        for (s32 j = i; j < n; j++)
+            if (!done[(size_t)j] && states[j]->device == states[i]->device) { idx.push_back(j); done[(size_t)j] = 1; }
+        try {
+            f(idx);
+        } catch (const HipError & e) {
+            fprintf(stderr, "bzip3_amd: HIP failure '%s' at %s:%d\n", e.what, e.file, e.line);
+            for (s32 j : idx) on_failure(states[j]);
+        } catch (const std::bad_alloc &) {
+            for (s32 j : idx) on_failure(states[j]);
+        }
+    }
+}
+
+void run_encode(bz3_state ** states, void ** buffers, s32 * sizes, s32 n) {
+    for_each_device_group(states, n, [&](const std::vector<s32> & idx) {
+        std::vector<bz3_state *> sts;
+        std::vector<u8 *> bufs;
+        std::vector<s32> szs;
+        for (s32 j : idx) { sts.push_back(states[j]); bufs.push_back((u8 *)buffers[j]); szs.push_back(sizes[j]); }
+        encode_group(sts.data(), bufs.data(), szs.data(), (s32)idx.size());
+    });
+    for (s32 i = 0; i < n; i++) sizes[i] = states[i]->result;
+}
+
+void run_decode(bz3_state ** states, void ** buffers, const size_t * buffer_sizes, const s32 * sizes, const s32 * orig_sizes, const u8 * hdrs, s32 n) {
+    for_each_device_group(states, n, [&](const std::vector<s32> & idx) {
+        std::vector<bz3_state *> sts;
+        std::vector<u8 *> bufs;
+        std::vector<size_t> bsz;
+        std::vector<s32> csz, osz;
+        std::vector<u8> hd;
+        for (s32 j : idx) {
+            sts.push_back(states[j]); bufs.push_back((u8 *)buffers[j]); bsz.push_back(buffer_sizes[j]); csz.push_back(sizes[j]); osz.push_back(orig_sizes[j]);
+            hd.insert(hd.end(), hdrs + 17 * (size_t)j, hdrs + 17 * (size_t)j + 17);
+        }
+        decode_group(sts.data(), bufs.data(), bsz.data(), csz.data(), osz.data(), hd.data(), (s32)idx.size());
+    });
+}
+
+// Host copies of the first 17 bytes of n device-resident blocks.
+void fetch_headers(bz3_state ** states, void ** buffers, const size_t * buffer_sizes, s32 n, std::vector<u8> & hdrs) {
+    hdrs.assign(17 * (size_t)n, 0);
+    for (s32 i = 0; i < n; i++) {
+        const size_t take = buffer_sizes[i] < 17 ? buffer_sizes[i] : 17;
+        if (take < 9) continue;
+        try {
+            HIP_CHECK(hipSetDevice(states[i]->device));
+            HIP_CHECK(hipMemcpyAsync(hdrs.data() + 17 * (size_t)i, buffers[i], take, hipMemcpyDeviceToHost, states[i]->stream));
+            HIP_CHECK(hipStreamSynchronize(states[i]->stream));
+        } catch (const HipError &) {
+        }
     }
 }
 
@@ -550,160 +708,110 @@ BZIP3_API size_t bz3_min_memory_needed(int32_t block_size) {
 }
 
 // ---- device-resident entry points (bz3_hip.h) -----------------------------------------------------
-BZIP3_API int32_t bz3_hip_encode_block_device(struct bz3_state * st, void * buffer, int32_t size) {
-    return guarded(st, -1, [&]() -> s32 {
-        encode_front(st, (u8 *)buffer, size);
-        return encode_finish(st);
-    });
-}
-
-BZIP3_API int32_t bz3_hip_decode_block_device(struct bz3_state * st, void * buffer, size_t buffer_size, int32_t compressed_size,
-                                              int32_t orig_size) {
-    return guarded(st, -1, [&]() -> s32 {
-        u8 hdr[17] = {0};
-        const size_t take = buffer_size < sizeof hdr ? buffer_size : sizeof hdr;
-        if (take >= 9) {
-            HIP_CHECK(hipSetDevice(st->device));
-            HIP_CHECK(hipMemcpyAsync(hdr, buffer, take, hipMemcpyDeviceToHost, st->stream));
-            HIP_CHECK(hipStreamSynchronize(st->stream));
-        }
-        decode_front(st, (u8 *)buffer, buffer_size, compressed_size, orig_size, hdr);
-        return decode_finish(st);
-    });
-}
-
 BZIP3_API void bz3_hip_encode_blocks_device(struct bz3_state * states[], void * buffers[], int32_t sizes[], int32_t n) {
-    for (s32 i = 0; i < n; i++) guarded(states[i], 0, [&]() -> s32 { encode_front(states[i], (u8 *)buffers[i], sizes[i]); return 0; });
-    for (s32 i = 0; i < n; i++) sizes[i] = guarded(states[i], -1, [&]() -> s32 { return encode_finish(states[i]); });
+    run_encode(states, buffers, sizes, n);
 }
 
 BZIP3_API void bz3_hip_decode_blocks_device(struct bz3_state * states[], void * buffers[], size_t buffer_sizes[], int32_t sizes[],
                                             int32_t orig_sizes[], int32_t n) {
-    for (s32 i = 0; i < n; i++)
-        guarded(states[i], 0, [&]() -> s32 {
-            bz3_state * st = states[i];
-            u8 hdr[17] = {0};
-            const size_t take = buffer_sizes[i] < sizeof hdr ? buffer_sizes[i] : sizeof hdr;
-            if (take >= 9) {
-                HIP_CHECK(hipSetDevice(st->device));
-                HIP_CHECK(hipMemcpyAsync(hdr, buffers[i], take, hipMemcpyDeviceToHost, st->stream));
-                HIP_CHECK(hipStreamSynchronize(st->stream));
-            }
-            decode_front(st, (u8 *)buffers[i], buffer_sizes[i], sizes[i], orig_sizes[i], hdr);
-            return 0;
-        });
-    for (s32 i = 0; i < n; i++) guarded(states[i], -1, [&]() -> s32 { return decode_finish(states[i]); });
+    std::vector<u8> hdrs;
+    fetch_headers(states, buffers, buffer_sizes, n, hdrs);
+    run_decode(states, buffers, buffer_sizes, sizes, orig_sizes, hdrs.data(), n);
 }
 
-// ---- host-buffer entry points (libbz3.h) ------------------------------------------------------------
-BZIP3_API int32_t bz3_encode_block(struct bz3_state * st, uint8_t * buffer, int32_t size) {
-    return guarded(st, -1, [&]() -> s32 {
-        if (size > st->block_size || size < 0) {
-            st->last_error = BZ3_ERR_DATA_TOO_BIG;
-            return -1;
-        }
-        HIP_CHECK(hipSetDevice(st->device));
-        ensure_io(st);
-        double t0 = now_ms();
-        HIP_CHECK(hipMemcpyAsync(st->d_io, buffer, (size_t)size, hipMemcpyHostToDevice, st->stream));
-        HIP_CHECK(hipStreamSynchronize(st->stream));
-        const float h2d = (float)(now_ms() - t0);
-        encode_front(st, st->d_io, size);
-        const s32 r = encode_finish(st);
-        if (r > 0) {
-            t0 = now_ms();
-            HIP_CHECK(hipMemcpyAsync(buffer, st->d_io, (size_t)r, hipMemcpyDeviceToHost, st->stream));
-            HIP_CHECK(hipStreamSynchronize(st->stream));
-            st->t[BZ3_HIP_T_COPY] += h2d + (float)(now_ms() - t0);
-        }
-        return r;
-    });
+BZIP3_API int32_t bz3_hip_encode_block_device(struct bz3_state * st, void * buffer, int32_t size) {
+    s32 sz = size;
+    run_encode(&st, &buffer, &sz, 1);
+    return sz;
 }
 
-BZIP3_API int32_t bz3_decode_block(struct bz3_state * st, uint8_t * buffer, size_t buffer_size, int32_t compressed_size, int32_t orig_size) {
-    return guarded(st, -1, [&]() -> s32 {
-        // the size checks that protect the H2D copy are the reference's first two (:658, :667)
-        if (buffer_size < 9 || buffer_size < (size_t)compressed_size) {
-            st->last_error = BZ3_ERR_DATA_SIZE_TOO_SMALL;
-            return -1;
-        }
-        if (compressed_size < 0 || (size_t)compressed_size > bz3_bound((size_t)st->block_size)) {
-            st->last_error = BZ3_ERR_MALFORMED_HEADER;
-            return -1;
-        }
-        HIP_CHECK(hipSetDevice(st->device));
-        ensure_io(st);
-        u8 hdr[17] = {0};
-        memcpy(hdr, buffer, buffer_size < sizeof hdr ? buffer_size : sizeof hdr);
-        double t0 = now_ms();
-        HIP_CHECK(hipMemcpyAsync(st->d_io, buffer, (size_t)compressed_size, hipMemcpyHostToDevice, st->stream));
-        HIP_CHECK(hipStreamSynchronize(st->stream));
-        const float h2d = (float)(now_ms() - t0);
-        decode_front(st, st->d_io, buffer_size, compressed_size, orig_size, hdr);
-        const s32 r = decode_finish(st);
-        if (r > 0) {
-            t0 = now_ms();
-            HIP_CHECK(hipMemcpyAsync(buffer, st->d_io, (size_t)r, hipMemcpyDeviceToHost, st->stream));
-            HIP_CHECK(hipStreamSynchronize(st->stream));
-            st->t[BZ3_HIP_T_COPY] += h2d + (float)(now_ms() - t0);
-        }
-        return r;
-    });
+BZIP3_API int32_t bz3_hip_decode_block_device(struct bz3_state * st, void * buffer, size_t buffer_size, int32_t compressed_size,
+                                              int32_t orig_size) {
+    bz3_hip_decode_blocks_device(&st, &buffer, &buffer_size, &compressed_size, &orig_size, 1);
+    return st->result;
 }
 
+// ---- host-buffer entry points (libbz3.h): stage through the state's d_io, then run the device path ------
 BZIP3_API void bz3_encode_blocks(struct bz3_state * states[], uint8_t * buffers[], int32_t sizes[], int32_t n) {
-    // upload everything, run all front halves (CM kernels pile up on their streams), join, download
-    for (s32 i = 0; i < n; i++)
-        guarded(states[i], 0, [&]() -> s32 {
-            bz3_state * st = states[i];
-            st->pending = bz3_state::FAILED;
-            if (sizes[i] > st->block_size || sizes[i] < 0) { st->last_error = BZ3_ERR_DATA_TOO_BIG; return 0; }
+    std::vector<void *> dev((size_t)n, nullptr);
+    std::vector<s32> in_sizes(sizes, sizes + n);
+    for (s32 i = 0; i < n; i++) {
+        bz3_state * st = states[i];
+        try {
             HIP_CHECK(hipSetDevice(st->device));
             ensure_io(st);
-            HIP_CHECK(hipMemcpyAsync(st->d_io, buffers[i], (size_t)sizes[i], hipMemcpyHostToDevice, st->stream));
-            HIP_CHECK(hipStreamSynchronize(st->stream));
-            encode_front(st, st->d_io, sizes[i]);
-            return 0;
-        });
-    for (s32 i = 0; i < n; i++)
-        sizes[i] = guarded(states[i], -1, [&]() -> s32 {
-            bz3_state * st = states[i];
-            const s32 r = encode_finish(st);
-            if (r > 0) {
-                HIP_CHECK(hipMemcpyAsync(buffers[i], st->d_io, (size_t)r, hipMemcpyDeviceToHost, st->stream));
+            dev[(size_t)i] = st->d_io;
+            if (sizes[i] >= 0 && sizes[i] <= st->block_size) {
+                const double t0 = now_ms();
+                HIP_CHECK(hipMemcpyAsync(st->d_io, buffers[i], (size_t)sizes[i], hipMemcpyHostToDevice, st->stream));
                 HIP_CHECK(hipStreamSynchronize(st->stream));
+                st->t[BZ3_HIP_T_COPY] = (float)(now_ms() - t0);
             }
-            return r;
-        });
+        } catch (const HipError &) {
+            on_failure(st);
+            in_sizes[(size_t)i] = -1;
+        }
+    }
+    run_encode(states, dev.data(), sizes, n);
+    for (s32 i = 0; i < n; i++) {
+        bz3_state * st = states[i];
+        if (sizes[i] <= 0) continue;
+        try {
+            HIP_CHECK(hipSetDevice(st->device));
+            HIP_CHECK(hipMemcpyAsync(buffers[i], st->d_io, (size_t)sizes[i], hipMemcpyDeviceToHost, st->stream));
+            HIP_CHECK(hipStreamSynchronize(st->stream));
+        } catch (const HipError &) {
+            on_failure(st);
+            sizes[i] = -1;
+        }
+    }
 }
 
 BZIP3_API void bz3_decode_blocks(struct bz3_state * states[], uint8_t * buffers[], size_t buffer_sizes[], int32_t sizes[], int32_t orig_sizes[],
                                  int32_t n) {
-    for (s32 i = 0; i < n; i++)
-        guarded(states[i], 0, [&]() -> s32 {
-            bz3_state * st = states[i];
-            st->pending = bz3_state::FAILED;
-            if (buffer_sizes[i] < 9 || buffer_sizes[i] < (size_t)sizes[i]) { st->last_error = BZ3_ERR_DATA_SIZE_TOO_SMALL; return 0; }
-            if (sizes[i] < 0 || (size_t)sizes[i] > bz3_bound((size_t)st->block_size)) { st->last_error = BZ3_ERR_MALFORMED_HEADER; return 0; }
+    std::vector<void *> dev((size_t)n, nullptr);
+    std::vector<u8> hdrs(17 * (size_t)n, 0);
+    for (s32 i = 0; i < n; i++) {
+        bz3_state * st = states[i];
+        // the two checks that protect the H2D copy are the reference's first two (:658, :667); decode_front repeats them
+        const bool copy_ok = buffer_sizes[i] >= 9 && buffer_sizes[i] >= (size_t)sizes[i] && sizes[i] >= 0 &&
+                             (size_t)sizes[i] <= bz3_bound((size_t)st->block_size);
+        memcpy(hdrs.data() + 17 * (size_t)i, buffers[i], buffer_sizes[i] < 17 ? buffer_sizes[i] : 17);
+        try {
             HIP_CHECK(hipSetDevice(st->device));
             ensure_io(st);
-            u8 hdr[17] = {0};
-            memcpy(hdr, buffers[i], buffer_sizes[i] < sizeof hdr ? buffer_sizes[i] : sizeof hdr);
-            HIP_CHECK(hipMemcpyAsync(st->d_io, buffers[i], (size_t)sizes[i], hipMemcpyHostToDevice, st->stream));
-            HIP_CHECK(hipStreamSynchronize(st->stream));
-            decode_front(st, st->d_io, buffer_sizes[i], sizes[i], orig_sizes[i], hdr);
-            return 0;
-        });
-    for (s32 i = 0; i < n; i++)
-        guarded(states[i], -1, [&]() -> s32 {
-            bz3_state * st = states[i];
-            const s32 r = decode_finish(st);
-            if (r > 0) {
-                HIP_CHECK(hipMemcpyAsync(buffers[i], st->d_io, (size_t)r, hipMemcpyDeviceToHost, st->stream));
+            dev[(size_t)i] = st->d_io;
+            if (copy_ok) {
+                HIP_CHECK(hipMemcpyAsync(st->d_io, buffers[i], (size_t)sizes[i], hipMemcpyHostToDevice, st->stream));
                 HIP_CHECK(hipStreamSynchronize(st->stream));
             }
-            return r;
-        });
+        } catch (const HipError &) {
+            on_failure(st);
+        }
+    }
+    run_decode(states, dev.data(), buffer_sizes, sizes, orig_sizes, hdrs.data(), n);
+    for (s32 i = 0; i < n; i++) {
+        bz3_state * st = states[i];
+        if (st->result <= 0) continue;
+        try {
+            HIP_CHECK(hipSetDevice(st->device));
+            HIP_CHECK(hipMemcpyAsync(buffers[i], st->d_io, (size_t)st->result, hipMemcpyDeviceToHost, st->stream));
+            HIP_CHECK(hipStreamSynchronize(st->stream));
+        } catch (const HipError &) {
+            on_failure(st);
+        }
+    }
+}
+
+BZIP3_API int32_t bz3_encode_block(struct bz3_state * st, uint8_t * buffer, int32_t size) {
+    s32 sz = size;
+    bz3_encode_blocks(&st, &buffer, &sz, 1);
+    return sz;
+}
+
+BZIP3_API int32_t bz3_decode_block(struct bz3_state * st, uint8_t * buffer, size_t buffer_size, int32_t compressed_size, int32_t orig_size) {
+    bz3_decode_blocks(&st, &buffer, &buffer_size, &compressed_size, &orig_size, 1);
+    return st->result;
 }
 
 // ---- frame API (src/libbz3.c:876-997): thin loops over the block API, same header and error codes ----
@@ -937,7 +1045,11 @@ BZIP3_API int32_t bz3_hip_stage_lzp_decode(const uint8_t * in, int32_t n, uint8_
         u8 * d = e.dev((size_t)n + 64, in, (size_t)n);
         u8 * o = e.dev((size_t)max + 64);
         Arena a = e.ctx->arena_for(workspace_bytes_for((u64)n + 64));
-        const s32 r = lzp_decode(d, (u32)n, o, (u32)max, a, e.s);
+        if (n < 4) return -1;  // :252
+        LzpDecodeJob job{d, (u32)n, o, (u32)max, a.take<u32>(LZP_LUT_WORDS), reinterpret_cast<s32 *>(a.take<u32>(4))};
+        LzpDecodeJob * d_job = a.take<LzpDecodeJob>(1);
+        lzp_decode_batch(&job, d_job, 1, e.s);
+        const s32 r = (s32)e.word(reinterpret_cast<const u32 *>(job.result));
         if (r > 0) e.down(out, o, (size_t)r);
         return r;
     });
@@ -980,7 +1092,9 @@ BZIP3_API int32_t bz3_hip_stage_cm_encode(const uint8_t * in, int32_t n, uint8_t
         u8 * d = e.dev((size_t)n + 64, in, (size_t)n);
         u8 * o = e.dev(bz3_bound((size_t)n) + 64);
         u32 * w = (u32 *)e.dev(64);
-        cm_encode(d, (u32)n, o, w, e.s);
+        CmEncodeJob job{d, (u32)n, o, w};
+        CmEncodeJob * d_job = (CmEncodeJob *)e.dev(sizeof job, &job, sizeof job);
+        cm_encode_batch(d_job, 1, e.s);
         const s32 size = (s32)e.word(w);
         e.down(out, o, (size_t)size);
         return size;
@@ -992,7 +1106,9 @@ BZIP3_API void bz3_hip_stage_cm_decode(const uint8_t * in, int32_t in_size, uint
         StageEnv e;
         u8 * d = e.dev((size_t)in_size + 64, in, (size_t)in_size);
         u8 * o = e.dev((size_t)n + 64);
-        cm_decode(d, (u32)in_size, o, (u32)n, e.s);
+        CmDecodeJob job{d, (u32)in_size, o, (u32)n};
+        CmDecodeJob * d_job = (CmDecodeJob *)e.dev(sizeof job, &job, sizeof job);
+        cm_decode_batch(d_job, 1, e.s);
         e.down(out, o, (size_t)n);
         return 0;
     });

@@ -100,98 +100,114 @@ __device__ __forceinline__ void cm_learn(CmLds & m, const CmProbe & q, u32 node,
 
 // ------------------------------------------------------------------------------------------------
 // encode: two waves.  Wave 1 ("model") walks the block: lanes 0..7 own the 8 tree levels of the current
-// byte, evaluate their node, update the counters and push the 18-bit probabilities into an LDS ring.
-// Wave 0 ("coder") drains the ring and runs the serial (low, range) recurrence in scalar registers.
-// The two overlap; the block finishes at the pace of the slower one (the coder: ~12 scalar
-// instructions per coded bit).
+// byte, evaluate their node, update the counters and push one 16-byte event per coded bit into an LDS ring.
+// Wave 0 ("coder") drains the ring and runs the serial range recurrence.
+//
+// Coder formulation (exact).  With high == low + range, the reference's update
+//     mid = low + ((range * P) >> 18);   bit ? high = mid : low = mid + 1                  (:388, :402)
+// is   bit = 1:  range' = (range * P) >> 18                       low' = low
+//      bit = 0:  range' = (range * (2^18 - P) - 1) >> 18          low' = low + (range - range')
+// (range - ((range*P)>>18) - 1 == ((range*(2^18-P)) - 1) >> 18 for every range, P < 2^18), so the model wave
+// ships (-s, -s, M, s) with M = P or 2^18 - P and the coder needs one v_mad_u64_u32, one 64-bit shift, one
+// v_sub and one v_mad per bit -- no bit test, no selects.  The coder state is deliberately kept in VECTOR
+// registers (seeded through an opaque v_mov): the events arrive in VGPRs from LDS broadcast reads, and moving
+// them to the scalar unit would cost a v_readfirstlane per operand.  A single wave issues one instruction every ~5.4
+// cycles (8.5 when dependent; profiles/r01_ubench_single_wave.txt), so instruction count is the currency.
 // ------------------------------------------------------------------------------------------------
-constexpr u32 CM_RING = 128;  // bytes of look-ahead between the model wave and the coder wave
+constexpr u32 CM_RING = 64;  // bytes of look-ahead between the model wave and the coder wave (8 KiB of LDS)
 
 __device__ __forceinline__ u32 lds_peek(const u32 * p) { return *reinterpret_cast<const volatile u32 *>(p); }
 __device__ __forceinline__ void lds_poke(u32 * p, u32 v) { *reinterpret_cast<volatile u32 *>(p) = v; }
 
-__global__ void __launch_bounds__(128) k_cm_encode(const u8 * __restrict__ in, u32 n, u8 * __restrict__ out, u32 * __restrict__ out_size) {
+__global__ void __launch_bounds__(128) k_cm_encode(const CmEncodeJob * __restrict__ jobs) {
+    // one workgroup per block: blockIdx.x selects the job
+    const u8 * __restrict__ in = jobs[blockIdx.x].in;
+    const u32 n = jobs[blockIdx.x].n;
+    u8 * __restrict__ out = jobs[blockIdx.x].out;
+    u32 * __restrict__ out_size = jobs[blockIdx.x].out_size;
     __shared__ CmLds m;
-    __shared__ u32 ring[CM_RING * 8];
+    __shared__ uint4 ring[CM_RING * 8];
     __shared__ u32 s_prod, s_cons;
     if (threadIdx.x == 0) { s_prod = 0; s_cons = 0; }
     cm_model_init(m);
     const int lane = lane_id();
+    const u32 * __restrict__ in32 = reinterpret_cast<const u32 *>(in);  // block buffers are 256-byte aligned
     if (cm_uniform((u32)wave_id()) == 1) {
         // ---- model wave --------------------------------------------------------------------------
         const u32 k = (u32)lane & 7u;
-        u32 c1 = 0, c2 = 0, run = 0, cons_seen = 0;
-        for (u32 base = 0; base < n; base += 64) {
-            const u32 mine = (base + lane < n) ? in[base + lane] : 0u;
-            const u32 cnt = (n - base < 64u) ? n - base : 64u;
-            for (u32 t = 0; t < cnt; t++) {
-                const u32 i = base + t;
-                while (i - cons_seen >= CM_RING) {  // ring full: wait for the coder
-                    cons_seen = lds_peek(&s_cons);
-                    if (i - cons_seen >= CM_RING) BZ3_SPIN_PAUSE();
-                }
-                const u32 c = cm_readlane(mine, (int)t);
-                run = (c1 == c2) ? run + 1 : 0;  // :367-372
-                const u32 f = run > 2 ? 1u : 0u;
-                const u32 node = (1u << k) | (c >> (8 - k));
-                const u32 bit = (c >> (7 - k)) & 1u;
-                CmProbe q = cm_probe(m, node, c1, c2, f);
-                wave_sync();
-                if (lane < 8) {
-                    cm_learn(m, q, node, c1, bit);
-                    ring[(i & (CM_RING - 1)) * 8 + k] = q.p18;
-                }
-                wave_sync();
-                c2 = c1;
-                c1 = c;
-                if ((i & 3u) == 3u || i + 1 == n) {
-                    lds_release();
-                    if (lane == 0) lds_poke(&s_prod, i + 1);
-                }
+        u32 c1 = 0, c2 = 0, run = 0, cons_seen = 0, word = 0;
+        for (u32 i = 0; i < n; i++) {
+            while (i - cons_seen >= CM_RING) {  // ring full: wait for the coder
+                cons_seen = lds_peek(&s_cons);
+                if (i - cons_seen >= CM_RING) BZ3_SPIN_PAUSE();
+            }
+            if ((i & 3u) == 0) word = cm_uniform(in32[i >> 2]);  // wave-uniform address: a scalar load
+            const u32 c = (word >> ((i & 3u) * 8u)) & 0xFFu;
+            run = (c1 == c2) ? run + 1 : 0;  // :367-372
+            const u32 f = run > 2 ? 1u : 0u;
+            const u32 node = (1u << k) | (c >> (8 - k));
+            const u32 bit = (c >> (7 - k)) & 1u;
+            CmProbe q = cm_probe(m, node, c1, c2, f);
+            wave_sync();
+            if (lane < 8) {
+                cm_learn(m, q, node, c1, bit);
+                const u32 neg = bit ? 0u : 0xFFFFFFFFu;
+                ring[(i & (CM_RING - 1)) * 8 + k] = make_uint4(neg, neg, bit ? q.p18 : (1u << 18) - q.p18, bit ^ 1u);
+            }
+            wave_sync();
+            c2 = c1;
+            c1 = c;
+            if ((i & 3u) == 3u || i + 1 == n) {
+                lds_release();
+                if (lane == 0) lds_poke(&s_prod, i + 1);
             }
         }
         return;
     }
-    // ---- coder wave: high == low + range throughout (:388-394 in (low, range) form) -----------------
-    u32 low = 0, range = 0xFFFFFFFFu, op = 0, prod_seen = 0;
-    for (u32 base = 0; base < n; base += 64) {
-        const u32 mine = (base + lane < n) ? in[base + lane] : 0u;
-        const u32 cnt = (n - base < 64u) ? n - base : 64u;
-        for (u32 t = 0; t < cnt; t++) {
-            const u32 i = base + t;
-            while (prod_seen <= i) {
-                prod_seen = lds_peek(&s_prod);
-                if (prod_seen <= i) BZ3_SPIN_PAUSE();
-            }
-            lds_acquire();
-            const u32 ev = ring[(i & (CM_RING - 1)) * 8 + ((u32)lane & 7u)];
-            const u32 c = cm_readlane(mine, (int)t);
-#pragma unroll
-            for (int kk = 0; kk < 8; kk++) {
-                const u32 p18 = cm_readlane(ev, kk);
-                const u32 tt = (u32)(((u64)range * p18) >> 18);
-                if ((c >> (7 - kk)) & 1u) {
-                    range = tt;  // high = mid
-                } else {
-                    low += tt + 1;  // low = mid + 1
-                    range -= tt + 1;
-                }
-                if (range < (1u << 24)) {  // necessary for (low ^ high) < 2^24; the exact test follows
-                    while ((low ^ (low + range)) < (1u << 24)) {
-                        if (lane == 0) out[op] = (u8)(low >> 24);
-                        op++;
-                        low <<= 8;
-                        range = (range << 8) | 0xFFu;
-                    }
-                }
-            }
-            if ((i & 15u) == 15u && lane == 0) lds_poke(&s_cons, i + 1);
+    // ---- coder wave (every lane carries the same state; lane 0 stores) ---------------------------------
+    u32 vzero;
+#ifdef BZ3_EMU
+    vzero = 0;
+#else
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));  // opaque zero: keeps the recurrence on the vector ALU
+#endif
+    u32 range = 0xFFFFFFFFu ^ vzero, op = 0, prod_seen = 0;
+    u64 low = vzero;  // only the low 32 bits are meaningful
+    for (u32 i = 0; i < n; i++) {
+        while (prod_seen <= i) {
+            prod_seen = lds_peek(&s_prod);
+            if (prod_seen <= i) BZ3_SPIN_PAUSE();
         }
+        lds_acquire();
+        const uint4 * __restrict__ evp = &ring[(i & (CM_RING - 1)) * 8];
+        uint4 ev[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) ev[kk] = evp[kk];  // same address in every lane: LDS broadcast reads
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+            const uint4 e = ev[kk];
+            const u64 prod = (u64)range * e.z + (((u64)e.y << 32) | e.x);
+            const u32 r2 = (u32)(prod >> 18);
+            low += (u64)(range - r2) * e.w;
+            range = r2;
+            if (__ballot(range < (1u << 24)) != 0ull) {  // necessary for (low ^ high) < 2^24; the exact test follows
+                u32 lo32 = (u32)low;
+                while (__ballot((lo32 ^ (lo32 + range)) < (1u << 24)) != 0ull) {  // :390-394
+                    if (lane == 0) out[op] = (u8)(lo32 >> 24);
+                    op++;
+                    lo32 <<= 8;
+                    range = (range << 8) | 0xFFu;
+                }
+                low = lo32;
+            }
+        }
+        if ((i & 15u) == 15u && lane == 0) lds_poke(&s_cons, i + 1);
     }
     if (lane == 0) {  // flush (:425-432)
+        u32 lo32 = (u32)low;
         for (int j = 0; j < 4; j++) {
-            out[op + j] = (u8)(low >> 24);
-            low <<= 8;
+            out[op + j] = (u8)(lo32 >> 24);
+            lo32 <<= 8;
         }
         *out_size = op + 4;
     }
@@ -203,7 +219,11 @@ __global__ void __launch_bounds__(128) k_cm_encode(const u8 * __restrict__ in, u
 // lane), makes the 8 serial decisions with v_readlane + scalar arithmetic, and publishes the byte; the
 // 8 lanes whose node lies on the decoded path then update their counters.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(320) k_cm_decode(const u8 * __restrict__ in, u32 in_size, u8 * __restrict__ out, u32 n) {
+__global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restrict__ jobs) {
+    const u8 * __restrict__ in = jobs[blockIdx.x].in;
+    const u32 in_size = jobs[blockIdx.x].in_size;
+    u8 * __restrict__ out = jobs[blockIdx.x].out;
+    const u32 n = jobs[blockIdx.x].n;
     __shared__ CmLds m;
     __shared__ u32 ptab[256];
     __shared__ u32 s_byte;
@@ -211,7 +231,7 @@ __global__ void __launch_bounds__(320) k_cm_decode(const u8 * __restrict__ in, u
     const int lane = lane_id();
     const bool coder = cm_uniform((u32)wave_id()) == 0;
     const u32 node = threadIdx.x - 64u;  // model lanes only
-    u32 low = 0, range = 0xFFFFFFFFu, x = 0, c1 = 0, c2 = 0, run = 0;  // x = code - low
+    u32 low = 0, range = 0xFFFFFFFFu, code = 0, c1 = 0, c2 = 0, run = 0;
     u32 ip = 0, ibase = 0;
     u32 window = (coder && ibase + lane < in_size) ? in[ibase + lane] : 0xFFFFFFFFu;
 #define CM_NEXT_BYTE(dst)                                                              \
@@ -227,7 +247,7 @@ __global__ void __launch_bounds__(320) k_cm_decode(const u8 * __restrict__ in, u
         for (int j = 0; j < 4; j++) {  // :438-441; bytes past the end read as -1 (:345)
             u32 b;
             CM_NEXT_BYTE(b);
-            x = (x << 8) + b;
+            code = (code << 8) + b;
         }
     }
     u32 staged = 0;
@@ -254,20 +274,21 @@ __global__ void __launch_bounds__(320) k_cm_decode(const u8 * __restrict__ in, u
                     const u32 a = cm_readlane(p2, src), b = cm_readlane(p3, src);
                     p18 = (ctx & 64u) ? b : a;
                 }
-                const u32 tt = (u32)(((u64)range * p18) >> 18);  // mid - low (:464)
-                const bool bit = x <= tt;                        // code <= mid
+                const u32 mid = low + (u32)(((u64)range * p18) >> 18);  // :464 (high == low + range)
+                // NB: the comparison must be on absolute values: a truncated stream feeds -1 bytes (:345) and
+                // can push `code` below `low`, where the reference still decodes a 1.
+                const bool bit = code <= mid;
 #ifdef BZ3_EMU
                 ctx = ctx * 2 + (bit ? 1u : 0u);
 #else
                 // ctx = 2*ctx + bit on the scalar unit (keeps the node index out of vector registers)
-                asm volatile("s_cmp_le_u32 %1, %2\n\ts_addc_u32 %0, %0, %0" : "+s"(ctx) : "s"(x), "s"(tt) : "scc");
+                asm volatile("s_cmp_le_u32 %1, %2\n\ts_addc_u32 %0, %0, %0" : "+s"(ctx) : "s"(code), "s"(mid) : "scc");
 #endif
                 if (bit) {
-                    range = tt;
+                    range = mid - low;
                 } else {
-                    low += tt + 1;
-                    x -= tt + 1;
-                    range -= tt + 1;
+                    range -= mid - low + 1;
+                    low = mid + 1;
                 }
                 if (range < (1u << 24)) {
                     while ((low ^ (low + range)) < (1u << 24)) {  // :470-474
@@ -275,7 +296,7 @@ __global__ void __launch_bounds__(320) k_cm_decode(const u8 * __restrict__ in, u
                         range = (range << 8) | 0xFFu;
                         u32 b;
                         CM_NEXT_BYTE(b);
-                        x = (x << 8) + b;
+                        code = (code << 8) + b;
                     }
                 }
             }
@@ -299,12 +320,12 @@ __global__ void __launch_bounds__(320) k_cm_decode(const u8 * __restrict__ in, u
 #undef CM_NEXT_BYTE
 }
 
-void cm_encode(const u8 * d_in, u32 n, u8 * d_out, u32 * d_out_size, hipStream_t s) {
-    launch(k_cm_encode, dim3(1), dim3(128), 0, s, d_in, n, d_out, d_out_size);
+void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s) {
+    if (njobs) launch(k_cm_encode, dim3(njobs), dim3(128), 0, s, d_jobs);
 }
 
-void cm_decode(const u8 * d_in, u32 in_size, u8 * d_out, u32 n, hipStream_t s) {
-    launch(k_cm_decode, dim3(1), dim3(320), 0, s, d_in, in_size, d_out, n);
+void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s) {
+    if (njobs) launch(k_cm_decode, dim3(njobs), dim3(320), 0, s, d_jobs);
 }
 
 }  // namespace bz3

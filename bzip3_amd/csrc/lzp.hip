@@ -7,14 +7,17 @@
 // match are the only ones not visited.  So:
 //   1. prev[p] = previous position with the same hash, ALL positions assumed visited.  Grid-parallel:
 //      one stable radix sort of (hash, position) with sort.hip, neighbours in sorted order.
-//   2. A single workgroup (the "driver") walks the block in 4096-position tiles.  Every lane resolves
-//      its candidate (prev chain, skipping positions already swallowed by matches), runs the
-//      reference's 8-byte pre-test and, for the few positions that pass ("events"), records a
-//      48-bit byte-equality mask.  One lane then replays the `heur` chain over the events in order
-//      using only those masks; the first event that reaches 40 matching bytes is a real match: the
-//      whole workgroup measures its length, marks the swallowed positions, and the tile restarts
-//      behind it.  Text has few events and very few matches; repetitive data has few, long matches.
-//   3. Emission is grid-parallel again: per-position output counts (literal / escaped 0xF2 literal /
+//   2. Grid-parallel "static" pass: every position runs the reference's 8-byte pre-test against prev[p]
+//      and the positions that pass are flagged in a bitmap (0.02-0.5 % of a text block).
+//   3. A single workgroup (the "driver") visits only flagged positions, 131072 positions per bitmap
+//      window: lanes resolve the true candidate of each flagged position (prev chain, skipping positions
+//      already swallowed by matches), re-run the pre-test and record a 48-bit byte-equality mask.  One
+//      lane replays the reference's `heur` chain over these events in order using only the masks; the
+//      first event that reaches 40 matching bytes is a real match: the whole workgroup measures its
+//      length, marks the swallowed positions and flags next[s] of every swallowed s (the only positions
+//      whose candidate just changed), then the scan resumes behind the match.  Driver work is
+//      proportional to the number of events and matches, not to the block size.
+//   4. Emission is grid-parallel again: per-position output counts (literal / escaped 0xF2 literal /
 //      match token), device-wide scan, scatter.
 // Decode mirrors it: literals between two 0xF2 bytes are copied and inserted into the table in bulk
 // (scatter-max), every 0xF2 is a sequencing point resolved against the table.
@@ -28,109 +31,223 @@ constexpr int LZ_HASH_BITS = 18;   // LZP_DICTIONARY, :84
 constexpr int LZ_MIN = 40;         // LZP_MIN_MATCH, :85
 constexpr u8 LZ_ESC = 0xF2;        // MATCH, :87
 constexpr int LZ_DRV = 1024;       // driver workgroup size
-constexpr int LZ_TILE = 4096;      // positions per driver iteration
 constexpr int LZ_BLOCK = 256;
 constexpr int LZ_ITEMS = 16;
 constexpr int LZ_ETILE = LZ_BLOCK * LZ_ITEMS;
 
 __device__ __forceinline__ u32 lz_hash(u32 ctx) { return ((ctx >> 15) ^ ctx ^ (ctx >> 3)) & ((1u << LZ_HASH_BITS) - 1u); }
-__device__ __forceinline__ bool lz_eq4(const u8 * __restrict__ a, const u8 * __restrict__ b) {
-    return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3];
-}
+__device__ __forceinline__ bool lz_eq4(const u8 * __restrict__ a, const u8 * __restrict__ b) { return load_u32_any(a) == load_u32_any(b); }
 __device__ __forceinline__ bool lz_skipped(const u32 * __restrict__ skip, u32 p) { return (skip[p >> 5] >> (p & 31)) & 1u; }
 
-// ---- 1. predecessor array ---------------------------------------------------------------------
+// ---- 1. predecessor / successor links -------------------------------------------------------------
 __global__ void __launch_bounds__(LZ_BLOCK) k_lzp_hash(const u8 * __restrict__ in, u32 n, u32 * __restrict__ keys) {
     const u32 k = blockIdx.x * LZ_BLOCK + threadIdx.x;  // position p = k + 4
-    if (k + 4 < n + 0u && k + 4 >= 4) keys[k] = lz_hash(load_be32(in + k));
+    if (k + 4 < n) keys[k] = lz_hash(load_be32(in + k));
 }
 
-__global__ void __launch_bounds__(LZ_BLOCK) k_lzp_prev(const u32 * __restrict__ keys, const u32 * __restrict__ vals, u32 m, u32 * __restrict__ prev) {
+__global__ void __launch_bounds__(LZ_BLOCK) k_lzp_links(const u32 * __restrict__ keys, const u32 * __restrict__ vals, u32 m, u32 * __restrict__ prev,
+                                                       u32 * __restrict__ next) {
     const u32 k = blockIdx.x * LZ_BLOCK + threadIdx.x;
     if (k >= m) return;
-    prev[vals[k] + 4] = (k > 0 && keys[k] == keys[k - 1]) ? vals[k - 1] + 4 : 0u;
+    const u32 key = keys[k], p = vals[k] + 4;
+    prev[p] = (k > 0 && keys[k - 1] == key) ? vals[k - 1] + 4 : 0u;
+    next[p] = (k + 1 < m && keys[k + 1] == key) ? vals[k + 1] + 4 : 0u;
 }
 
-// Nearest visited ancestor of p in its hash chain (0 = none).
-__device__ __forceinline__ u32 lz_candidate(const u32 * __restrict__ prev, const u32 * __restrict__ skip, u32 p) {
+// Nearest visited ancestor of p in its hash chain (0 = none).  Swallowed positions are never un-swallowed, so
+// every link of the walked path may be short-cut to the answer (path compression): without it a phrase that
+// recurs k times costs O(k) per later occurrence, because all but its first copy sit inside earlier matches.
+// Concurrent walkers only ever write the same value into the same link, so the race is benign.
+__device__ __forceinline__ u32 lz_candidate(u32 * __restrict__ prev, const u32 * __restrict__ skip, u32 p) {
     u32 v = prev[p];
-    while (v != 0 && lz_skipped(skip, v)) v = prev[v];
+    if (v == 0 || !lz_skipped(skip, v)) return v;
+    u32 steps = 0;
+    while (v != 0 && lz_skipped(skip, v)) { v = prev[v]; steps++; }
+    if (steps > 1) {
+        u32 x = prev[p];
+        prev[p] = v;
+        while (x != v && x != 0) {
+            const u32 nx = prev[x];
+            prev[x] = v;
+            x = nx;
+        }
+    }
     return v;
 }
 
-// ---- 2. driver ----------------------------------------------------------------------------------
+__device__ __forceinline__ bool lz_pretest(const u8 * __restrict__ in, u32 p, u32 v) {  // :143-144
+    // all four loads are issued before the first compare (no short-circuit: one memory round trip, not four)
+    const u32 a0 = load_u32_any(in + p), b0 = load_u32_any(in + v);
+    const u32 a1 = load_u32_any(in + p + LZ_MIN - 4), b1 = load_u32_any(in + v + LZ_MIN - 4);
+    return ((a0 ^ b0) | (a1 ^ b1)) == 0;
+}
+
+// bit b of the result = (in[p+b] == in[v+b]) for b < 48
+__device__ __forceinline__ u64 lz_eqmask48(const u8 * __restrict__ in, u32 p, u32 v) {
+    u32 x[12];
+#pragma unroll
+    for (int w = 0; w < 12; w++) x[w] = load_u32_any(in + p + 4 * w) ^ load_u32_any(in + v + 4 * w);
+    u64 mask = 0;
+#pragma unroll
+    for (int w = 0; w < 12; w++) {
+        const u32 t = x[w];
+        const u32 nib = ((t & 0xFFu) == 0 ? 1u : 0u) | ((t & 0xFF00u) == 0 ? 2u : 0u) | ((t & 0xFF0000u) == 0 ? 4u : 0u) | ((t & 0xFF000000u) == 0 ? 8u : 0u);
+        mask |= (u64)nib << (4 * w);
+    }
+    return mask;
+}
+
+// ---- 2. static events: one bit per position whose hash predecessor passes the pre-test ---------------
+__global__ void __launch_bounds__(LZ_BLOCK) k_lzp_static(const u8 * __restrict__ in, u32 n, const u32 * __restrict__ prev, u32 * __restrict__ cand_bits,
+                                                        u32 nwords) {
+    const u32 main_end = n - (LZ_MIN + 32);
+    const u64 wave_global = (u64)blockIdx.x * (LZ_BLOCK / WAVE) + wave_id();
+    const u64 stride = (u64)gridDim.x * (LZ_BLOCK / WAVE);
+    for (u64 base = wave_global * WAVE; base < (u64)nwords * 32; base += stride * WAVE) {
+        const u64 p = base + lane_id();
+        bool ev = false;
+        if (p >= 4 && p < main_end) {
+            const u32 v = prev[p];
+            ev = v > 0 && lz_pretest(in, (u32)p, v);
+        }
+        const u64 bits = __ballot(ev);
+        if (lane_id() == 0) {
+            const u32 w = (u32)(base >> 5);
+            if (w < nwords) cand_bits[w] = (u32)bits;
+            if (w + 1 < nwords) cand_bits[w + 1] = (u32)(bits >> 32);
+        }
+    }
+}
+
+// ---- 3. driver ----------------------------------------------------------------------------------
+constexpr int LZ_EV_CAP = 2048;              // events resolved per driver iteration
+constexpr int LZ_WIN_WORDS = 4 * LZ_DRV;     // bitmap words scanned per iteration (131072 positions)
+
 struct LzDriverOut {
     u32 end_pos;    // first position handled by the tail loop (>= n - 72)
     u32 n_matches;
+    u32 iterations; // driver loop iterations            } profiling counters
+    u32 evaluated;  // flagged positions it resolved     }
 };
 
-__global__ void __launch_bounds__(LZ_DRV) k_lzp_driver(const u8 * __restrict__ in, u32 n, const u32 * __restrict__ prev, u32 * __restrict__ skip,
-                                                      u32 * __restrict__ mlen, LzDriverOut * __restrict__ result) {
-    __shared__ u32 ev_pos[LZ_TILE];
-    __shared__ u32 ev_ref[LZ_TILE];
-    __shared__ u64 ev_mask[LZ_TILE];
+__global__ void __launch_bounds__(LZ_DRV) k_lzp_driver(const u8 * __restrict__ in, u32 n, u32 * __restrict__ prev, const u32 * __restrict__ next,
+                                                      u32 * __restrict__ cand_bits, u32 nwords, u32 * __restrict__ skip, u32 * __restrict__ mstart,
+                                                      u32 * __restrict__ mpos, u32 * __restrict__ mlen, LzDriverOut * __restrict__ result) {
+    __shared__ u32 cq[LZ_EV_CAP];
+    __shared__ u32 ev_ref[LZ_EV_CAP];
+    __shared__ u64 ev_mask[LZ_EV_CAP];
     __shared__ u32 red[LZ_DRV / WAVE + 1];
-    __shared__ u32 s_cur, s_heur, s_nev, s_accept, s_len, s_matches;
+    __shared__ u32 s_cur, s_heur, s_accept, s_len, s_matches;
     const u32 tid = threadIdx.x;
     const u32 main_end = n - (LZ_MIN + 32);  // the main loop handles positions < n - 72 (:137)
+    u32 iterations = 0, evaluated = 0;
     if (tid == 0) { s_cur = 4; s_heur = 0; s_matches = 0; }
     __syncthreads();
     for (;;) {
         const u32 cur = s_cur;
         if (cur >= main_end) break;
-        const u32 tile_end = (main_end - cur > (u32)LZ_TILE) ? cur + LZ_TILE : main_end;
-        // ---- candidates + 8-byte pre-test, events compacted in position order -------------------
-        u32 nev = 0;
-#pragma unroll 1
-        for (int k = 0; k < LZ_TILE / LZ_DRV; k++) {
-            const u32 p = cur + (u32)k * LZ_DRV + tid;
-            u32 v = 0;
-            bool ev = false;
-            if (p < tile_end) {
-                v = lz_candidate(prev, skip, p);
-                ev = v > 0 && lz_eq4(in + p + LZ_MIN - 4, in + v + LZ_MIN - 4) && lz_eq4(in + p, in + v);
+        iterations++;
+        // ---- scan one bitmap window for flagged positions >= cur ------------------------------------
+        const u32 w0 = (cur >> 5) & ~3u;  // 16-byte aligned window start: one dwordx4 load per lane
+        u32 word[4];
+        u32 cnt = 0;
+        {
+            const u32 wb = w0 + 4u * tid;
+            uint4 q4 = make_uint4(0u, 0u, 0u, 0u);
+            if (wb + 3 < nwords) q4 = *reinterpret_cast<const uint4 *>(cand_bits + wb);
+            else {
+                if (wb < nwords) q4.x = cand_bits[wb];
+                if (wb + 1 < nwords) q4.y = cand_bits[wb + 1];
+                if (wb + 2 < nwords) q4.z = cand_bits[wb + 2];
             }
-            u32 tot;
-            const u32 e = block_excl_add<LZ_DRV>(ev ? 1u : 0u, red, tot);
-            if (ev) {
-                u64 mask = 0;
-                for (int b = 0; b < 48; b++) mask |= (u64)(in[p + b] == in[v + b]) << b;
-                ev_pos[nev + e] = p;
-                ev_ref[nev + e] = v;
-                ev_mask[nev + e] = mask;
+            word[0] = q4.x; word[1] = q4.y; word[2] = q4.z; word[3] = q4.w;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u32 w = wb + (u32)k;
+                if (w < (cur >> 5)) word[k] = 0;
+                else if (w == (cur >> 5)) word[k] &= 0xFFFFFFFFu << (cur & 31u);
+                cnt += (u32)__popc(word[k]);
             }
-            nev += tot;
         }
-        __syncthreads();
-        // ---- replay the heur chain over the events (one lane; masks only, no memory traffic) ----
-        if (tid == 0) {
-            u32 heur = s_heur;
-            u32 accept = 0xFFFFFFFFu;
-            for (u32 e = 0; e < nev; e++) {
-                const u32 p = ev_pos[e];
-                const u64 mask = ev_mask[e];
-                if (heur > p && ((mask >> (heur - p)) & 0xFull) != 0xFull) continue;  // :145
-                u32 len = 4;
-                while (len < (u32)LZ_MIN && p + len < main_end && ((mask >> len) & 0xFull) == 0xFull) len += 4;  // :148-150
-                if (len < (u32)LZ_MIN) {
-                    if (heur < p + len) heur = p + len;  // :152-155
-                    continue;
+        u32 total;
+        const u32 pre = block_excl_add<LZ_DRV>(cnt, red, total);
+        const bool included = pre + cnt <= (u32)LZ_EV_CAP;
+        // first word NOT covered this iteration, and the number of events that are covered
+        const u32 cut_word = block_min<LZ_DRV>(included ? 0xFFFFFFFFu : w0 + 4u * tid, red);
+        const u32 cut_events = block_min<LZ_DRV>(included ? 0xFFFFFFFFu : pre, red);
+        const u32 nev = cut_events == 0xFFFFFFFFu ? total : cut_events;
+        u32 window_end = cut_word == 0xFFFFFFFFu ? (w0 + (u32)LZ_WIN_WORDS) * 32u : cut_word * 32u;
+        if (window_end > main_end || window_end < cur) window_end = main_end;
+        if (included && cnt) {
+            u32 o = pre;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u32 b = word[k];
+                const u32 pos0 = (w0 + 4u * tid + (u32)k) * 32u;
+                while (b) {
+                    const int bit = __ffs((int)b) - 1;
+                    b &= b - 1;
+                    cq[o++] = pos0 + (u32)bit;
                 }
-                accept = e;
-                break;
             }
-            s_heur = heur;
-            s_accept = accept;
         }
         __syncthreads();
-        const u32 accept = s_accept;
-        if (accept == 0xFFFFFFFFu) {
-            if (tid == 0) s_cur = tile_end;
+        if (nev == 0) {
+            if (tid == 0) s_cur = window_end;
             __syncthreads();
             continue;
         }
-        // ---- a real match: measure it with the whole workgroup ----------------------------------
-        const u32 p = ev_pos[accept], v = ev_ref[accept];
+        // ---- resolve the flagged positions against the current skip state, a sub-batch at a time (the first
+        //      event of a repeated region is usually the one that gets accepted) and replay the heur chain ----
+        if (tid == 0) s_accept = 0xFFFFFFFFu;
+        for (u32 b0 = 0, sub = WAVE; b0 < nev; b0 += sub, sub = LZ_DRV) {
+            const u32 b1 = (nev - b0 < sub) ? nev : b0 + sub;
+            evaluated += b1 - b0;
+            {
+                const u32 e = b0 + tid;
+                if (e < b1) {
+                    const u32 q = cq[e];
+                    u32 v = 0;
+                    if (q < main_end) {
+                        v = lz_candidate(prev, skip, q);
+                        if (v > 0 && !lz_pretest(in, q, v)) v = 0;
+                    }
+                    ev_mask[e] = v > 0 ? lz_eqmask48(in, q, v) : 0ull;
+                    ev_ref[e] = v;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {  // one lane; masks only, no memory traffic
+                u32 heur = s_heur;
+                u32 accept = 0xFFFFFFFFu;
+                for (u32 e = b0; e < b1; e++) {
+                    if (ev_ref[e] == 0) continue;
+                    const u32 p = cq[e];
+                    const u64 mask = ev_mask[e];
+                    if (heur > p && ((mask >> (heur - p)) & 0xFull) != 0xFull) continue;  // :145
+                    u32 len = 4;
+                    while (len < (u32)LZ_MIN && p + len < main_end && ((mask >> len) & 0xFull) == 0xFull) len += 4;  // :148-150
+                    if (len < (u32)LZ_MIN) {
+                        if (heur < p + len) heur = p + len;  // :152-155
+                        continue;
+                    }
+                    accept = e;
+                    break;
+                }
+                s_heur = heur;
+                s_accept = accept;
+            }
+            __syncthreads();
+            if (s_accept != 0xFFFFFFFFu) break;
+        }
+        const u32 accept = s_accept;
+        if (accept == 0xFFFFFFFFu) {
+            if (tid == 0) s_cur = window_end;
+            __syncthreads();
+            continue;
+        }
+        // ---- a real match: measure it with the whole workgroup ----------------------------------------
+        const u32 p = cq[accept], v = ev_ref[accept];
         u32 len = LZ_MIN;
         for (;;) {
             const u32 off = len + 4u * tid;
@@ -143,56 +260,80 @@ __global__ void __launch_bounds__(LZ_DRV) k_lzp_driver(const u8 * __restrict__ i
             len += in[p + len] == in[v + len];  // :157-159
             len += in[p + len] == in[v + len];
             len += in[p + len] == in[v + len];
-            mlen[p] = len;
+            const u32 k = s_matches;
+            mpos[k] = p;
+            mlen[k] = len;
+            mstart[p >> 5] |= 1u << (p & 31u);
             s_len = len;
-            s_matches++;
+            s_matches = k + 1;
             s_cur = p + len;
         }
         __syncthreads();
         len = s_len;
-        // swallowed positions p+1 .. p+len-1
         {
-            const u32 a = p + 1, b = p + len;  // [a, b)
-            for (u32 w = (a >> 5) + tid; w <= ((b - 1) >> 5) && a < b; w += LZ_DRV) {
+            const u32 a = p + 1, b = p + len;  // swallowed positions [a, b)
+            for (u32 w = (a >> 5) + tid; w <= ((b - 1) >> 5); w += LZ_DRV) {
                 const u32 lo = w << 5;
                 u32 m = 0xFFFFFFFFu;
                 if (lo < a) m &= 0xFFFFFFFFu << (a - lo);
                 if (lo + 32 > b) m &= 0xFFFFFFFFu >> (lo + 32 - b);
                 skip[w] |= m;  // only this workgroup writes the bitmap; distinct lanes own distinct words
             }
+            // the candidate of next[s] just changed for every swallowed s: flag it for re-evaluation
+            for (u32 sidx = a + tid; sidx < b; sidx += LZ_DRV) {
+                const u32 nq = next[sidx];
+                if (nq >= b && nq < main_end) atomicOr(&cand_bits[nq >> 5], 1u << (nq & 31u));
+            }
         }
         __threadfence_block();
         __syncthreads();
+        l1_invalidate();  // the flags above were set by atomics at L2; make the next window's plain loads see them
     }
     if (tid == 0) {
         result->end_pos = s_cur;
         result->n_matches = s_matches;
+        result->iterations = iterations;
+        result->evaluated = evaluated;
     }
 }
 
-// ---- 3. emission -------------------------------------------------------------------------------
-__device__ __forceinline__ u32 lz_emit_count(const u8 * __restrict__ in, const u32 * __restrict__ prev, const u32 * __restrict__ skip,
-                                             const u32 * __restrict__ mlen, u32 p, u32 & ml) {
+// ---- 4. emission -------------------------------------------------------------------------------
+__device__ __forceinline__ u32 lz_match_len(const u32 * __restrict__ mpos, const u32 * __restrict__ mlen, u32 nm, u32 p) {
+    u32 lo = 0, hi = nm;  // mpos is ascending; p is known to be a match start
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (mpos[mid] <= p) lo = mid; else hi = mid;
+    }
+    return mlen[lo];
+}
+
+__device__ __forceinline__ u32 lz_emit_count(const u8 * __restrict__ in, u32 * __restrict__ prev, const u32 * __restrict__ skip,
+                                             const u32 * __restrict__ mstart, const u32 * __restrict__ mpos, const u32 * __restrict__ mlen, u32 nm, u32 p,
+                                             u32 & ml) {
     ml = 0;
     if (p < 4) return 1u;
     if (lz_skipped(skip, p)) return 0u;
-    ml = mlen[p];
-    if (ml) return 2u + (ml - LZ_MIN) / 254u;  // MATCH, 254 x q, remainder (:164-173)
+    if (lz_skipped(mstart, p)) {
+        ml = lz_match_len(mpos, mlen, nm, p);
+        return 2u + (ml - LZ_MIN) / 254u;  // MATCH, 254 x q, remainder (:164-173)
+    }
     if (in[p] != LZ_ESC) return 1u;
     return lz_candidate(prev, skip, p) > 0 ? 2u : 1u;  // escape only when the slot was live (:176-181, :194)
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(LZ_BLOCK) k_lzp_emit(const u8 * __restrict__ in, u32 n, const u32 * __restrict__ prev, const u32 * __restrict__ skip,
-                                                      const u32 * __restrict__ mlen, u32 * __restrict__ tile_sum, u8 * __restrict__ out) {
+__global__ void __launch_bounds__(LZ_BLOCK) k_lzp_emit(const u8 * __restrict__ in, u32 n, u32 * __restrict__ prev, const u32 * __restrict__ skip,
+                                                      const u32 * __restrict__ mstart, const u32 * __restrict__ mpos, const u32 * __restrict__ mlen,
+                                                      const LzDriverOut * __restrict__ drv, u32 * __restrict__ tile_sum, u8 * __restrict__ out) {
     __shared__ u32 lds[LZ_BLOCK / WAVE + 1];
+    const u32 nm = drv->n_matches;
     const u64 base = (u64)blockIdx.x * LZ_ETILE + (u64)threadIdx.x * LZ_ITEMS;
     u32 cnt[LZ_ITEMS], ml[LZ_ITEMS];
     u32 sum = 0;
 #pragma unroll 4
     for (int k = 0; k < LZ_ITEMS; k++) {
-        cnt[k] = (base + k < n) ? lz_emit_count(in, prev, skip, mlen, (u32)(base + k), ml[k]) : 0u;
-        if (base + k >= n) ml[k] = 0;
+        ml[k] = 0;
+        cnt[k] = (base + k < n) ? lz_emit_count(in, prev, skip, mstart, mpos, mlen, nm, (u32)(base + k), ml[k]) : 0u;
         sum += cnt[k];
     }
     u32 tot;
@@ -222,10 +363,15 @@ s32 lzp_encode(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s) {
     if (n < LZ_MIN + 32) return -1;  // :244
     const size_t mk = tmp.mark();
     const u32 m = n - 4;
+    const u32 nwords = (n + 31) / 32 + 2;
     u32 * prev = tmp.take<u32>(n);
-    u32 * mlen = tmp.take<u32>(n);
-    u32 * skip = tmp.take<u32>((n >> 5) + 2);
-    LzDriverOut * d_res = reinterpret_cast<LzDriverOut *>(tmp.take<u32>(4));
+    u32 * next = tmp.take<u32>(n);
+    u32 * skip = tmp.take<u32>(nwords);
+    u32 * mstart = tmp.take<u32>(nwords);
+    u32 * cand_bits = tmp.take<u32>(nwords);
+    u32 * mpos = tmp.take<u32>(n / LZ_MIN + 2);
+    u32 * mlen = tmp.take<u32>(n / LZ_MIN + 2);
+    LzDriverOut * d_res = reinterpret_cast<LzDriverOut *>(tmp.take<u32>(8));
     u32 * d_total = tmp.take<u32>(1);
     {
         const size_t mk2 = tmp.mark();
@@ -238,22 +384,35 @@ s32 lzp_encode(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s) {
         radix_pass<u32>(k1, k0, (const u32 *)v1, v0, m, 8, 0xFFFFFFFFu, 0u, tmp, s);
         radix_pass<u32>(k0, k1, (const u32 *)v0, v1, m, 16, 0xFFFFFFFFu, 0u, tmp, s);
         HIP_CHECK(hipMemsetAsync(prev, 0, 16, s));
-        launch(k_lzp_prev, dim3((m + LZ_BLOCK - 1) / LZ_BLOCK), dim3(LZ_BLOCK), 0, s, (const u32 *)k1, (const u32 *)v1, m, prev);
+        HIP_CHECK(hipMemsetAsync(next, 0, 16, s));
+        launch(k_lzp_links, dim3((m + LZ_BLOCK - 1) / LZ_BLOCK), dim3(LZ_BLOCK), 0, s, (const u32 *)k1, (const u32 *)v1, m, prev, next);
         tmp.release(mk2);
     }
-    HIP_CHECK(hipMemsetAsync(mlen, 0, (size_t)n * 4, s));
-    HIP_CHECK(hipMemsetAsync(skip, 0, ((size_t)(n >> 5) + 2) * 4, s));
-    launch(k_lzp_driver, dim3(1), dim3(LZ_DRV), 0, s, d_in, n, (const u32 *)prev, skip, mlen, d_res);
+    HIP_CHECK(hipMemsetAsync(skip, 0, (size_t)nwords * 4, s));
+    HIP_CHECK(hipMemsetAsync(mstart, 0, (size_t)nwords * 4, s));
+    {
+        u32 grid = (nwords * 32u / WAVE + (LZ_BLOCK / WAVE) - 1) / (LZ_BLOCK / WAVE);
+        if (grid > 8192) grid = 8192;
+        launch(k_lzp_static, dim3(grid), dim3(LZ_BLOCK), 0, s, d_in, n, (const u32 *)prev, cand_bits, nwords);
+    }
+    launch(k_lzp_driver, dim3(1), dim3(LZ_DRV), 0, s, d_in, n, prev, (const u32 *)next, cand_bits, nwords, skip, mstart, mpos, mlen, d_res);
     const u32 tiles = (n + LZ_ETILE - 1) / LZ_ETILE;
     u32 * tile_sum = tmp.take<u32>(tiles + 1);
-    launch(k_lzp_emit<0>, dim3(tiles), dim3(LZ_BLOCK), 0, s, d_in, n, (const u32 *)prev, (const u32 *)skip, (const u32 *)mlen, tile_sum, (u8 *)nullptr);
+    launch(k_lzp_emit<0>, dim3(tiles), dim3(LZ_BLOCK), 0, s, d_in, n, prev, (const u32 *)skip, (const u32 *)mstart, (const u32 *)mpos, (const u32 *)mlen,
+           (const LzDriverOut *)d_res, tile_sum, (u8 *)nullptr);
     exclusive_scan_u32(tile_sum, tiles, d_total, tmp, s);
     u32 total = 0;
     HIP_CHECK(hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
+    if (getenv("BZ3_HIP_TRACE")) {
+        LzDriverOut h;
+        HIP_CHECK(hipMemcpy(&h, d_res, sizeof h, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[bz3 lzp] n=%u matches=%u driver_iterations=%u evaluated=%u out=%u\n", n, h.n_matches, h.iterations, h.evaluated, total);
+    }
     s32 result = -1;
     if (total < n - 8) {  // the reference gives up once the output reaches n - 8 bytes (:128, :197)
-        launch(k_lzp_emit<1>, dim3(tiles), dim3(LZ_BLOCK), 0, s, d_in, n, (const u32 *)prev, (const u32 *)skip, (const u32 *)mlen, tile_sum, d_out);
+        launch(k_lzp_emit<1>, dim3(tiles), dim3(LZ_BLOCK), 0, s, d_in, n, prev, (const u32 *)skip, (const u32 *)mstart, (const u32 *)mpos,
+               (const u32 *)mlen, (const LzDriverOut *)d_res, tile_sum, d_out);
         result = (s32)total;
     }
     tmp.release(mk);
@@ -261,14 +420,16 @@ s32 lzp_encode(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s) {
 }
 
 // ---- decode -------------------------------------------------------------------------------------
-constexpr int LZD_CHUNK = 16384;
+constexpr int LZD_CHUNK = 16384;  // input bytes staged in LDS per iteration (16 per lane)
 
-struct LzDecodeOut {
-    s32 size;  // decoded size or -1
-};
-
-__global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const u8 * __restrict__ in, u32 n, u8 * __restrict__ out, u32 max_out, u32 * __restrict__ lut,
-                                                      LzDecodeOut * __restrict__ result) {
+__global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const LzpDecodeJob * __restrict__ jobs) {
+    const u8 * __restrict__ in = jobs[blockIdx.x].in;
+    const u32 n = jobs[blockIdx.x].n;
+    u8 * __restrict__ out = jobs[blockIdx.x].out;
+    const u32 max_out = jobs[blockIdx.x].max_out;
+    u32 * __restrict__ lut = jobs[blockIdx.x].lut;
+    s32 * __restrict__ result = jobs[blockIdx.x].result;
+    __shared__ u8 stage[LZD_CHUNK + 16];  // [0..3] = the 4 output bytes before the chunk, [4..] = input bytes
     __shared__ u32 red[LZ_DRV / WAVE + 1];
     __shared__ u32 s_ip, s_op, s_copy_src, s_copy_cnt, s_fail;
     const u32 tid = threadIdx.x;
@@ -279,30 +440,43 @@ __global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const u8 * __restrict__ i
     for (;;) {
         const u32 ip = s_ip, op = s_op;
         if (s_fail || ip >= n || op >= max_out) break;
-        // first 0xF2 in the next chunk of input
+        const u32 chunk = (n - ip > (u32)LZD_CHUNK) ? (u32)LZD_CHUNK : n - ip;
+        // stage the chunk (16 consecutive bytes per lane) and the 4 bytes of output context
+        u8 mine[16];
+        const u32 j0 = tid * 16u;
+#pragma unroll
+        for (int k = 0; k < 16; k++) mine[k] = (j0 + k < chunk) ? in[ip + j0 + k] : (u8)0;
+        if (tid < 4) stage[tid] = out[op - 4 + tid];
+#pragma unroll
+        for (int k = 0; k < 16; k++) stage[4 + j0 + k] = mine[k];
         u32 first = 0xFFFFFFFFu;
-        const u32 chunk_end = (n - ip > (u32)LZD_CHUNK) ? ip + LZD_CHUNK : n;
-        for (u32 i = ip + tid; i < chunk_end; i += LZ_DRV)
-            if (in[i] == LZ_ESC) { first = i; break; }
-        first = block_min<LZ_DRV>(first, red);
+#pragma unroll
+        for (int k = 15; k >= 0; k--)
+            if (j0 + k < chunk && mine[k] == LZ_ESC) first = j0 + (u32)k;
+        first = block_min<LZ_DRV>(first, red);  // (also orders the LDS staging)
         const bool hit = first != 0xFFFFFFFFu;
-        u32 lit = (hit ? first : chunk_end) - ip;
+        u32 lit = hit ? first : chunk;
         bool room = true;
         if (lit > max_out - op) { lit = max_out - op; room = false; }
-        // bulk literals: copy, then insert every (visited) output position into the table
-        for (u32 j = tid; j < lit; j += LZ_DRV) out[op + j] = in[ip + j];
-        __threadfence_block();
-        __syncthreads();
-        for (u32 j = tid; j < lit; j += LZ_DRV) atomicMax(&lut[lz_hash(load_be32(out + op + j - 4))], op + j);
+        // bulk literals: copy out and insert every (visited) output position into the table
+#pragma unroll 4
+        for (int k = 0; k < 16; k++) {
+            const u32 j = j0 + (u32)k;
+            if (j < lit) {
+                out[op + j] = mine[k];
+                const u32 ctx = ((u32)stage[j] << 24) | ((u32)stage[j + 1] << 16) | ((u32)stage[j + 2] << 8) | (u32)stage[j + 3];
+                atomicMax(&lut[lz_hash(ctx)], op + j);
+            }
+        }
         __threadfence_block();
         __syncthreads();
         if (tid == 0) {
             u32 i2 = ip + lit, o2 = op + lit;
             s_copy_cnt = 0;
             if (hit && room && o2 < max_out) {
-                const u32 h = lz_hash(load_be32(out + o2 - 4));
-                const u32 cand = lut[h];
-                lut[h] = o2;
+                // hash context of o2: the 4 bytes before it are stage[lit .. lit+3]
+                const u32 ctx = ((u32)stage[lit] << 24) | ((u32)stage[lit + 1] << 16) | ((u32)stage[lit + 2] << 8) | (u32)stage[lit + 3];
+                const u32 cand = atomicExch(&lut[lz_hash(ctx)], o2);  // read the slot (at L2, where the atomics landed) and visit o2
                 if (cand > 0) {
                     i2++;
                     if (i2 == n) s_fail = 1;  // :215
@@ -344,21 +518,14 @@ __global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const u8 * __restrict__ i
             __syncthreads();
         }
     }
-    if (tid == 0) result->size = s_fail ? -1 : (s32)s_op;
+    if (tid == 0) *result = s_fail ? -1 : (s32)s_op;
 }
 
-s32 lzp_decode(const u8 * d_in, u32 n, u8 * d_out, u32 max_out, Arena & tmp, hipStream_t s) {
-    if (n < 4) return -1;  // :252
-    const size_t mk = tmp.mark();
-    u32 * lut = tmp.take<u32>((size_t)1 << LZ_HASH_BITS);
-    LzDecodeOut * d_res = reinterpret_cast<LzDecodeOut *>(tmp.take<u32>(2));
-    HIP_CHECK(hipMemsetAsync(lut, 0, sizeof(u32) << LZ_HASH_BITS, s));
-    launch(k_lzp_decode, dim3(1), dim3(LZ_DRV), 0, s, d_in, n, d_out, max_out, lut, d_res);
-    LzDecodeOut h;
-    HIP_CHECK(hipMemcpyAsync(&h, d_res, sizeof h, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
-    tmp.release(mk);
-    return h.size;
+void lzp_decode_batch(const LzpDecodeJob * h_jobs, LzpDecodeJob * d_jobs, u32 njobs, hipStream_t s) {
+    if (!njobs) return;
+    for (u32 i = 0; i < njobs; i++) HIP_CHECK(hipMemsetAsync(h_jobs[i].lut, 0, LZP_LUT_WORDS * sizeof(u32), s));
+    HIP_CHECK(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LzpDecodeJob) * njobs, hipMemcpyHostToDevice, s));
+    launch(k_lzp_decode, dim3(njobs), dim3(LZ_DRV), 0, s, (const LzpDecodeJob *)d_jobs);
 }
 
 }  // namespace bz3

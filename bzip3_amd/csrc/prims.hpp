@@ -36,6 +36,23 @@ __device__ __forceinline__ void lds_acquire() {
 #endif
 }
 
+// Drop this CU's vector-L1 lines so that later plain loads see what global atomics (executed at L2) wrote.
+__device__ __forceinline__ void l1_invalidate() {
+#ifndef BZ3_EMU
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
+
+// Load that bypasses the CU's vector L1 (served by L2): for words that other lanes update with global
+// atomics (which execute at L2) inside the same kernel.
+__device__ __forceinline__ u32 ld_l2(const u32 * p) {
+#ifdef BZ3_EMU
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_incl_add(T v) {
     const int l = lane_id();
@@ -160,6 +177,10 @@ __device__ __forceinline__ T block_max(T v, T * lds) {
     __syncthreads();
     return r;
 }
+
+// One 32-bit load at any byte address (gfx950 global/LDS accesses need no natural alignment).
+struct __attribute__((packed)) PackedU32 { u32 v; };
+__device__ __forceinline__ u32 load_u32_any(const u8 * p) { return reinterpret_cast<const PackedU32 *>(p)->v; }
 
 __device__ __forceinline__ u32 load_le32(const u8 * p) {
     return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24);

@@ -37,8 +37,17 @@ void mrle_decode(const u8 * d_enc, u32 m, u8 * d_out, u32 outlen, u32 * d_total,
 // ---- LZP (lzp.hip) -- replaces lzp_compress / lzp_decompress, src/libbz3.c:124-257 -----------
 // Synchronous (host reads match statistics between phases).  Returns the encoded size or -1.
 s32 lzp_encode(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s);
-// Returns the decoded size or -1.  d_out must hold `max_out` bytes.
-s32 lzp_decode(const u8 * d_in, u32 n, u8 * d_out, u32 max_out, Arena & tmp, hipStream_t s);
+// Decode: one workgroup per block, so a batch of blocks decodes concurrently (one launch, grid = jobs).
+struct LzpDecodeJob {
+    const u8 * in;
+    u32 n;
+    u8 * out;
+    u32 max_out;
+    u32 * lut;     // 2^18 words, zeroed by lzp_decode_batch
+    s32 * result;  // device word: decoded size or -1
+};
+constexpr size_t LZP_LUT_WORDS = (size_t)1 << 18;
+void lzp_decode_batch(const LzpDecodeJob * h_jobs, LzpDecodeJob * d_jobs, u32 njobs, hipStream_t s);  // asynchronous
 
 // ---- BWT (bwt.hip) -- replaces libsais_bwt, include/libsais.h:4095-4121 ----------------------
 // Synchronous.  Returns the primary index (>= 1).  Rounds/active statistics are reported for profiling.
@@ -56,10 +65,22 @@ void bwt_inverse(const u8 * d_in, u32 n, u32 idx, u8 * d_out, Arena & tmp, hipSt
 size_t unbwt_workspace_bytes(u64 n);
 
 // ---- CM coder (cm.hip) -- replaces begin/encode_bytes/decode_bytes, src/libbz3.c:333-494 -----
-// One workgroup per block, model resident in LDS.  Asynchronous.
-// encode: d_out receives the coded bytes, *d_out_size the byte count.
-void cm_encode(const u8 * d_in, u32 n, u8 * d_out, u32 * d_out_size, hipStream_t s);
-// decode: reads `in_size` coded bytes (reads past the end yield 0xFF.. like read_in, :345).
-void cm_decode(const u8 * d_in, u32 in_size, u8 * d_out, u32 n, hipStream_t s);
+// One workgroup (= one CU: the 145.5 KiB model fills its LDS) per block; a batch is ONE launch with
+// grid = number of blocks, so the blocks of bz3_encode_blocks / bz3_decode_blocks run side by side without
+// depending on how HIP maps streams to hardware queues.  Asynchronous.  Job arrays live in device memory.
+struct CmEncodeJob {
+    const u8 * in;
+    u32 n;
+    u8 * out;        // receives the coded bytes
+    u32 * out_size;  // receives the coded byte count
+};
+struct CmDecodeJob {
+    const u8 * in;   // coded bytes; reads past in_size yield 0xFF.. like read_in (:345)
+    u32 in_size;
+    u8 * out;
+    u32 n;
+};
+void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s);
+void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s);
 
 }  // namespace bz3

@@ -90,8 +90,8 @@ def text(n, seed=1, chains=2048):
     """n bytes of Markov text.  `chains` independent chains are generated in lockstep and concatenated."""
     t = bigram_tables()
     rng = np.random.Generator(np.random.PCG64(seed))
-    avg = float(t["lens"].mean())
-    steps = int(n / (avg * chains) * 1.25) + 8
+    avg = float(t["lens"][t["succ"]].mean())  # frequency-weighted word length (+1 space)
+    steps = int(n / (avg * chains) * 1.15) + 16
     state = rng.integers(0, t["nvocab"], size=chains)
     toks = np.empty((steps, chains), dtype=np.int64)
     for s in range(steps):

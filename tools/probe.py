@@ -14,11 +14,13 @@ def main():
     kind = sys.argv[2] if len(sys.argv) > 2 else "text"
     n = int(mib * (1 << 20))
     d = {"text": lambda: datagen.text(n, seed=5, chains=8192), "random": lambda: datagen.random_bytes(n),
-         "lowent": lambda: datagen.low_entropy(n), "repeats": lambda: datagen.repeats(n)}[kind]()
+         "lowent": lambda: datagen.low_entropy(n), "repeats": lambda: datagen.repeats(n),
+         "bigtext": lambda: (datagen.text(32 << 20, seed=5, chains=65536) * (n // (32 << 20) + 1))[:n]}[kind]()
     lib = bzip3_amd.load()
     bs = max(n, 65 * 1024)
     with bzip3_amd.State(bs, lib) as st:
-        for rep in range(2):
+        reps = 1 if '--once' in sys.argv else 2
+        for rep in range(reps):
             t0 = time.time()
             m, err, blk = st.encode_block(d)
             t1 = time.time()
