@@ -113,9 +113,12 @@ def load(path=None):
 
 
 def _cbuf(data, cap):
-    buf = (C.c_uint8 * max(1, cap))()
+    cap = max(1, cap)
+    if len(data) == cap:
+        return (C.c_uint8 * cap).from_buffer_copy(data)
+    buf = (C.c_uint8 * cap)()
     if len(data):
-        C.memmove(buf, bytes(data), len(data))
+        C.memmove(buf, data if isinstance(data, bytes) else bytes(data), len(data))
     return buf
 
 
@@ -131,43 +134,43 @@ class StageApi:
     def mrle_encode(self, data):
         out = (C.c_uint8 * (len(data) + 64))()
         n = self.lib.bz3_hip_stage_mrle_encode(_cbuf(data, len(data)), len(data), out)
-        return bytes(out[:n])
+        return C.string_at(out, n)
 
     def mrle_decode(self, data, outlen, maxin=None):
         maxin = len(data) if maxin is None else maxin
         out = (C.c_uint8 * max(1, outlen))()
         rc = self.lib.bz3_hip_stage_mrle_decode(_cbuf(data, len(data)), out, outlen, maxin)
-        return rc, bytes(out[:outlen])
+        return rc, C.string_at(out, outlen)
 
     def lzp_encode(self, data):
         out = (C.c_uint8 * (len(data) + 64))()
         n = self.lib.bz3_hip_stage_lzp_encode(_cbuf(data, len(data)), len(data), out)
-        return n, (bytes(out[:n]) if n > 0 else b"")
+        return n, (C.string_at(out, n) if n > 0 else b"")
 
     def lzp_decode(self, data, maxout):
         out = (C.c_uint8 * max(8, maxout))()
         n = self.lib.bz3_hip_stage_lzp_decode(_cbuf(data, len(data)), len(data), out, maxout)
-        return n, (bytes(out[:n]) if n > 0 else b"")
+        return n, (C.string_at(out, n) if n > 0 else b"")
 
     def bwt(self, data):
         out = (C.c_uint8 * max(1, len(data)))()
         idx = self.lib.bz3_hip_stage_bwt(_cbuf(data, len(data)), out, len(data))
-        return idx, bytes(out[: len(data)])
+        return idx, C.string_at(out, len(data))
 
     def unbwt(self, data, idx):
         out = (C.c_uint8 * max(1, len(data)))()
         rc = self.lib.bz3_hip_stage_unbwt(_cbuf(data, len(data)), out, len(data), idx)
-        return rc, bytes(out[: len(data)])
+        return rc, C.string_at(out, len(data))
 
     def cm_encode(self, data):
         out = (C.c_uint8 * (len(data) + len(data) // 50 + 64))()
         n = self.lib.bz3_hip_stage_cm_encode(_cbuf(data, len(data)), len(data), out)
-        return bytes(out[:n])
+        return C.string_at(out, n)
 
     def cm_decode(self, data, n):
         out = (C.c_uint8 * max(1, n))()
         self.lib.bz3_hip_stage_cm_decode(_cbuf(data, len(data)), len(data), out, n)
-        return bytes(out[:n])
+        return C.string_at(out, n)
 
 
 class State:
@@ -219,7 +222,7 @@ class State:
         cap = self.lib.bz3_bound(max(len(data), self.block_size)) + 64
         buf = _cbuf(data, cap)
         n = self.lib.bz3_encode_block(self.ptr, buf, len(data))
-        return n, self.last_error, (bytes(buf[:n]) if n > 0 else b"")
+        return n, self.last_error, (C.string_at(buf, n) if n > 0 else b"")
 
     def decode_block(self, data, orig_size, buffer_size=None, comp_size=None):
         cap = self.lib.bz3_bound(self.block_size) + 64
@@ -227,7 +230,7 @@ class State:
         comp_size = len(data) if comp_size is None else comp_size
         buf = _cbuf(data, max(cap, buffer_size, len(data) + 1))
         n = self.lib.bz3_decode_block(self.ptr, buf, buffer_size, comp_size, orig_size)
-        return n, self.last_error, (bytes(buf[:n]) if n > 0 else b"")
+        return n, self.last_error, (C.string_at(buf, n) if n > 0 else b"")
 
 
 def encode_block(data, block_size, lib=None):

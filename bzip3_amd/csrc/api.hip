@@ -221,9 +221,11 @@ inline bool sizes_fit(size_t buffer_size, s32 lzp_size, s32 rle_size, s32 orig_s
 //   2. ONE launch of the CM kernel, one workgroup (= one CU) per block                      (cm_encode_batch)
 //   3. per block: header, copy back into the caller's buffer if the ping-pong ended there   (encode_finish)
 // ======================================================================================================
-void encode_front(bz3_state * st, u8 * buf, s32 data_size, Arena & arena) {
+// Phase 1a: CRC, mRLE, LZP preparation (hash links + static events).  c receives the LZP context.
+void encode_front_a(bz3_state * st, u8 * buf, s32 data_size, Arena & arena, LzpEncodeCtx & c) {
     st->pending = bz3_state::FAILED;
     st->result = -1;
+    c.active = false;
     if (data_size > st->block_size || data_size < 0) {  // :588-591 (a negative size would walk off the buffer)
         st->last_error = BZ3_ERR_DATA_TOO_BIG;
         return;
@@ -244,34 +246,49 @@ void encode_front(bz3_state * st, u8 * buf, s32 data_size, Arena & arena) {
 
     u32 n = (u32)data_size;
     u8 *b1 = buf, *b2 = st->d_swap;
-    s32 model = 0, lzp_size = 0, rle_size = 0;
-
+    st->model = 0;
+    st->rle_size = 0;
     t0 = now_ms();
     {  // :609-614
         MrleEncScratch sc;
         const size_t mk = arena.mark();
         mrle_encode_size(b1, n, sc, arena, s);
-        rle_size = (s32)(32u + read_word(s, sc.total));
-        if (rle_size < (s32)n) {
+        st->rle_size = (s32)(32u + read_word(s, sc.total));
+        if (st->rle_size < (s32)n) {
             mrle_encode_write(b1, n, sc, b2, s);
             HIP_CHECK(hipStreamSynchronize(s));
             u8 * tmp = b1; b1 = b2; b2 = tmp;
-            n = (u32)rle_size;
-            model |= 4;
+            n = (u32)st->rle_size;
+            st->model |= 4;
         }
         arena.release(mk);
     }
     st->t[BZ3_HIP_T_RLE] = (float)(now_ms() - t0);
-
+    st->b1 = b1;
+    st->b2 = b2;
+    st->n_cm = n;
     t0 = now_ms();
-    lzp_size = lzp_encode(b1, n, b2, arena, s);  // :616-621
+    lzp_encode_prepare(b1, n, c, arena, s);  // :616 (first third)
+    st->t[BZ3_HIP_T_LZP] = (float)(now_ms() - t0);
+    st->pending = bz3_state::ENC_CODED;
+}
+
+// Phase 1b (after the LZP drivers of the window have run): LZP emission, BWT, header.
+void encode_front_b(bz3_state * st, Arena & arena, const LzpEncodeCtx & c, float driver_ms) {
+    if (st->pending != bz3_state::ENC_CODED) return;
+    st->pending = bz3_state::FAILED;
+    hipStream_t s = st->stream;
+    u8 *b1 = st->b1, *b2 = st->b2;
+    u32 n = st->n_cm;
+    double t0 = now_ms();
+    const s32 lzp_size = lzp_encode_finish(c, b2, arena, s);  // :616-621
     if (lzp_size > 0 && lzp_size < (s32)n) {
-        HIP_CHECK(hipStreamSynchronize(s));
         u8 * tmp = b1; b1 = b2; b2 = tmp;
         n = (u32)lzp_size;
-        model |= 2;
+        st->model |= 2;
     }
-    st->t[BZ3_HIP_T_LZP] = (float)(now_ms() - t0);
+    st->lzp_size = lzp_size;
+    st->t[BZ3_HIP_T_LZP] += driver_ms + (float)(now_ms() - t0);
 
     t0 = now_ms();
     const s32 bwt_idx = bwt_forward(b1, n, b2, arena, s, &st->bwt);  // :623-627
@@ -281,9 +298,9 @@ void encode_front(bz3_state * st, u8 * buf, s32 data_size, Arena & arena) {
         return;
     }
     s32 overhead = 2;  // :630-632
-    if (model & 2) overhead++;
-    if (model & 4) overhead++;
-    launch(k_write_header, dim3(1), dim3(64), 0, s, b1, (const u32 *)(st->d_words + 1), (u32)bwt_idx, (u32)model, (u32)lzp_size, (u32)rle_size);  // :641-647
+    if (st->model & 2) overhead++;
+    if (st->model & 4) overhead++;
+    launch(k_write_header, dim3(1), dim3(64), 0, s, b1, (const u32 *)(st->d_words + 1), (u32)bwt_idx, (u32)st->model, (u32)lzp_size, (u32)st->rle_size);  // :641-647
     st->b1 = b1;
     st->b2 = b2;
     st->n_cm = n;
@@ -324,13 +341,44 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         const size_t w = workspace_bytes_for((u64)(sizes[i] > 0 ? sizes[i] : 0) + 64);
         if (w > need) need = w;
     }
-    Arena arena = lead->ctx->arena_for(need + (size_t)n * sizeof(CmEncodeJob) + 4096);
+    // LZP drivers are serial single-workgroup kernels: blocks are prepared in windows and each window's
+    // drivers run as one launch (one workgroup per block).  The window contexts stay on the arena meanwhile.
+    u64 n_max = 64;
+    for (s32 i = 0; i < n; i++)
+        if (sizes[i] > 0 && (u64)sizes[i] > n_max) n_max = (u64)sizes[i];
+    const size_t ctx_bytes = lzp_encode_ctx_bytes(n_max + 64);
+    s32 window = (s32)(((size_t)40 << 30) / ctx_bytes);
+    if (window < 1) window = 1;
+    if (window > 32) window = 32;
+    if (window > n) window = n;
+    Arena arena = lead->ctx->arena_for(need + (size_t)window * (ctx_bytes + 65536) + (size_t)n * sizeof(CmEncodeJob) + 65536);
     CmEncodeJob * d_jobs = arena.take<CmEncodeJob>((size_t)n);
     std::vector<CmEncodeJob> jobs;
-    for (s32 i = 0; i < n; i++) {
-        encode_front(sts[i], bufs[i], sizes[i], arena);
-        if (sts[i]->pending == bz3_state::ENC_CODED)
-            jobs.push_back(CmEncodeJob{sts[i]->b2, sts[i]->n_cm, sts[i]->b1 + sts[i]->overhead * 4 + 1, sts[i]->d_words + 2});  // :634-638
+    for (s32 w0 = 0; w0 < n; w0 += window) {
+        const s32 w1 = (w0 + window < n) ? w0 + window : n;
+        const size_t mk = arena.mark();
+        std::vector<LzpEncodeCtx> ctxs((size_t)(w1 - w0));
+        std::vector<LzpDriverJob> lz;
+        for (s32 i = w0; i < w1; i++) {
+            encode_front_a(sts[i], bufs[i], sizes[i], arena, ctxs[(size_t)(i - w0)]);
+            if (sts[i]->pending == bz3_state::ENC_CODED && ctxs[(size_t)(i - w0)].active) lz.push_back(lzp_driver_job(ctxs[(size_t)(i - w0)]));
+        }
+        float driver_ms = 0.f;
+        if (!lz.empty()) {
+            // every prepare above ran on its own state's stream and those streams are idle again only after a sync
+            for (s32 i = w0; i < w1; i++) HIP_CHECK(hipStreamSynchronize(sts[i]->stream));
+            const double t0 = now_ms();
+            LzpDriverJob * d_lz = arena.take<LzpDriverJob>(lz.size());
+            lzp_driver_batch(lz.data(), d_lz, (u32)lz.size(), lead->stream);
+            HIP_CHECK(hipStreamSynchronize(lead->stream));
+            driver_ms = (float)(now_ms() - t0);
+        }
+        for (s32 i = w0; i < w1; i++) {
+            encode_front_b(sts[i], arena, ctxs[(size_t)(i - w0)], driver_ms);
+            if (sts[i]->pending == bz3_state::ENC_CODED)
+                jobs.push_back(CmEncodeJob{sts[i]->b2, sts[i]->n_cm, sts[i]->b1 + sts[i]->overhead * 4 + 1, sts[i]->d_words + 2});  // :634-638
+        }
+        arena.release(mk);
     }
     float cm_ms = 0.f;
     if (!jobs.empty()) {

@@ -123,16 +123,21 @@ __global__ void __launch_bounds__(LZ_BLOCK) k_lzp_static(const u8 * __restrict__
 constexpr int LZ_EV_CAP = 2048;              // events resolved per driver iteration
 constexpr int LZ_WIN_WORDS = 4 * LZ_DRV;     // bitmap words scanned per iteration (131072 positions)
 
-struct LzDriverOut {
-    u32 end_pos;    // first position handled by the tail loop (>= n - 72)
-    u32 n_matches;
-    u32 iterations; // driver loop iterations            } profiling counters
-    u32 evaluated;  // flagged positions it resolved     }
-};
 
-__global__ void __launch_bounds__(LZ_DRV) k_lzp_driver(const u8 * __restrict__ in, u32 n, u32 * __restrict__ prev, const u32 * __restrict__ next,
-                                                      u32 * __restrict__ cand_bits, u32 nwords, u32 * __restrict__ skip, u32 * __restrict__ mstart,
-                                                      u32 * __restrict__ mpos, u32 * __restrict__ mlen, LzDriverOut * __restrict__ result) {
+
+__global__ void __launch_bounds__(LZ_DRV) k_lzp_driver(const LzpDriverJob * __restrict__ jobs) {
+    // one workgroup per block: a batch of blocks runs its (serial) drivers side by side
+    const u8 * __restrict__ in = jobs[blockIdx.x].in;
+    const u32 n = jobs[blockIdx.x].n;
+    u32 * __restrict__ prev = jobs[blockIdx.x].prev;
+    const u32 * __restrict__ next = jobs[blockIdx.x].next;
+    u32 * __restrict__ cand_bits = jobs[blockIdx.x].cand_bits;
+    const u32 nwords = jobs[blockIdx.x].nwords;
+    u32 * __restrict__ skip = jobs[blockIdx.x].skip;
+    u32 * __restrict__ mstart = jobs[blockIdx.x].mstart;
+    u32 * __restrict__ mpos = jobs[blockIdx.x].mpos;
+    u32 * __restrict__ mlen = jobs[blockIdx.x].mlen;
+    LzDriverOut * __restrict__ result = jobs[blockIdx.x].result;
     __shared__ u32 cq[LZ_EV_CAP];
     __shared__ u32 ev_ref[LZ_EV_CAP];
     __shared__ u64 ev_mask[LZ_EV_CAP];
@@ -359,20 +364,26 @@ __global__ void __launch_bounds__(LZ_BLOCK) k_lzp_emit(const u8 * __restrict__ i
     }
 }
 
-s32 lzp_encode(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s) {
-    if (n < LZ_MIN + 32) return -1;  // :244
-    const size_t mk = tmp.mark();
+size_t lzp_encode_ctx_bytes(u64 n) { return n * 8 + (n / 32 + 8) * 12 + (n / LZ_MIN + 8) * 8 + 4096; }
+
+// Phase A (asynchronous): hash links + static event bitmap.  Allocations stay on the arena until the caller
+// releases its mark, so several blocks can be prepared before their drivers run as one batch.
+void lzp_encode_prepare(const u8 * d_in, u32 n, LzpEncodeCtx & c, Arena & tmp, hipStream_t s) {
+    c.active = false;
+    c.in = d_in;
+    c.n = n;
+    if (n < LZ_MIN + 32) return;  // :244
+    c.active = true;
     const u32 m = n - 4;
-    const u32 nwords = (n + 31) / 32 + 2;
-    u32 * prev = tmp.take<u32>(n);
-    u32 * next = tmp.take<u32>(n);
-    u32 * skip = tmp.take<u32>(nwords);
-    u32 * mstart = tmp.take<u32>(nwords);
-    u32 * cand_bits = tmp.take<u32>(nwords);
-    u32 * mpos = tmp.take<u32>(n / LZ_MIN + 2);
-    u32 * mlen = tmp.take<u32>(n / LZ_MIN + 2);
-    LzDriverOut * d_res = reinterpret_cast<LzDriverOut *>(tmp.take<u32>(8));
-    u32 * d_total = tmp.take<u32>(1);
+    c.nwords = (n + 31) / 32 + 2;
+    c.prev = tmp.take<u32>(n);
+    c.next = tmp.take<u32>(n);
+    c.skip = tmp.take<u32>(c.nwords);
+    c.mstart = tmp.take<u32>(c.nwords);
+    c.cand_bits = tmp.take<u32>(c.nwords);
+    c.mpos = tmp.take<u32>(n / LZ_MIN + 2);
+    c.mlen = tmp.take<u32>(n / LZ_MIN + 2);
+    c.d_res = reinterpret_cast<LzDriverOut *>(tmp.take<u32>(8));
     {
         const size_t mk2 = tmp.mark();
         u32 * k0 = tmp.take<u32>(m);
@@ -383,40 +394,73 @@ s32 lzp_encode(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s) {
         radix_pass<u32>(k0, k1, (const u32 *)nullptr, v1, m, 0, 0xFFFFFFFFu, 0u, tmp, s);
         radix_pass<u32>(k1, k0, (const u32 *)v1, v0, m, 8, 0xFFFFFFFFu, 0u, tmp, s);
         radix_pass<u32>(k0, k1, (const u32 *)v0, v1, m, 16, 0xFFFFFFFFu, 0u, tmp, s);
-        HIP_CHECK(hipMemsetAsync(prev, 0, 16, s));
-        HIP_CHECK(hipMemsetAsync(next, 0, 16, s));
-        launch(k_lzp_links, dim3((m + LZ_BLOCK - 1) / LZ_BLOCK), dim3(LZ_BLOCK), 0, s, (const u32 *)k1, (const u32 *)v1, m, prev, next);
-        tmp.release(mk2);
+        HIP_CHECK(hipMemsetAsync(c.prev, 0, 16, s));
+        HIP_CHECK(hipMemsetAsync(c.next, 0, 16, s));
+        launch(k_lzp_links, dim3((m + LZ_BLOCK - 1) / LZ_BLOCK), dim3(LZ_BLOCK), 0, s, (const u32 *)k1, (const u32 *)v1, m, c.prev, c.next);
+        tmp.release(mk2);  // the sort buffers are dead once k_lzp_links has run (stream order protects them)
     }
-    HIP_CHECK(hipMemsetAsync(skip, 0, (size_t)nwords * 4, s));
-    HIP_CHECK(hipMemsetAsync(mstart, 0, (size_t)nwords * 4, s));
-    {
-        u32 grid = (nwords * 32u / WAVE + (LZ_BLOCK / WAVE) - 1) / (LZ_BLOCK / WAVE);
-        if (grid > 8192) grid = 8192;
-        launch(k_lzp_static, dim3(grid), dim3(LZ_BLOCK), 0, s, d_in, n, (const u32 *)prev, cand_bits, nwords);
-    }
-    launch(k_lzp_driver, dim3(1), dim3(LZ_DRV), 0, s, d_in, n, prev, (const u32 *)next, cand_bits, nwords, skip, mstart, mpos, mlen, d_res);
+    HIP_CHECK(hipMemsetAsync(c.skip, 0, (size_t)c.nwords * 4, s));
+    HIP_CHECK(hipMemsetAsync(c.mstart, 0, (size_t)c.nwords * 4, s));
+    u32 grid = (c.nwords * 32u / WAVE + (LZ_BLOCK / WAVE) - 1) / (LZ_BLOCK / WAVE);
+    if (grid > 8192) grid = 8192;
+    launch(k_lzp_static, dim3(grid), dim3(LZ_BLOCK), 0, s, d_in, n, (const u32 *)c.prev, c.cand_bits, c.nwords);
+}
+
+LzpDriverJob lzp_driver_job(const LzpEncodeCtx & c) {
+    return LzpDriverJob{c.in, c.n, c.prev, c.next, c.cand_bits, c.nwords, c.skip, c.mstart, c.mpos, c.mlen, c.d_res};
+}
+
+// Phase B (asynchronous): the serial drivers of a batch of blocks, one workgroup each.
+void lzp_driver_batch(const LzpDriverJob * h_jobs, LzpDriverJob * d_jobs, u32 njobs, hipStream_t s) {
+    if (!njobs) return;
+    HIP_CHECK(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LzpDriverJob) * njobs, hipMemcpyHostToDevice, s));
+    launch(k_lzp_driver, dim3(njobs), dim3(LZ_DRV), 0, s, (const LzpDriverJob *)d_jobs);
+}
+
+// Phase C (synchronous): sizes the output, gives up like the reference when it would not shrink, emits.
+s32 lzp_encode_finish(const LzpEncodeCtx & c, u8 * d_out, Arena & tmp, hipStream_t s) {
+    if (!c.active) return -1;
+    const size_t mk = tmp.mark();
+    const u32 n = c.n;
     const u32 tiles = (n + LZ_ETILE - 1) / LZ_ETILE;
     u32 * tile_sum = tmp.take<u32>(tiles + 1);
-    launch(k_lzp_emit<0>, dim3(tiles), dim3(LZ_BLOCK), 0, s, d_in, n, prev, (const u32 *)skip, (const u32 *)mstart, (const u32 *)mpos, (const u32 *)mlen,
-           (const LzDriverOut *)d_res, tile_sum, (u8 *)nullptr);
+    u32 * d_total = tmp.take<u32>(1);
+    launch(k_lzp_emit<0>, dim3(tiles), dim3(LZ_BLOCK), 0, s, c.in, n, c.prev, (const u32 *)c.skip, (const u32 *)c.mstart, (const u32 *)c.mpos, (const u32 *)c.mlen,
+           (const LzDriverOut *)c.d_res, tile_sum, (u8 *)nullptr);
     exclusive_scan_u32(tile_sum, tiles, d_total, tmp, s);
     u32 total = 0;
     HIP_CHECK(hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     if (getenv("BZ3_HIP_TRACE")) {
         LzDriverOut h;
-        HIP_CHECK(hipMemcpy(&h, d_res, sizeof h, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(&h, c.d_res, sizeof h, hipMemcpyDeviceToHost));
         fprintf(stderr, "[bz3 lzp] n=%u matches=%u driver_iterations=%u evaluated=%u out=%u\n", n, h.n_matches, h.iterations, h.evaluated, total);
     }
     s32 result = -1;
     if (total < n - 8) {  // the reference gives up once the output reaches n - 8 bytes (:128, :197)
-        launch(k_lzp_emit<1>, dim3(tiles), dim3(LZ_BLOCK), 0, s, d_in, n, prev, (const u32 *)skip, (const u32 *)mstart, (const u32 *)mpos,
-               (const u32 *)mlen, (const LzDriverOut *)d_res, tile_sum, d_out);
+        launch(k_lzp_emit<1>, dim3(tiles), dim3(LZ_BLOCK), 0, s, c.in, n, c.prev, (const u32 *)c.skip, (const u32 *)c.mstart, (const u32 *)c.mpos,
+               (const u32 *)c.mlen, (const LzDriverOut *)c.d_res, tile_sum, d_out);
+        HIP_CHECK(hipStreamSynchronize(s));
         result = (s32)total;
     }
     tmp.release(mk);
     return result;
+}
+
+// One block, start to finish (stage hook).
+s32 lzp_encode(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s) {
+    const size_t mk = tmp.mark();
+    LzpEncodeCtx c;
+    lzp_encode_prepare(d_in, n, c, tmp, s);
+    s32 r = -1;
+    if (c.active) {
+        LzpDriverJob job = lzp_driver_job(c);
+        LzpDriverJob * d_job = tmp.take<LzpDriverJob>(1);
+        lzp_driver_batch(&job, d_job, 1, s);
+        r = lzp_encode_finish(c, d_out, tmp, s);
+    }
+    tmp.release(mk);
+    return r;
 }
 
 // ---- decode -------------------------------------------------------------------------------------

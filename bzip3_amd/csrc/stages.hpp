@@ -35,8 +35,40 @@ void mrle_encode_write(const u8 * d_in, u32 n, const MrleEncScratch & sc, u8 * d
 void mrle_decode(const u8 * d_enc, u32 m, u8 * d_out, u32 outlen, u32 * d_total, Arena & tmp, hipStream_t s);
 
 // ---- LZP (lzp.hip) -- replaces lzp_compress / lzp_decompress, src/libbz3.c:124-257 -----------
-// Synchronous (host reads match statistics between phases).  Returns the encoded size or -1.
-s32 lzp_encode(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s);
+// Encode runs in three phases so that the serial "driver" kernels of many blocks can run side by side
+// (one workgroup per block): prepare (grid-wide, async) -> driver batch (async) -> finish (grid-wide, sync).
+struct LzDriverOut {
+    u32 end_pos;     // first position handled by the tail loop (>= n - 72)
+    u32 n_matches;
+    u32 iterations;  // driver loop iterations          } profiling counters
+    u32 evaluated;   // flagged positions it resolved   }
+};
+struct LzpEncodeCtx {
+    bool active = false;  // false: n < 72, LZP declines (:244)
+    const u8 * in = nullptr;
+    u32 n = 0, nwords = 0;
+    u32 *prev = nullptr, *next = nullptr, *skip = nullptr, *mstart = nullptr, *cand_bits = nullptr, *mpos = nullptr, *mlen = nullptr;
+    LzDriverOut * d_res = nullptr;
+};
+struct LzpDriverJob {
+    const u8 * in;
+    u32 n;
+    u32 * prev;
+    const u32 * next;
+    u32 * cand_bits;
+    u32 nwords;
+    u32 * skip;
+    u32 * mstart;
+    u32 * mpos;
+    u32 * mlen;
+    LzDriverOut * result;
+};
+size_t lzp_encode_ctx_bytes(u64 n);
+void lzp_encode_prepare(const u8 * d_in, u32 n, LzpEncodeCtx & c, Arena & tmp, hipStream_t s);
+LzpDriverJob lzp_driver_job(const LzpEncodeCtx & c);
+void lzp_driver_batch(const LzpDriverJob * h_jobs, LzpDriverJob * d_jobs, u32 njobs, hipStream_t s);
+s32 lzp_encode_finish(const LzpEncodeCtx & c, u8 * d_out, Arena & tmp, hipStream_t s);  // encoded size or -1
+s32 lzp_encode(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s);         // one block, all three phases
 // Decode: one workgroup per block, so a batch of blocks decodes concurrently (one launch, grid = jobs).
 struct LzpDecodeJob {
     const u8 * in;

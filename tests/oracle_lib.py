@@ -68,43 +68,43 @@ class Oracle:
     def mrle_encode(self, data):
         out = (C.c_uint8 * (len(data) + 64))()
         n = self.lib.orc_mrle_encode(_buf(data), len(data), out)
-        return bytes(out[:n])
+        return C.string_at(out, n)
 
     def mrle_decode(self, data, outlen, maxin=None):
         maxin = len(data) if maxin is None else maxin
         out = (C.c_uint8 * max(1, outlen))()
         rc = self.lib.orc_mrle_decode(_buf(data), out, outlen, maxin)
-        return rc, bytes(out[:outlen])
+        return rc, C.string_at(out, outlen)
 
     def lzp_encode(self, data):
         out = (C.c_uint8 * (len(data) + 64))()
         n = self.lib.orc_lzp_encode(_buf(data), len(data), out)
-        return n, (bytes(out[:n]) if n > 0 else b"")
+        return n, (C.string_at(out, n) if n > 0 else b"")
 
     def lzp_decode(self, data, maxout):
         out = (C.c_uint8 * max(8, maxout))()
         n = self.lib.orc_lzp_decode(_buf(data), len(data), out, maxout)
-        return n, (bytes(out[:n]) if n > 0 else b"")
+        return n, (C.string_at(out, n) if n > 0 else b"")
 
     def bwt(self, data):
         out = (C.c_uint8 * max(1, len(data)))()
         idx = self.lib.orc_bwt(_buf(data), out, len(data))
-        return idx, bytes(out[: len(data)])
+        return idx, C.string_at(out, len(data))
 
     def unbwt(self, data, idx):
         out = (C.c_uint8 * max(1, len(data)))()
         rc = self.lib.orc_unbwt(_buf(data), out, len(data), idx)
-        return rc, bytes(out[: len(data)])
+        return rc, C.string_at(out, len(data))
 
     def cm_encode(self, data):
         out = (C.c_uint8 * (len(data) + len(data) // 50 + 64))()
         n = self.lib.orc_cm_encode(_buf(data), len(data), out)
-        return bytes(out[:n])
+        return C.string_at(out, n)
 
     def cm_decode(self, data, n):
         out = (C.c_uint8 * max(1, n))()
         self.lib.orc_cm_decode(_buf(data), len(data), out, n)
-        return bytes(out[:n])
+        return C.string_at(out, n)
 
     def encode_block(self, data, block_size):
         cap = self.bound(max(len(data), 64)) + 64
@@ -112,7 +112,7 @@ class Oracle:
         C.memmove(buf, bytes(data), len(data))
         err = C.c_int32(0)
         n = self.lib.orc_encode_block(buf, len(data), block_size, C.byref(err))
-        return n, err.value, (bytes(buf[:n]) if n > 0 else b"")
+        return n, err.value, (C.string_at(buf, n) if n > 0 else b"")
 
     def decode_block(self, data, orig_size, block_size, buffer_size=None, comp_size=None):
         cap = self.bound(block_size) + 64
@@ -122,7 +122,7 @@ class Oracle:
         C.memmove(buf, bytes(data), len(data))
         err = C.c_int32(0)
         n = self.lib.orc_decode_block(buf, buffer_size, comp_size, orig_size, block_size, C.byref(err))
-        return n, err.value, (bytes(buf[:n]) if n > 0 else b"")
+        return n, err.value, (C.string_at(buf, n) if n > 0 else b"")
 
 
 class RefStages:
@@ -161,43 +161,43 @@ class RefStages:
     def mrle_encode(self, data):
         out = (C.c_uint8 * (len(data) + 64))()
         n = self.lib.ref_mrlec(_buf(data), len(data), out)
-        return bytes(out[:n])
+        return C.string_at(out, n)
 
     def mrle_decode(self, data, outlen, maxin=None):
         maxin = len(data) if maxin is None else maxin
         out = (C.c_uint8 * max(1, outlen))()
         rc = self.lib.ref_mrled(_buf(data), out, outlen, maxin)
-        return rc, bytes(out[:outlen])
+        return rc, C.string_at(out, outlen)
 
     def lzp_encode(self, data):
         out = (C.c_uint8 * (len(data) + 64))()
         n = self.lib.ref_lzp_compress(_buf(data), out, len(data))
-        return n, (bytes(out[:n]) if n > 0 else b"")
+        return n, (C.string_at(out, n) if n > 0 else b"")
 
     def lzp_decode(self, data, maxout):
         out = (C.c_uint8 * max(8, maxout))()
         n = self.lib.ref_lzp_decompress(_buf(data), out, len(data), maxout)
-        return n, (bytes(out[:n]) if n > 0 else b"")
+        return n, (C.string_at(out, n) if n > 0 else b"")
 
     def bwt(self, data):
         out = (C.c_uint8 * max(1, len(data)))()
         idx = self.lib.ref_bwt(_buf(data), out, len(data))
-        return idx, bytes(out[: len(data)])
+        return idx, C.string_at(out, len(data))
 
     def unbwt(self, data, idx):
         out = (C.c_uint8 * max(1, len(data)))()
         rc = self.lib.ref_unbwt(_buf(data), out, len(data), idx)
-        return rc, bytes(out[: len(data)])
+        return rc, C.string_at(out, len(data))
 
     def cm_encode(self, data):
         out = (C.c_uint8 * (len(data) + len(data) // 50 + 64))()
         n = self.lib.ref_cm_encode(_buf(data), len(data), out)
-        return bytes(out[:n])
+        return C.string_at(out, n)
 
     def cm_decode(self, data, n):
         out = (C.c_uint8 * max(1, n))()
         self.lib.ref_cm_decode(_buf(data), len(data), out, n)
-        return bytes(out[:n])
+        return C.string_at(out, n)
 
 
 class RefLib:
@@ -264,7 +264,7 @@ class Bz3:
             C.memmove(buf, bytes(data), len(data))
             n = self.lib.bz3_encode_block(st, buf, len(data))
             err = self.lib.bz3_last_error(st)
-            return n, err, (bytes(buf[:n]) if n > 0 else b"")
+            return n, err, (C.string_at(buf, n) if n > 0 else b"")
         finally:
             self.lib.bz3_free(st)
 
@@ -279,6 +279,6 @@ class Bz3:
             C.memmove(buf, bytes(data), len(data))
             n = self.lib.bz3_decode_block(st, buf, buffer_size, comp_size, orig_size)
             err = self.lib.bz3_last_error(st)
-            return n, err, (bytes(buf[:n]) if n > 0 else b"")
+            return n, err, (C.string_at(buf, n) if n > 0 else b"")
         finally:
             self.lib.bz3_free(st)

@@ -1,0 +1,38 @@
+"""Times the whole-GPU stages (everything except the CM coder) at full block size through the stage hooks:
+python tools/stage_probe.py <MiB>.  Host wall-clock per call, includes the H2D/D2H of the hook."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import torch  # noqa: E402  (first: shared HIP runtime)
+
+import bzip3_amd  # noqa: E402
+from bench import gen_text_device  # noqa: E402
+
+
+def main():
+    mib = float(sys.argv[1]) if len(sys.argv) > 1 else 256
+    n = int(mib * (1 << 20))
+    d = bytes(gen_text_device(torch, n, 7, torch.device("cuda", 0)).cpu().numpy())
+    g = bzip3_amd.StageApi(bzip3_amd.load())
+    for rep in range(2):
+        t = time.time(); crc = g.crc32c(d); t_crc = time.time() - t
+        t = time.time(); rle = g.mrle_encode(d); t_rle = time.time() - t
+        t = time.time(); nl, lz = g.lzp_encode(d); t_lzp = time.time() - t
+        src = lz if nl > 0 else d
+        t = time.time(); idx, u = g.bwt(src); t_bwt = time.time() - t
+        t = time.time(); rc, back = g.unbwt(u, idx); t_unbwt = time.time() - t
+        assert rc == 0 and back == src
+        t_unlzp = 0.0
+        if nl > 0:
+            t = time.time(); k, back2 = g.lzp_decode(lz, n + 100); t_unlzp = time.time() - t
+            assert k == n and back2 == d
+        print(f"[{mib:g} MiB rep{rep}] crc {t_crc*1e3:.0f} ms  rle {t_rle*1e3:.0f} ms (-> {len(rle)})  lzp {t_lzp*1e3:.0f} ms (-> {nl})  "
+              f"bwt {t_bwt*1e3:.0f} ms  unbwt {t_unbwt*1e3:.0f} ms  unlzp {t_unlzp*1e3:.0f} ms   [hook times include ~{n/25e9*2e3:.0f} ms of PCIe copies]")
+        sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()
