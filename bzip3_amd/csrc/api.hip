@@ -376,7 +376,7 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         for (s32 i = w0; i < w1; i++) {
             encode_front_b(sts[i], arena, ctxs[(size_t)(i - w0)], driver_ms);
             if (sts[i]->pending == bz3_state::ENC_CODED)
-                jobs.push_back(CmEncodeJob{sts[i]->b2, sts[i]->n_cm, sts[i]->b1 + sts[i]->overhead * 4 + 1, sts[i]->d_words + 2});  // :634-638
+                jobs.push_back(CmEncodeJob{dev_addr(sts[i]->b2), dev_addr(sts[i]->b1 + sts[i]->overhead * 4 + 1), dev_addr(sts[i]->d_words + 2), sts[i]->n_cm, 0u});  // :634-638
         }
         arena.release(mk);
     }
@@ -558,7 +558,7 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     for (s32 i = 0; i < n; i++) {
         decode_front(sts[i], bufs[i], buffer_sizes[i], sizes[i], orig_sizes[i], hdrs + 17 * (size_t)i);
         if (sts[i]->pending == bz3_state::DEC_CODED)
-            cm_jobs.push_back(CmDecodeJob{sts[i]->cm_in, sts[i]->cm_in_size, sts[i]->d_swap, (u32)sts[i]->size_before_bwt});
+            cm_jobs.push_back(CmDecodeJob{dev_addr(sts[i]->cm_in), dev_addr(sts[i]->d_swap), sts[i]->cm_in_size, (u32)sts[i]->size_before_bwt});
     }
     size_t n_lzp = 0;
     for (s32 i = 0; i < n; i++)
@@ -597,8 +597,8 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
                 continue;
             }
             const size_t bound = bz3_bound((size_t)st->block_size);
-            lz_jobs.push_back(LzpDecodeJob{st->b1, (u32)st->lzp_size, st->b2, (u32)bound, luts + lz_jobs.size() * LZP_LUT_WORDS,
-                                           reinterpret_cast<s32 *>(st->d_words + 5)});
+            lz_jobs.push_back(LzpDecodeJob{dev_addr(st->b1), dev_addr(st->b2), dev_addr(luts + lz_jobs.size() * LZP_LUT_WORDS), dev_addr(st->d_words + 5),
+                                           (u32)st->lzp_size, (u32)bound});
         }
     }
     // ---- phase 3: ONE LZP-decode launch (one workgroup per block) -----------------------------------------
@@ -1094,10 +1094,11 @@ BZIP3_API int32_t bz3_hip_stage_lzp_decode(const uint8_t * in, int32_t n, uint8_
         u8 * o = e.dev((size_t)max + 64);
         Arena a = e.ctx->arena_for(workspace_bytes_for((u64)n + 64));
         if (n < 4) return -1;  // :252
-        LzpDecodeJob job{d, (u32)n, o, (u32)max, a.take<u32>(LZP_LUT_WORDS), reinterpret_cast<s32 *>(a.take<u32>(4))};
+        u32 * d_result = a.take<u32>(4);
+        LzpDecodeJob job{dev_addr(d), dev_addr(o), dev_addr(a.take<u32>(LZP_LUT_WORDS)), dev_addr(d_result), (u32)n, (u32)max};
         LzpDecodeJob * d_job = a.take<LzpDecodeJob>(1);
         lzp_decode_batch(&job, d_job, 1, e.s);
-        const s32 r = (s32)e.word(reinterpret_cast<const u32 *>(job.result));
+        const s32 r = (s32)e.word(d_result);
         if (r > 0) e.down(out, o, (size_t)r);
         return r;
     });
@@ -1140,7 +1141,8 @@ BZIP3_API int32_t bz3_hip_stage_cm_encode(const uint8_t * in, int32_t n, uint8_t
         u8 * d = e.dev((size_t)n + 64, in, (size_t)n);
         u8 * o = e.dev(bz3_bound((size_t)n) + 64);
         u32 * w = (u32 *)e.dev(64);
-        CmEncodeJob job{d, (u32)n, o, w};
+        const char * dbg = getenv("BZ3_CM_DEBUG");  // profiling only: 1 = coder alone, 2 = model alone (output invalid)
+        CmEncodeJob job{dev_addr(d), dev_addr(o), dev_addr(w), (u32)n, dbg ? (u32)atoi(dbg) : 0u};
         CmEncodeJob * d_job = (CmEncodeJob *)e.dev(sizeof job, &job, sizeof job);
         cm_encode_batch(d_job, 1, e.s);
         const s32 size = (s32)e.word(w);
@@ -1154,7 +1156,7 @@ BZIP3_API void bz3_hip_stage_cm_decode(const uint8_t * in, int32_t in_size, uint
         StageEnv e;
         u8 * d = e.dev((size_t)in_size + 64, in, (size_t)in_size);
         u8 * o = e.dev((size_t)n + 64);
-        CmDecodeJob job{d, (u32)in_size, o, (u32)n};
+        CmDecodeJob job{dev_addr(d), dev_addr(o), (u32)in_size, (u32)n};
         CmDecodeJob * d_job = (CmDecodeJob *)e.dev(sizeof job, &job, sizeof job);
         cm_decode_batch(d_job, 1, e.s);
         e.down(out, o, (size_t)n);

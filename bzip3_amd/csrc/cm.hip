@@ -99,118 +99,258 @@ __device__ __forceinline__ void cm_learn(CmLds & m, const CmProbe & q, u32 node,
 }
 
 // ------------------------------------------------------------------------------------------------
-// encode: two waves.  Wave 1 ("model") walks the block: lanes 0..7 own the 8 tree levels of the current
-// byte, evaluate their node, update the counters and push one 16-byte event per coded bit into an LDS ring.
+// encode: four waves.
+//
+// The model factorises exactly by tree node: C0[node], C1[*][node] and the two C2 rows of a node are touched
+// only by the coded bits that pass through that node, and the encoder knows every byte up front.  So the three
+// "model" waves give every tree node its own lane (wave 1: levels 0-5 = nodes 1..63, wave 2: level 6 = nodes
+// 64..127, wave 3: level 7 = nodes 128..255, two per lane) and walk the block in chunks of 32 bytes:
+//   chain loop : for each byte of the chunk, the lanes whose node lies on that byte's path (one per level)
+//                read their counters, form p, read the two C2 cells, update all four counters, and leave
+//                (p, x1, x2, bit) in a per-wave LDS event array.  Only counter traffic is on this serial path;
+//                a counter that is hit again right away is forwarded in registers (BWT output is run-heavy);
+//   event loop : one lane per event finishes the interpolation (ssep, 18-bit probability) and writes the
+//                16-byte coder event into the LDS ring.
 // Wave 0 ("coder") drains the ring and runs the serial range recurrence.
 //
 // Coder formulation (exact).  With high == low + range, the reference's update
 //     mid = low + ((range * P) >> 18);   bit ? high = mid : low = mid + 1                  (:388, :402)
 // is   bit = 1:  range' = (range * P) >> 18                       low' = low
 //      bit = 0:  range' = (range * (2^18 - P) - 1) >> 18          low' = low + (range - range')
-// (range - ((range*P)>>18) - 1 == ((range*(2^18-P)) - 1) >> 18 for every range, P < 2^18), so the model wave
-// ships (-s, -s, M, s) with M = P or 2^18 - P and the coder needs one v_mad_u64_u32, one 64-bit shift, one
+// (range - ((range*P)>>18) - 1 == ((range*(2^18-P)) - 1) >> 18 for every range, P < 2^18), so the model waves
+// ship (-s, -s, M, s) with M = P or 2^18 - P and the coder needs one v_mad_u64_u32, one 64-bit shift, one
 // v_sub and one v_mad per bit -- no bit test, no selects.  The coder state is deliberately kept in VECTOR
 // registers (seeded through an opaque v_mov): the events arrive in VGPRs from LDS broadcast reads, and moving
 // them to the scalar unit would cost a v_readfirstlane per operand.  A single wave issues one instruction every ~5.4
 // cycles (8.5 when dependent; profiles/r01_ubench_single_wave.txt), so instruction count is the currency.
 // ------------------------------------------------------------------------------------------------
-constexpr u32 CM_RING = 64;  // bytes of look-ahead between the model wave and the coder wave (8 KiB of LDS)
+constexpr u32 CM_RING = 64;   // bytes of look-ahead between the model waves and the coder wave (8 KiB of LDS)
+constexpr u32 CM_CHUNK = 32;  // bytes per model-wave chunk
 
-__device__ __forceinline__ u32 lds_peek(const u32 * p) { return *reinterpret_cast<const volatile u32 *>(p); }
-__device__ __forceinline__ void lds_poke(u32 * p, u32 v) { *reinterpret_cast<volatile u32 *>(p) = v; }
+#ifdef BZ3_EMU
+#define LDS_PEEK(var) (*reinterpret_cast<const volatile u32 *>(&(var)))
+#define LDS_POKE(var, v) (*reinterpret_cast<volatile u32 *>(&(var)) = (v))
+#else
+// relaxed workgroup-scope atomics on __shared__ words: plain ds_read_b32 / ds_write_b32 that the compiler
+// neither caches in registers nor turns into flat (generic address space) accesses
+#define LDS_PEEK(var) __hip_atomic_load(&(var), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define LDS_POKE(var, v) __hip_atomic_store(&(var), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#endif
 
-__global__ void __launch_bounds__(128) k_cm_encode(const CmEncodeJob * __restrict__ jobs) {
+struct CmEvent {  // what the chain loop leaves for the event loop
+    u32 px1;      // p | x1 << 16
+    u32 x2b;      // x2 | bit << 16
+};
+
+// Per-lane constants of a model lane: LDS byte offsets are precomputed so that the chain body is branch-free.
+struct CmLane {
+    u32 node;      // first node of this lane (second one, if any, is node + 64)
+    u32 lvl;       // tree level of the node(s)
+    u32 hibit;     // 1 << lvl
+    u32 shr;       // 8 - lvl
+    u32 bitpos;    // 7 - lvl
+};
+
+// Counter updates without a branch on the bit (:347-348).  For a 16-bit counter x and shift s,
+//   bit = 1:  x + ((x ^ 65535) >> s)  ==  x - (x >> s) + (65535 >> s)      bit = 0:  x - (x >> s)
+// so every update is "x - (x >> s) + K" with K = bit ? (65535 >> s) : 0; the two C2 cells (s = 6) are done as one
+// packed 2 x u16 operation on the 32-bit word that holds both.
+__device__ __forceinline__ u32 cm_upd(u32 x, int s, u32 k) { return x - (x >> s) + k; }
+__device__ __forceinline__ u32 cm_upd_pair6(u32 w, u32 k2) {
+    const u32 sh = (w >> 6) & 0x03FF03FFu;  // per-half x >> 6
+    return w - sh + k2;                     // no borrow/carry crosses the halves: each half stays within [0, 65535]
+}
+
+// One byte of the chain: wave-uniform (c, c1 << 8, c2 << 8, f) and the lanes of this wave whose node is on the path.
+template <int NSLOT>
+__device__ __forceinline__ void cm_chain_step(CmLds & m, CmEvent * __restrict__ ev_row, const CmLane & L, u32 c, u32 c1s, u32 c2s, u32 f,
+                                              u32 (&c0)[NSLOT]) {
+    const u32 path = L.hibit | (c >> L.shr);  // the node of this lane's level on this byte's path
+    bool hit = path == L.node;
+    if (NSLOT == 2) hit = hit || path == L.node + 64u;
+    if (hit) {
+        const u32 bit = (c >> L.bitpos) & 1u;
+        const u32 mk = 0u - bit;                        // all ones when the bit is 1
+        u32 p0 = c0[0];
+        if (NSLOT == 2) p0 = (path == L.node) ? c0[0] : c0[NSLOT - 1];
+        const u32 a1 = c1s + path, a2 = c2s + path;     // C1 indices (c1 * 256 + node)
+        const u32 p1 = m.c1[a1];
+        const u32 p2 = m.c1[a2];
+        const u32 p = ((p0 + p1) * 7u + 2u * p2) >> 4;  // :380
+        const u32 ci = (2u * path + f) * CM_C2_STRIDE + (p >> 12);
+        const u32 w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[ci]));  // x1 | x2 << 16 (cells j, j+1)
+        const u32 na = cm_upd(p0, 2, mk & 16383u);      // :396-399 / :411-414
+        const u32 nb = cm_upd(p1, 4, mk & 4095u);
+        const u32 nw = cm_upd_pair6(w, mk & 0x03FF03FFu);
+        if (NSLOT == 2) {
+            c0[0] = (path == L.node) ? na : c0[0];
+            c0[NSLOT - 1] = (path == L.node) ? c0[NSLOT - 1] : na;
+        } else {
+            c0[0] = na;
+        }
+        m.c1[a1] = (u16)nb;
+        reinterpret_cast<PackedU32 *>(&m.c2[ci])->v = nw;
+        CmEvent e;
+        e.px1 = p | (bit << 16);
+        e.x2b = w;
+        *ev_row = e;
+    }
+}
+
+// One chunk of one model wave.  NSLOT = nodes per lane (1 or 2).  lvl_lo / nlvl = tree levels this wave owns.
+template <int NSLOT, bool FULL>
+__device__ __forceinline__ void cm_model_chunk(CmLds & m, CmEvent * __restrict__ ev, uint4 * __restrict__ ring, const u32 packed, const u32 fmask,
+                                               const u32 cnt, const u32 base, const CmLane & L, const u32 lvl_lo, const u32 nlvl, u32 (&c0)[NSLOT]) {
+    const int lane = lane_id();
+    CmEvent * __restrict__ ev_lvl = ev + (L.lvl - lvl_lo) * CM_CHUNK;
+    // ---- chain loop: serial in time, parallel over the nodes of this wave ------------------------------
+    if (FULL) {
+#pragma unroll
+        for (int r = 0; r < (int)CM_CHUNK; r++) {
+            const u32 w = cm_readlane(packed, r);  // byte r | byte r-1 << 8 | byte r-2 << 16   (wave-uniform)
+            cm_chain_step<NSLOT>(m, ev_lvl + r, L, w & 0xFFu, w & 0xFF00u, (w >> 8) & 0xFF00u, (fmask >> r) & 1u, c0);
+        }
+    } else {
+        for (u32 r = 0; r < cnt; r++) {
+            const u32 w = cm_readlane(packed, (int)r);
+            cm_chain_step<NSLOT>(m, ev_lvl + r, L, w & 0xFFu, w & 0xFF00u, (w >> 8) & 0xFF00u, (fmask >> r) & 1u, c0);
+        }
+    }
+    wave_sync();
+    // ---- event loop: one lane per event, 18-bit probability -> coder event ----------------------------
+    const u32 nev = nlvl * CM_CHUNK;
+    for (u32 e0 = 0; e0 < nev; e0 += WAVE) {
+        const u32 e = e0 + (u32)lane;
+        const u32 r = e % CM_CHUNK, k = lvl_lo + e / CM_CHUNK;
+        if (e < nev && r < cnt) {
+            const CmEvent q = ev[e];
+            const int p = (int)(q.px1 & 0xFFFFu), x1 = (int)(q.x2b & 0xFFFFu), x2 = (int)(q.x2b >> 16);
+            const u32 bit = q.px1 >> 16;
+            const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);  // :385
+            const u32 p18 = (u32)(ssep * 3 + p);                     // :388
+            const u32 neg = bit ? 0u : 0xFFFFFFFFu;
+            ring[((base + r) & (CM_RING - 1)) * 8 + k] = make_uint4(neg, neg, bit ? p18 : (1u << 18) - p18, bit ^ 1u);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restrict__ jobs) {
     // one workgroup per block: blockIdx.x selects the job
-    const u8 * __restrict__ in = jobs[blockIdx.x].in;
+    const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 n = jobs[blockIdx.x].n;
-    u8 * __restrict__ out = jobs[blockIdx.x].out;
-    u32 * __restrict__ out_size = jobs[blockIdx.x].out_size;
+    u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
+    u32 * __restrict__ out_size = global_ptr<u32>(jobs[blockIdx.x].out_size);
+    const u32 debug = jobs[blockIdx.x].debug;
     __shared__ CmLds m;
     __shared__ uint4 ring[CM_RING * 8];
-    __shared__ u32 s_prod, s_cons;
-    if (threadIdx.x == 0) { s_prod = 0; s_cons = 0; }
+    __shared__ CmEvent ev_a[6 * CM_CHUNK], ev_b[CM_CHUNK], ev_c[CM_CHUNK];
+    __shared__ u32 s_prod[3], s_cons;
+    if (threadIdx.x < 3) s_prod[threadIdx.x] = 0;
+    if (threadIdx.x == 3) s_cons = 0;
+    if (debug == 1)  // profiling only: a ring full of p = 1/2 events, so the lone coder emits exactly one byte per input byte
+        for (u32 t = threadIdx.x; t < CM_RING * 8; t += blockDim.x) ring[t] = make_uint4(0u, 0u, 1u << 17, 0u);
     cm_model_init(m);
     const int lane = lane_id();
-    const u32 * __restrict__ in32 = reinterpret_cast<const u32 *>(in);  // block buffers are 256-byte aligned
-    if (cm_uniform((u32)wave_id()) == 1) {
-        // ---- model wave --------------------------------------------------------------------------
-        const u32 k = (u32)lane & 7u;
-        u32 c1 = 0, c2 = 0, run = 0, cons_seen = 0, word = 0;
-        for (u32 i = 0; i < n; i++) {
-            while (i - cons_seen >= CM_RING) {  // ring full: wait for the coder
-                cons_seen = lds_peek(&s_cons);
-                if (i - cons_seen >= CM_RING) BZ3_SPIN_PAUSE();
+    const u32 role = cm_uniform((u32)wave_id());
+    if (role != 0) {
+        if (debug == 1) return;
+        // ---- model waves -----------------------------------------------------------------------------
+        const u32 lvl_lo = role == 1 ? 0u : role == 2 ? 6u : 7u;
+        const u32 nlvl = role == 1 ? 6u : 1u;
+        CmLane L;
+        L.node = role == 1 ? (u32)lane : role == 2 ? 64u + (u32)lane : 128u + (u32)lane;
+        L.lvl = role == 1 ? (lane ? (u32)(31 - __clz(lane)) : 0u) : lvl_lo;  // lane 0 of wave 1 owns no node (node 0 never matches)
+        L.hibit = 1u << L.lvl;
+        L.shr = 8u - L.lvl;
+        L.bitpos = 7u - L.lvl;
+        CmEvent * ev = role == 1 ? ev_a : role == 2 ? ev_b : ev_c;
+        u32 c0a[1] = {32768u}, c0b[2] = {32768u, 32768u};  // C0 of this lane's node(s) lives in registers
+        u32 cons_seen = 0;
+        u32 hist = 0;  // the 4 bytes before the chunk, oldest in the top byte (zeros before the block starts)
+        for (u32 base = 0; base < n; base += CM_CHUNK) {
+            const u32 cnt = (n - base < CM_CHUNK) ? n - base : CM_CHUNK;
+            while (debug != 2 && base + cnt - cons_seen > CM_RING) {  // ring full: wait for the coder
+                cons_seen = LDS_PEEK(s_cons);
+                if (base + cnt - cons_seen > CM_RING) BZ3_SPIN_PAUSE();
             }
-            if ((i & 3u) == 0) word = cm_uniform(in32[i >> 2]);  // wave-uniform address: a scalar load
-            const u32 c = (word >> ((i & 3u) * 8u)) & 0xFFu;
-            run = (c1 == c2) ? run + 1 : 0;  // :367-372
-            const u32 f = run > 2 ? 1u : 0u;
-            const u32 node = (1u << k) | (c >> (8 - k));
-            const u32 bit = (c >> (7 - k)) & 1u;
-            CmProbe q = cm_probe(m, node, c1, c2, f);
-            wave_sync();
-            if (lane < 8) {
-                cm_learn(m, q, node, c1, bit);
-                const u32 neg = bit ? 0u : 0xFFFFFFFFu;
-                ring[(i & (CM_RING - 1)) * 8 + k] = make_uint4(neg, neg, bit ? q.p18 : (1u << 18) - q.p18, bit ^ 1u);
+            // lane r holds byte r of the chunk together with its 4 predecessors
+            const u32 mine = ((u32)lane < cnt) ? in[base + lane] : 0u;
+            u32 prev4 = 0;  // bytes r-1, r-2, r-3, r-4 in bits 0-7, 8-15, 16-23, 24-31
+#pragma unroll
+            for (int d = 1; d <= 4; d++) {
+                const u32 up = __shfl_up(mine, (unsigned)d);
+                // lanes < d reach back into the previous chunk: hist holds byte -1 in bits 0-7 ... byte -4 in bits 24-31
+                const u32 h = (hist >> (8u * (((u32)d - 1u - (u32)lane) & 3u))) & 0xFFu;
+                prev4 |= (((u32)lane >= (u32)d) ? up : h) << (8 * (d - 1));
             }
-            wave_sync();
-            c2 = c1;
-            c1 = c;
-            if ((i & 3u) == 3u || i + 1 == n) {
-                lds_release();
-                if (lane == 0) lds_poke(&s_prod, i + 1);
+            const u32 packed = mine | ((prev4 & 0xFFFFu) << 8);
+            // run flag of byte i (:367-372): set iff i >= 2 and the four preceding bytes are equal
+            const u32 i = base + (u32)lane;
+            const bool fr = (u32)lane < cnt && i >= 2 && (prev4 & 0xFFu) == ((prev4 >> 8) & 0xFFu) && (prev4 & 0xFFFFu) == (prev4 >> 16);
+            const u32 fmask = (u32)__ballot(fr);
+            if (role == 3) {
+                if (cnt == CM_CHUNK) cm_model_chunk<2, true>(m, ev, ring, packed, fmask, cnt, base, L, lvl_lo, nlvl, c0b);
+                else cm_model_chunk<2, false>(m, ev, ring, packed, fmask, cnt, base, L, lvl_lo, nlvl, c0b);
+            } else {
+                if (cnt == CM_CHUNK) cm_model_chunk<1, true>(m, ev, ring, packed, fmask, cnt, base, L, lvl_lo, nlvl, c0a);
+                else cm_model_chunk<1, false>(m, ev, ring, packed, fmask, cnt, base, L, lvl_lo, nlvl, c0a);
             }
+            // history for the next chunk (only needed after a full chunk): byte -d of the next chunk = byte cnt-d of this one
+            if (cnt == CM_CHUNK) {
+                hist = cm_readlane(mine, (int)CM_CHUNK - 1) | (cm_readlane(mine, (int)CM_CHUNK - 2) << 8) | (cm_readlane(mine, (int)CM_CHUNK - 3) << 16) |
+                       (cm_readlane(mine, (int)CM_CHUNK - 4) << 24);
+            }
+            lds_release();
+            if (lane == 0) LDS_POKE(s_prod[role - 1], base + cnt);
         }
         return;
     }
-    // ---- coder wave (every lane carries the same state; lane 0 stores) ---------------------------------
+    // ---- coder wave: ONE active lane (an LDS read then returns 16 bytes, not 64 x 16) ------------------------
+    if (debug == 2 || lane != 0) return;
     u32 vzero;
 #ifdef BZ3_EMU
     vzero = 0;
 #else
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));  // opaque zero: keeps the recurrence on the vector ALU
 #endif
-    u32 range = 0xFFFFFFFFu ^ vzero, op = 0, prod_seen = 0;
-    u64 low = vzero;  // only the low 32 bits are meaningful
+    u32 range = 0xFFFFFFFFu ^ vzero, low = vzero, op = 0, prod_seen = debug == 1 ? 0xFFFFFFFFu : 0u;
     for (u32 i = 0; i < n; i++) {
         while (prod_seen <= i) {
-            prod_seen = lds_peek(&s_prod);
+            const u32 a = LDS_PEEK(s_prod[0]), b = LDS_PEEK(s_prod[1]), c = LDS_PEEK(s_prod[2]);
+            prod_seen = a < b ? (a < c ? a : c) : (b < c ? b : c);
             if (prod_seen <= i) BZ3_SPIN_PAUSE();
         }
         lds_acquire();
         const uint4 * __restrict__ evp = &ring[(i & (CM_RING - 1)) * 8];
         uint4 ev[8];
 #pragma unroll
-        for (int kk = 0; kk < 8; kk++) ev[kk] = evp[kk];  // same address in every lane: LDS broadcast reads
+        for (int kk = 0; kk < 8; kk++) ev[kk] = evp[kk];
 #pragma unroll
         for (int kk = 0; kk < 8; kk++) {
-            const uint4 e = ev[kk];
+            const uint4 e = ev[kk];  // (-s, -s, M, s): see the header comment
             const u64 prod = (u64)range * e.z + (((u64)e.y << 32) | e.x);
             const u32 r2 = (u32)(prod >> 18);
-            low += (u64)(range - r2) * e.w;
+            low += (range - r2) & e.x;
             range = r2;
-            if (__ballot(range < (1u << 24)) != 0ull) {  // necessary for (low ^ high) < 2^24; the exact test follows
-                u32 lo32 = (u32)low;
-                while (__ballot((lo32 ^ (lo32 + range)) < (1u << 24)) != 0ull) {  // :390-394
-                    if (lane == 0) out[op] = (u8)(lo32 >> 24);
-                    op++;
-                    lo32 <<= 8;
+            // Branch on a wave-uniform condition (ballot of the single live lane -> s_cbranch_vccnz): a divergent
+            // `if` would save/restore EXEC around every bit, and every EXEC write stalls the following VALU op.
+            // __builtin_expect keeps the renormalisation out of line: the common case must FALL THROUGH, a taken
+            // branch per coded bit costs an instruction-fetch redirect (~40 cycles on a lone wave).
+            if (__builtin_expect(__ballot(range < (1u << 24)) != 0ull, 0)) {  // necessary for (low ^ high) < 2^24; the exact test follows
+                while (__ballot((low ^ (low + range)) < (1u << 24)) != 0ull) {  // :390-394
+                    out[op++] = (u8)(low >> 24);
+                    low <<= 8;
                     range = (range << 8) | 0xFFu;
                 }
-                low = lo32;
             }
         }
-        if ((i & 15u) == 15u && lane == 0) lds_poke(&s_cons, i + 1);
+        if ((i & 15u) == 15u) LDS_POKE(s_cons, i + 1);
     }
-    if (lane == 0) {  // flush (:425-432)
-        u32 lo32 = (u32)low;
-        for (int j = 0; j < 4; j++) {
-            out[op + j] = (u8)(lo32 >> 24);
-            lo32 <<= 8;
-        }
-        *out_size = op + 4;
+    for (int j = 0; j < 4; j++) {  // flush (:425-432)
+        out[op + j] = (u8)(low >> 24);
+        low <<= 8;
     }
+    *out_size = op + 4;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -220,9 +360,9 @@ __global__ void __launch_bounds__(128) k_cm_encode(const CmEncodeJob * __restric
 // 8 lanes whose node lies on the decoded path then update their counters.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restrict__ jobs) {
-    const u8 * __restrict__ in = jobs[blockIdx.x].in;
+    const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 in_size = jobs[blockIdx.x].in_size;
-    u8 * __restrict__ out = jobs[blockIdx.x].out;
+    u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
     const u32 n = jobs[blockIdx.x].n;
     __shared__ CmLds m;
     __shared__ u32 ptab[256];
@@ -321,7 +461,7 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
 }
 
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s) {
-    if (njobs) launch(k_cm_encode, dim3(njobs), dim3(128), 0, s, d_jobs);
+    if (njobs) launch(k_cm_encode, dim3(njobs), dim3(256), 0, s, d_jobs);
 }
 
 void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s) {

@@ -127,17 +127,17 @@ constexpr int LZ_WIN_WORDS = 4 * LZ_DRV;     // bitmap words scanned per iterati
 
 __global__ void __launch_bounds__(LZ_DRV) k_lzp_driver(const LzpDriverJob * __restrict__ jobs) {
     // one workgroup per block: a batch of blocks runs its (serial) drivers side by side
-    const u8 * __restrict__ in = jobs[blockIdx.x].in;
+    const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 n = jobs[blockIdx.x].n;
-    u32 * __restrict__ prev = jobs[blockIdx.x].prev;
-    const u32 * __restrict__ next = jobs[blockIdx.x].next;
-    u32 * __restrict__ cand_bits = jobs[blockIdx.x].cand_bits;
+    u32 * __restrict__ prev = global_ptr<u32>(jobs[blockIdx.x].prev);
+    const u32 * __restrict__ next = global_ptr<const u32>(jobs[blockIdx.x].next);
+    u32 * __restrict__ cand_bits = global_ptr<u32>(jobs[blockIdx.x].cand_bits);
     const u32 nwords = jobs[blockIdx.x].nwords;
-    u32 * __restrict__ skip = jobs[blockIdx.x].skip;
-    u32 * __restrict__ mstart = jobs[blockIdx.x].mstart;
-    u32 * __restrict__ mpos = jobs[blockIdx.x].mpos;
-    u32 * __restrict__ mlen = jobs[blockIdx.x].mlen;
-    LzDriverOut * __restrict__ result = jobs[blockIdx.x].result;
+    u32 * __restrict__ skip = global_ptr<u32>(jobs[blockIdx.x].skip);
+    u32 * __restrict__ mstart = global_ptr<u32>(jobs[blockIdx.x].mstart);
+    u32 * __restrict__ mpos = global_ptr<u32>(jobs[blockIdx.x].mpos);
+    u32 * __restrict__ mlen = global_ptr<u32>(jobs[blockIdx.x].mlen);
+    LzDriverOut * __restrict__ result = global_ptr<LzDriverOut>(jobs[blockIdx.x].result);
     __shared__ u32 cq[LZ_EV_CAP];
     __shared__ u32 ev_ref[LZ_EV_CAP];
     __shared__ u64 ev_mask[LZ_EV_CAP];
@@ -407,7 +407,8 @@ void lzp_encode_prepare(const u8 * d_in, u32 n, LzpEncodeCtx & c, Arena & tmp, h
 }
 
 LzpDriverJob lzp_driver_job(const LzpEncodeCtx & c) {
-    return LzpDriverJob{c.in, c.n, c.prev, c.next, c.cand_bits, c.nwords, c.skip, c.mstart, c.mpos, c.mlen, c.d_res};
+    return LzpDriverJob{dev_addr(c.in), dev_addr(c.prev), dev_addr(c.next), dev_addr(c.cand_bits), dev_addr(c.skip), dev_addr(c.mstart), dev_addr(c.mpos),
+                        dev_addr(c.mlen), dev_addr(c.d_res), c.n, c.nwords};
 }
 
 // Phase B (asynchronous): the serial drivers of a batch of blocks, one workgroup each.
@@ -467,12 +468,12 @@ s32 lzp_encode(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s) {
 constexpr int LZD_CHUNK = 16384;  // input bytes staged in LDS per iteration (16 per lane)
 
 __global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const LzpDecodeJob * __restrict__ jobs) {
-    const u8 * __restrict__ in = jobs[blockIdx.x].in;
+    const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 n = jobs[blockIdx.x].n;
-    u8 * __restrict__ out = jobs[blockIdx.x].out;
+    u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
     const u32 max_out = jobs[blockIdx.x].max_out;
-    u32 * __restrict__ lut = jobs[blockIdx.x].lut;
-    s32 * __restrict__ result = jobs[blockIdx.x].result;
+    u32 * __restrict__ lut = global_ptr<u32>(jobs[blockIdx.x].lut);
+    s32 * __restrict__ result = global_ptr<s32>(jobs[blockIdx.x].result);
     __shared__ u8 stage[LZD_CHUNK + 16];  // [0..3] = the 4 output bytes before the chunk, [4..] = input bytes
     __shared__ u32 red[LZ_DRV / WAVE + 1];
     __shared__ u32 s_ip, s_op, s_copy_src, s_copy_cnt, s_fail;
@@ -567,7 +568,7 @@ __global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const LzpDecodeJob * __re
 
 void lzp_decode_batch(const LzpDecodeJob * h_jobs, LzpDecodeJob * d_jobs, u32 njobs, hipStream_t s) {
     if (!njobs) return;
-    for (u32 i = 0; i < njobs; i++) HIP_CHECK(hipMemsetAsync(h_jobs[i].lut, 0, LZP_LUT_WORDS * sizeof(u32), s));
+    for (u32 i = 0; i < njobs; i++) HIP_CHECK(hipMemsetAsync(reinterpret_cast<void *>(h_jobs[i].lut), 0, LZP_LUT_WORDS * sizeof(u32), s));
     HIP_CHECK(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LzpDecodeJob) * njobs, hipMemcpyHostToDevice, s));
     launch(k_lzp_decode, dim3(njobs), dim3(LZ_DRV), 0, s, (const LzpDecodeJob *)d_jobs);
 }

@@ -50,18 +50,11 @@ struct LzpEncodeCtx {
     u32 *prev = nullptr, *next = nullptr, *skip = nullptr, *mstart = nullptr, *cand_bits = nullptr, *mpos = nullptr, *mlen = nullptr;
     LzDriverOut * d_res = nullptr;
 };
-struct LzpDriverJob {
-    const u8 * in;
-    u32 n;
-    u32 * prev;
-    const u32 * next;
-    u32 * cand_bits;
-    u32 nwords;
-    u32 * skip;
-    u32 * mstart;
-    u32 * mpos;
-    u32 * mlen;
-    LzDriverOut * result;
+struct LzpDriverJob {  // device addresses as integers: see prims.hpp global_ptr()
+    u64 in;
+    u64 prev, next, cand_bits, skip, mstart, mpos, mlen;
+    u64 result;  // LzDriverOut *
+    u32 n, nwords;
 };
 size_t lzp_encode_ctx_bytes(u64 n);
 void lzp_encode_prepare(const u8 * d_in, u32 n, LzpEncodeCtx & c, Arena & tmp, hipStream_t s);
@@ -70,13 +63,12 @@ void lzp_driver_batch(const LzpDriverJob * h_jobs, LzpDriverJob * d_jobs, u32 nj
 s32 lzp_encode_finish(const LzpEncodeCtx & c, u8 * d_out, Arena & tmp, hipStream_t s);  // encoded size or -1
 s32 lzp_encode(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s);         // one block, all three phases
 // Decode: one workgroup per block, so a batch of blocks decodes concurrently (one launch, grid = jobs).
-struct LzpDecodeJob {
-    const u8 * in;
-    u32 n;
-    u8 * out;
-    u32 max_out;
-    u32 * lut;     // 2^18 words, zeroed by lzp_decode_batch
-    s32 * result;  // device word: decoded size or -1
+struct LzpDecodeJob {  // device addresses as integers: see prims.hpp global_ptr()
+    u64 in;
+    u64 out;
+    u64 lut;     // 2^18 words, zeroed by lzp_decode_batch
+    u64 result;  // s32 *: decoded size or -1
+    u32 n, max_out;
 };
 constexpr size_t LZP_LUT_WORDS = (size_t)1 << 18;
 void lzp_decode_batch(const LzpDecodeJob * h_jobs, LzpDecodeJob * d_jobs, u32 njobs, hipStream_t s);  // asynchronous
@@ -100,16 +92,17 @@ size_t unbwt_workspace_bytes(u64 n);
 // One workgroup (= one CU: the 145.5 KiB model fills its LDS) per block; a batch is ONE launch with
 // grid = number of blocks, so the blocks of bz3_encode_blocks / bz3_decode_blocks run side by side without
 // depending on how HIP maps streams to hardware queues.  Asynchronous.  Job arrays live in device memory.
-struct CmEncodeJob {
-    const u8 * in;
+struct CmEncodeJob {  // device addresses as integers: see prims.hpp global_ptr()
+    u64 in;
+    u64 out;       // receives the coded bytes
+    u64 out_size;  // u32 *: receives the coded byte count
     u32 n;
-    u8 * out;        // receives the coded bytes
-    u32 * out_size;  // receives the coded byte count
+    u32 debug;     // 0 = normal; profiling only (output invalid): 1 = coder wave alone, 2 = model waves alone
 };
 struct CmDecodeJob {
-    const u8 * in;   // coded bytes; reads past in_size yield 0xFF.. like read_in (:345)
+    u64 in;        // coded bytes; reads past in_size yield 0xFF.. like read_in (:345)
+    u64 out;
     u32 in_size;
-    u8 * out;
     u32 n;
 };
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s);
