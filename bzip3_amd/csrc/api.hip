@@ -558,7 +558,7 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     for (s32 i = 0; i < n; i++) {
         decode_front(sts[i], bufs[i], buffer_sizes[i], sizes[i], orig_sizes[i], hdrs + 17 * (size_t)i);
         if (sts[i]->pending == bz3_state::DEC_CODED)
-            cm_jobs.push_back(CmDecodeJob{dev_addr(sts[i]->cm_in), dev_addr(sts[i]->d_swap), sts[i]->cm_in_size, (u32)sts[i]->size_before_bwt});
+            cm_jobs.push_back(CmDecodeJob{dev_addr(sts[i]->cm_in), dev_addr(sts[i]->d_swap), sts[i]->cm_in_size, (u32)sts[i]->size_before_bwt, 0u, 0u});
     }
     size_t n_lzp = 0;
     for (s32 i = 0; i < n; i++)
@@ -1156,7 +1156,8 @@ BZIP3_API void bz3_hip_stage_cm_decode(const uint8_t * in, int32_t in_size, uint
         StageEnv e;
         u8 * d = e.dev((size_t)in_size + 64, in, (size_t)in_size);
         u8 * o = e.dev((size_t)n + 64);
-        CmDecodeJob job{dev_addr(d), dev_addr(o), (u32)in_size, (u32)n};
+        const char * dbg = getenv("BZ3_CM_DEBUG");  // profiling only (output invalid)
+        CmDecodeJob job{dev_addr(d), dev_addr(o), (u32)in_size, (u32)n, dbg ? (u32)atoi(dbg) : 0u, 0u};
         CmDecodeJob * d_job = (CmDecodeJob *)e.dev(sizeof job, &job, sizeof job);
         cm_decode_batch(d_job, 1, e.s);
         e.down(out, o, (size_t)n);

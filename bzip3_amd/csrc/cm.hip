@@ -364,13 +364,21 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
     const u32 in_size = jobs[blockIdx.x].in_size;
     u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
     const u32 n = jobs[blockIdx.x].n;
+    const u32 debug = jobs[blockIdx.x].debug;
     __shared__ CmLds m;
     __shared__ u32 ptab[256];
     __shared__ u32 s_byte;
     cm_model_init(m);
+    if (debug && threadIdx.x < 256) ptab[threadIdx.x] = 1u << 17;  // profiling modes: defined probabilities
+    if (debug && threadIdx.x == 0) s_byte = 'e';
+    __syncthreads();
     const int lane = lane_id();
     const bool coder = cm_uniform((u32)wave_id()) == 0;
-    const u32 node = threadIdx.x - 64u;  // model lanes only
+    // model lanes: one tree node each; the node's C0 counter lives in a register
+    const u32 node = threadIdx.x - 64u;
+    const u32 lvl = (!coder && node) ? (u32)(31 - __clz((int)node)) : 0u;
+    const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
+    u32 c0 = 32768u, q_p1 = 0, q_w = 0, q_a1 = 0, q_ci = 0;
     u32 low = 0, range = 0xFFFFFFFFu, code = 0, c1 = 0, c2 = 0, run = 0;
     u32 ip = 0, ibase = 0;
     u32 window = (coder && ibase + lane < in_size) ? in[ibase + lane] : 0xFFFFFFFFu;
@@ -391,25 +399,31 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
         }
     }
     u32 staged = 0;
-    CmProbe q;
-    q.p0 = q.p1 = q.x1 = q.x2 = q.c2off = q.p18 = 0;
     for (u32 i = 0; i < n; i++) {
         run = (c1 == c2) ? run + 1 : 0;
         const u32 f = run > 2 ? 1u : 0u;
-        if (!coder) {
-            q = cm_probe(m, node, c1, c2, f);
-            ptab[node] = q.p18;
+        if (!coder && debug != 1) {
+            // probabilities of all 255 nodes for this byte (:377-388); node 0 computes a dummy
+            q_a1 = c1 * 256u + node;
+            q_p1 = m.c1[q_a1];
+            const u32 p2 = m.c1[c2 * 256u + node];
+            const int p = (int)(((c0 + q_p1) * 7u + 2u * p2) >> 4);
+            q_ci = (2u * node + f) * CM_C2_STRIDE + (u32)(p >> 12);
+            q_w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[q_ci]));  // x1 | x2 << 16
+            const int x1 = (int)(q_w & 0xFFFFu), x2 = (int)(q_w >> 16);
+            const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);
+            ptab[node] = (u32)(ssep * 3 + p);
         }
         __syncthreads();
-        if (coder) {
+        if (coder && debug != 2) {
             const u32 p0 = ptab[lane], p1 = ptab[lane + 64], p2 = ptab[lane + 128], p3 = ptab[lane + 192];
             u32 ctx = 1;
 #pragma unroll
-            for (int lvl = 0; lvl < 8; lvl++) {  // :453-489
+            for (int lvl_i = 0; lvl_i < 8; lvl_i++) {  // :453-489
                 u32 p18;
                 const int src = (int)(ctx & 63u);
-                if (lvl < 6) p18 = cm_readlane(p0, src);
-                else if (lvl == 6) p18 = cm_readlane(p1, src);
+                if (lvl_i < 6) p18 = cm_readlane(p0, src);
+                else if (lvl_i == 6) p18 = cm_readlane(p1, src);
                 else {
                     const u32 a = cm_readlane(p2, src), b = cm_readlane(p3, src);
                     p18 = (ctx & 64u) ? b : a;
@@ -430,7 +444,7 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
                     range -= mid - low + 1;
                     low = mid + 1;
                 }
-                if (range < (1u << 24)) {
+                if (__builtin_expect(range < (1u << 24), 0)) {  // out of line: the common case falls through
                     while ((low ^ (low + range)) < (1u << 24)) {  // :470-474
                         low <<= 8;
                         range = (range << 8) | 0xFFu;
@@ -450,9 +464,14 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
         }
         __syncthreads();
         const u32 c = cm_uniform(s_byte);
-        if (!coder && node != 0) {
-            const int lvl = 31 - __clz((int)node);
-            if (((256u | c) >> (8 - lvl)) == node) cm_learn(m, q, node, c1, (c >> (7 - lvl)) & 1u);
+        if (!coder && debug != 1) {
+            // the 8 lanes whose node is on the decoded path update their counters (branch-free, see cm_upd)
+            if ((hibit | (c >> shr)) == node) {
+                const u32 mk = 0u - ((c >> bitpos) & 1u);
+                c0 = cm_upd(c0, 2, mk & 16383u);
+                m.c1[q_a1] = (u16)cm_upd(q_p1, 4, mk & 4095u);
+                reinterpret_cast<PackedU32 *>(&m.c2[q_ci])->v = cm_upd_pair6(q_w, mk & 0x03FF03FFu);
+            }
         }
         c2 = c1;
         c1 = c;

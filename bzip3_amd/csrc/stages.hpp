@@ -104,6 +104,8 @@ struct CmDecodeJob {
     u64 out;
     u32 in_size;
     u32 n;
+    u32 debug;     // 0 = normal; profiling only (output invalid): 1 = coder work only, 2 = model work only
+    u32 pad;
 };
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s);
 void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s);

@@ -12,3 +12,10 @@ for mode in ("0", "1", "2", "0"):
     os.environ["BZ3_CM_DEBUG"] = mode
     t = time.time(); out = g.cm_encode(u); dt = time.time() - t
     print(f"BZ3_CM_DEBUG={mode}: {dt*1e3:.0f} ms for {n} bytes = {dt/n*1e9:.0f} ns/B ({dt/n*2.4e9:.0f} cycles/B)", flush=True)
+
+os.environ["BZ3_CM_DEBUG"] = "0"
+enc = g.cm_encode(u)
+for mode in ("0", "1", "2", "0"):
+    os.environ["BZ3_CM_DEBUG"] = mode
+    t = time.time(); out = g.cm_decode(enc, n); dt = time.time() - t
+    print(f"decode BZ3_CM_DEBUG={mode}: {dt*1e3:.0f} ms for {n} bytes = {dt/n*1e9:.0f} ns/B ({dt/n*2.4e9:.0f} cycles/B)", flush=True)
