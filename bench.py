@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--blocks", type=int, default=int(os.environ.get("BZ3_BENCH_BLOCKS", "8")), help="256 MiB blocks per GPU")
+    ap.add_argument("--blocks", type=int, default=int(os.environ.get("BZ3_BENCH_BLOCKS", "240")), help="256 MiB blocks per GPU")
     ap.add_argument("--block-mib", type=float, default=float(os.environ.get("BZ3_BENCH_BLOCK_MIB", "256")))
     ap.add_argument("--kind", default="text", choices=["text", "random"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -48,7 +48,27 @@ def parse():
     return ap.parse_args()
 
 
-def gen_text_device(torch, nbytes, seed, device):
+T_START = time.perf_counter()
+
+
+def progress(msg):
+    """Milestones on stderr (stdout carries only the JSON line)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.perf_counter() - T_START:8.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def gen_text_device(torch, nbytes, seed, device, piece=32 << 20):
+    """`nbytes` of synthetic text, generated in pieces of at most 32 MiB (bounded temporaries), each piece its own seed."""
+    parts = []
+    done = 0
+    while done < nbytes:
+        m = min(piece, nbytes - done)
+        parts.append(gen_text_piece(torch, m, seed * 1000 + len(parts), device))
+        done += m
+    return parts[0] if len(parts) == 1 else torch.cat(parts)
+
+
+def gen_text_piece(torch, nbytes, seed, device):
     """Word-bigram Markov text over shakespeare.txt tokens (tests/datagen.py), generated on the GPU:
     `chains` independent chains advance in lockstep; their words are laid out chain after chain."""
     import datagen
@@ -172,11 +192,15 @@ def main():
         bufs.append(buf)
         sums.append(int(buf[:block_size].to(torch.int64).sum().item()))
     probe = bufs[0][: 1 << 16].clone()
+    del base
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()  # hand the generator's temporaries back: the codec workspace is hipMalloc'ed outside torch
     t_gen = time.perf_counter() - t_gen
+    progress(f"{nblk} x {block_size} B input blocks resident in HBM ({t_gen:.1f}s)")
 
     states = (C.c_void_p * nblk)(*[lib.bz3_new(block_size) for _ in range(nblk)])
     assert all(states), "bz3_new failed"
+    progress("states created")
     ptrs = (C.c_void_p * nblk)(*[b.data_ptr() for b in bufs])
     bsz = (C.c_size_t * nblk)(*[cap] * nblk)
     orig = (C.c_int32 * nblk)(*[block_size] * nblk)
@@ -195,6 +219,7 @@ def main():
         t0 = time.perf_counter()
         lib.bz3_hip_encode_blocks_device(states, ptrs, sizes, nblk)
         t1 = time.perf_counter()
+        progress(f"encode_blocks done in {t1 - t0:.1f}s")
         for i in range(nblk):
             assert sizes[i] > 0 and lib.bz3_last_error(states[i]) == 0, f"encode failed on block {i}"
         if record:
@@ -208,6 +233,7 @@ def main():
         t2 = time.perf_counter()
         lib.bz3_hip_decode_blocks_device(states, ptrs, bsz, sizes, orig, nblk)
         t3 = time.perf_counter()
+        progress(f"decode_blocks done in {t3 - t2:.1f}s")
         for i in range(nblk):
             assert lib.bz3_last_error(states[i]) == 0, f"decode failed on block {i}"
         if record:

@@ -4,9 +4,10 @@
 // bz3_decode_block (:656-809) are ping-pong pipelines over the caller's buffer and the state's swap
 // buffer; every size/flag decision and every error code is reproduced.  What changes is WHERE things
 // live: both buffers are in HBM, the stages are the kernels of crc32c/mrle/lzp/bwt/unbwt/cm.hip, the
-// suffix-sort workspace is one arena per GPU shared by all states, and each state owns a HIP stream so
-// that the long single-CU CM kernels of many blocks overlap with the whole-GPU stages of the next
-// block (bz3_encode_blocks / bz3_decode_blocks, :845-870, without pthreads).
+// suffix-sort workspace is one arena per GPU shared by all states, and a batch call
+// (bz3_encode_blocks / bz3_decode_blocks, :845-870, without pthreads) runs in phases on ONE stream per GPU:
+// the whole-GPU stages block after block, the serial stages (LZP driver, LZP decoder, CM coder) as ONE
+// launch with one workgroup per block, so up to 256 blocks share the GPU's 256 CUs.
 //
 // There is no CPU implementation of any stage in this library: without a usable HIP device
 // bz3_new() returns NULL and the stage hooks abort loudly.
@@ -157,7 +158,8 @@ struct bz3_state {
     s8 last_error = BZ3_OK;
     int device = 0;
     DeviceCtx * ctx = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // owned
+    hipStream_t xs = nullptr;      // execution stream of the current call: the lead state's stream of its device group
     u8 * d_swap = nullptr;  // the reference's swap_buffer, in HBM
     u8 * d_io = nullptr;    // staging for the host-buffer API (lazy)
     size_t cap = 0;         // bz3_bound(block_size) rounded up
@@ -230,7 +232,7 @@ void encode_front_a(bz3_state * st, u8 * buf, s32 data_size, Arena & arena, LzpE
         st->last_error = BZ3_ERR_DATA_TOO_BIG;
         return;
     }
-    hipStream_t s = st->stream;
+    hipStream_t s = st->xs;
     for (float & x : st->t) x = 0.f;
     double t0 = now_ms();
     crc32c_device(buf, (u64)data_size, 1u, st->ctx->d_crc, st->d_words, s);  // :593
@@ -277,7 +279,7 @@ void encode_front_a(bz3_state * st, u8 * buf, s32 data_size, Arena & arena, LzpE
 void encode_front_b(bz3_state * st, Arena & arena, const LzpEncodeCtx & c, float driver_ms) {
     if (st->pending != bz3_state::ENC_CODED) return;
     st->pending = bz3_state::FAILED;
-    hipStream_t s = st->stream;
+    hipStream_t s = st->xs;
     u8 *b1 = st->b1, *b2 = st->b2;
     u32 n = st->n_cm;
     double t0 = now_ms();
@@ -312,19 +314,19 @@ void encode_finish(bz3_state * st, float cm_ms) {
     const bz3_state::Pending p = st->pending;
     st->pending = bz3_state::NONE;
     if (p == bz3_state::FAILED || p == bz3_state::NONE) return;
-    HIP_CHECK(hipStreamSynchronize(st->stream));
+    HIP_CHECK(hipStreamSynchronize(st->xs));
     if (p == bz3_state::ENC_STORED) {
         st->result = st->size + 8;
         return;
     }
     st->t[BZ3_HIP_T_CM] = cm_ms;
-    const u32 coded = read_word(st->stream, st->d_words + 2);
+    const u32 coded = read_word(st->xs, st->d_words + 2);
     const s32 total = (s32)coded + st->overhead * 4 + 1;
     st->last_error = BZ3_OK;  // :649
     if (st->b1 != st->user) {  // :651
         double t0 = now_ms();
-        HIP_CHECK(hipMemcpyAsync(st->user, st->b1, (size_t)total, hipMemcpyDeviceToDevice, st->stream));
-        HIP_CHECK(hipStreamSynchronize(st->stream));
+        HIP_CHECK(hipMemcpyAsync(st->user, st->b1, (size_t)total, hipMemcpyDeviceToDevice, st->xs));
+        HIP_CHECK(hipStreamSynchronize(st->xs));
         st->t[BZ3_HIP_T_COPY] += (float)(now_ms() - t0);
     }
     st->result = total;
@@ -336,6 +338,10 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     bz3_state * lead = sts[0];
     DeviceGuard g(lead->device);
     std::lock_guard<std::mutex> lk(lead->ctx->mu);
+    // One execution stream per call: the whole-GPU phases of the blocks run one after the other anyway, and stream
+    // order is what protects the arena's scratch regions, which consecutive blocks reuse while earlier kernels are
+    // still in flight.
+    for (s32 i = 0; i < n; i++) sts[i]->xs = lead->stream;
     size_t need = 0;
     for (s32 i = 0; i < n; i++) {
         const size_t w = workspace_bytes_for((u64)(sizes[i] > 0 ? sizes[i] : 0) + 64);
@@ -365,8 +371,7 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         }
         float driver_ms = 0.f;
         if (!lz.empty()) {
-            // every prepare above ran on its own state's stream and those streams are idle again only after a sync
-            for (s32 i = w0; i < w1; i++) HIP_CHECK(hipStreamSynchronize(sts[i]->stream));
+            HIP_CHECK(hipStreamSynchronize(lead->stream));  // the prepares above are in flight on the group's stream
             const double t0 = now_ms();
             LzpDriverJob * d_lz = arena.take<LzpDriverJob>(lz.size());
             lzp_driver_batch(lz.data(), d_lz, (u32)lz.size(), lead->stream);
@@ -412,7 +417,7 @@ void decode_front(bz3_state * st, u8 * buf, size_t buffer_size, s32 compressed_s
         st->last_error = BZ3_ERR_MALFORMED_HEADER;
         return;
     }
-    hipStream_t s = st->stream;
+    hipStream_t s = st->xs;
     for (float & x : st->t) x = 0.f;
     st->user = buf;
     st->buffer_size = buffer_size;
@@ -470,7 +475,7 @@ void decode_front(bz3_state * st, u8 * buf, size_t buffer_size, s32 compressed_s
 // After the CM kernel: index checks and inverse BWT.  Leaves the data in st->b1, the free buffer in st->b2.
 // Returns false when the block failed.
 bool decode_unbwt(bz3_state * st, Arena & arena, float cm_ms) {
-    hipStream_t s = st->stream;
+    hipStream_t s = st->xs;
     st->t[BZ3_HIP_T_CM] = cm_ms;
     const s32 n = st->size_before_bwt;
     if (st->bwt_idx > n) {  // :750-753
@@ -496,7 +501,7 @@ bool decode_unbwt(bz3_state * st, Arena & arena, float cm_ms) {
 
 // After the LZP kernel (if any): mRLE decode, size checks, copy back, CRC.
 void decode_finish(bz3_state * st, Arena & arena) {
-    hipStream_t s = st->stream;
+    hipStream_t s = st->xs;
     const size_t bound = bz3_bound((size_t)st->block_size);
     (void)bound;
     u8 *b1 = st->b1, *b2 = st->b2;
@@ -548,6 +553,7 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     DeviceGuard g(lead->device);
     std::lock_guard<std::mutex> lk(lead->ctx->mu);
     hipStream_t s = lead->stream;
+    for (s32 i = 0; i < n; i++) sts[i]->xs = s;  // see encode_group
     size_t need = 0;
     for (s32 i = 0; i < n; i++) {
         const size_t w = workspace_bytes_for(bz3_bound((size_t)sts[i]->block_size) + 64);
@@ -582,8 +588,8 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     for (s32 i = 0; i < n; i++) {
         bz3_state * st = sts[i];
         if (st->pending == bz3_state::DEC_STORED) {  // :686-691
-            HIP_CHECK(hipStreamSynchronize(st->stream));
-            if (read_word(st->stream, st->d_words + 1) != st->crc) st->last_error = BZ3_ERR_CRC;
+            HIP_CHECK(hipStreamSynchronize(st->xs));
+            if (read_word(st->xs, st->d_words + 1) != st->crc) st->last_error = BZ3_ERR_CRC;
             else st->result = st->size;  // last_error untouched (:691)
             continue;
         }
@@ -730,6 +736,7 @@ BZIP3_API struct bz3_state * bz3_new(int32_t block_size) {
         st->ctx = ctx;
         HIP_CHECK(hipSetDevice(dev));
         HIP_CHECK(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
+        st->xs = st->stream;
         HIP_CHECK(hipEventCreate(&st->ev0));
         HIP_CHECK(hipEventCreate(&st->ev1));
         st->cap = (bz3_bound((size_t)block_size) + 4096 + 255) & ~(size_t)255;
