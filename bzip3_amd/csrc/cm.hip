@@ -354,34 +354,51 @@ __global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// decode: five waves.  Waves 1..4 hold one tree node per lane (node = thread - 64): before every byte
-// they evaluate all 255 probabilities into an LDS table; wave 0 loads the table into registers (4 per
-// lane), makes the 8 serial decisions with v_readlane + scalar arithmetic, and publishes the byte; the
-// 8 lanes whose node lies on the decoded path then update their counters.
+// decode: four waves, one tree node per lane (node = thread), ONE barrier per byte.
+//
+//  model   : before every byte each lane evaluates its node's 18-bit probability (the 255 nodes of the next
+//            byte depend only on state that is fixed once the previous byte is known) and leaves it, pre-shifted
+//            by 14 so that ((range * P) >> 18) is a single v_mul_hi_u32, in an LDS table (double-buffered).
+//  walk    : every wave then decodes the byte by itself -- redundantly, so nobody has to be told the result.
+//            The 8 serial decisions are SPECULATED across lanes: lane l assumes that the first six bits of the
+//            byte are l and runs the (low, range) recurrence along that path without waiting for any
+//            comparison; the comparisons only clear bits of a wave-wide `valid` mask (scalar unit).  After six
+//            levels exactly one lane is left; every lane then decodes its last two bits for real.  Per level
+//            the dependent chain is v_mul_hi_u32 + one add instead of a compare/select/readlane round trip.
+//            Renormalisation (:470-474) is needed on the surviving path only about once per 50 bits; it is
+//            done out of line on the scalar unit, from the state of a valid lane.
+//  update  : the 8 lanes whose node lies on the decoded path update their counters.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restrict__ jobs) {
+__global__ void __launch_bounds__(256) k_cm_decode(const CmDecodeJob * __restrict__ jobs) {
     const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 in_size = jobs[blockIdx.x].in_size;
     u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
     const u32 n = jobs[blockIdx.x].n;
     const u32 debug = jobs[blockIdx.x].debug;
     __shared__ CmLds m;
-    __shared__ u32 ptab[256];
-    __shared__ u32 s_byte;
+    __shared__ u32 ptab[2][256];  // (18-bit probability of node) << 14
     cm_model_init(m);
-    if (debug && threadIdx.x < 256) ptab[threadIdx.x] = 1u << 17;  // profiling modes: defined probabilities
-    if (debug && threadIdx.x == 0) s_byte = 'e';
+    if (debug == 1) {  // profiling mode "walk only": defined probabilities
+        ptab[0][threadIdx.x] = 1u << 31;
+        ptab[1][threadIdx.x] = 1u << 31;
+    }
     __syncthreads();
     const int lane = lane_id();
-    const bool coder = cm_uniform((u32)wave_id()) == 0;
-    // model lanes: one tree node each; the node's C0 counter lives in a register
-    const u32 node = threadIdx.x - 64u;
-    const u32 lvl = (!coder && node) ? (u32)(31 - __clz((int)node)) : 0u;
+    const bool writer = cm_uniform((u32)wave_id()) == 0;
+    // model side: one tree node per lane; the node's C0 counter lives in a register
+    const u32 node = threadIdx.x;
+    const u32 lvl = node ? (u32)(31 - __clz((int)node)) : 0u;
     const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
     u32 c0 = 32768u, q_p1 = 0, q_w = 0, q_a1 = 0, q_ci = 0;
-    u32 low = 0, range = 0xFFFFFFFFu, code = 0, c1 = 0, c2 = 0, run = 0;
+    // walk side: lane l assumes bits b0..b5 = l; nbK = all-ones where the assumed bit of level K is 0
+    const u32 ul = (u32)lane;
+    const u32 nb0 = ((ul >> 5) & 1u) - 1u, nb1 = ((ul >> 4) & 1u) - 1u, nb2 = ((ul >> 3) & 1u) - 1u;
+    const u32 nb3 = ((ul >> 2) & 1u) - 1u, nb4 = ((ul >> 1) & 1u) - 1u, nb5 = (ul & 1u) - 1u;
+    const u32 ix0 = 1u, ix1 = 2u | (ul >> 5), ix2 = 4u | (ul >> 4), ix3 = 8u | (ul >> 3), ix4 = 16u | (ul >> 2), ix5 = 32u | (ul >> 1);
+    const u32 ix6 = 64u | ul, ix7 = 128u | (ul << 1);
+    u32 low_u = 0, range_u = 0xFFFFFFFFu, code = 0, c1 = 0, c2 = 0, run = 0;
     u32 ip = 0, ibase = 0;
-    u32 window = (coder && ibase + lane < in_size) ? in[ibase + lane] : 0xFFFFFFFFu;
+    u32 window = (ibase + lane < in_size) ? in[ibase + lane] : 0xFFFFFFFFu;
 #define CM_NEXT_BYTE(dst)                                                              \
     do {                                                                               \
         if (ip - ibase >= 64u) {                                                       \
@@ -391,18 +408,60 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
         dst = cm_readlane(window, (int)(ip - ibase));                                  \
         ip++;                                                                          \
     } while (0)
-    if (coder) {
-        for (int j = 0; j < 4; j++) {  // :438-441; bytes past the end read as -1 (:345)
-            u32 b;
-            CM_NEXT_BYTE(b);
-            code = (code << 8) + b;
-        }
+    for (int j = 0; j < 4; j++) {  // :438-441; bytes past the end read as -1 (:345)
+        u32 b;
+        CM_NEXT_BYTE(b);
+        code = (code << 8) + b;
     }
+// Renormalisation of the surviving path (:470-474).  All valid lanes carry the same (low, range): take them from one
+// of those lanes, shift on the scalar unit, and hand the result to every lane (the others are dead anyway).
+#define CM_RENORM()                                                                                   \
+    do {                                                                                              \
+        const u64 need_ = valid & __ballot(range < (1u << 24));                                       \
+        if (__builtin_expect(need_ != 0, 0)) {                                                        \
+            const int w_ = __ffsll((unsigned long long)need_) - 1;                                    \
+            u32 l_ = cm_readlane(low, w_), r_ = cm_readlane(range, w_);                               \
+            while ((l_ ^ (l_ + r_)) < (1u << 24)) {                                                   \
+                l_ <<= 8;                                                                             \
+                r_ = (r_ << 8) | 0xFFu;                                                               \
+                u32 b_;                                                                               \
+                CM_NEXT_BYTE(b_);                                                                     \
+                code = (code << 8) + b_;                                                              \
+            }                                                                                         \
+            low = l_;                                                                                 \
+            range = r_;                                                                               \
+        }                                                                                             \
+    } while (0)
+// One speculated level: the lane assumes its bit (NB = all-ones when that bit is 0); CK = lanes assuming a 1.
+#define CM_SPEC_LEVEL(P, NB, CK)                                                                      \
+    do {                                                                                              \
+        const u32 t_ = (u32)(((u64)range * (P)) >> 32);            /* (range * p18) >> 18, :464 */    \
+        const u32 mid_ = low + t_;                                                                    \
+        /* NB: compare absolute values: a truncated stream feeds -1 bytes (:345) and can push `code` */ \
+        /* below `low`, where the reference still decodes a 1.                                       */ \
+        const u64 vote_ = __ballot(code <= mid_);                                                     \
+        valid &= ~(vote_ ^ (CK));                                                                     \
+        const u32 x_ = t_ ^ (NB);                                  /* bit 1: t; bit 0: ~t */          \
+        range = x_ + (range & (NB));                               /* t  |  range - t - 1 */          \
+        low -= x_ & (NB);                                          /* low |  mid + 1      */          \
+        CM_RENORM();                                                                                  \
+    } while (0)
+// One decoded level (the lane takes the bit it decodes).
+#define CM_REAL_LEVEL(P, BIT)                                                                         \
+    do {                                                                                              \
+        const u32 t_ = (u32)(((u64)range * (P)) >> 32);                                               \
+        const u32 mid_ = low + t_;                                                                    \
+        BIT = code <= mid_;                                                                           \
+        range = BIT ? t_ : range - t_ - 1u;                                                           \
+        low = BIT ? low : mid_ + 1u;                                                                  \
+        CM_RENORM();                                                                                  \
+    } while (0)
     u32 staged = 0;
     for (u32 i = 0; i < n; i++) {
         run = (c1 == c2) ? run + 1 : 0;
         const u32 f = run > 2 ? 1u : 0u;
-        if (!coder && debug != 1) {
+        u32 * __restrict__ pt = ptab[i & 1u];
+        if (debug != 1) {
             // probabilities of all 255 nodes for this byte (:377-388); node 0 computes a dummy
             q_a1 = c1 * 256u + node;
             q_p1 = m.c1[q_a1];
@@ -412,59 +471,40 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
             q_w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[q_ci]));  // x1 | x2 << 16
             const int x1 = (int)(q_w & 0xFFFFu), x2 = (int)(q_w >> 16);
             const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);
-            ptab[node] = (u32)(ssep * 3 + p);
+            pt[node] = (u32)(ssep * 3 + p) << 14;
         }
         __syncthreads();
-        if (coder && debug != 2) {
-            const u32 p0 = ptab[lane], p1 = ptab[lane + 64], p2 = ptab[lane + 128], p3 = ptab[lane + 192];
-            u32 ctx = 1;
-#pragma unroll
-            for (int lvl_i = 0; lvl_i < 8; lvl_i++) {  // :453-489
-                u32 p18;
-                const int src = (int)(ctx & 63u);
-                if (lvl_i < 6) p18 = cm_readlane(p0, src);
-                else if (lvl_i == 6) p18 = cm_readlane(p1, src);
-                else {
-                    const u32 a = cm_readlane(p2, src), b = cm_readlane(p3, src);
-                    p18 = (ctx & 64u) ? b : a;
-                }
-                const u32 mid = low + (u32)(((u64)range * p18) >> 18);  // :464 (high == low + range)
-                // NB: the comparison must be on absolute values: a truncated stream feeds -1 bytes (:345) and
-                // can push `code` below `low`, where the reference still decodes a 1.
-                const bool bit = code <= mid;
-#ifdef BZ3_EMU
-                ctx = ctx * 2 + (bit ? 1u : 0u);
-#else
-                // ctx = 2*ctx + bit on the scalar unit (keeps the node index out of vector registers)
-                asm volatile("s_cmp_le_u32 %1, %2\n\ts_addc_u32 %0, %0, %0" : "+s"(ctx) : "s"(code), "s"(mid) : "scc");
-#endif
-                if (bit) {
-                    range = mid - low;
-                } else {
-                    range -= mid - low + 1;
-                    low = mid + 1;
-                }
-                if (__builtin_expect(range < (1u << 24), 0)) {  // out of line: the common case falls through
-                    while ((low ^ (low + range)) < (1u << 24)) {  // :470-474
-                        low <<= 8;
-                        range = (range << 8) | 0xFFu;
-                        u32 b;
-                        CM_NEXT_BYTE(b);
-                        code = (code << 8) + b;
-                    }
-                }
-            }
-            const u32 c = ctx & 255u;
-            if (lane == 0) s_byte = c;
+        u32 c;
+        if (debug != 2) {
+            const u32 P0 = pt[ix0], P1 = pt[ix1], P2 = pt[ix2], P3 = pt[ix3], P4 = pt[ix4], P5 = pt[ix5], P6 = pt[ix6];
+            const u32 P7a = pt[ix7], P7b = pt[ix7 + 1u];
+            u32 low = low_u, range = range_u;  // per-lane copies of the wave-uniform coder state
+            u64 valid = ~0ull;
+            CM_SPEC_LEVEL(P0, nb0, 0xFFFFFFFF00000000ull);  // :453-489
+            CM_SPEC_LEVEL(P1, nb1, 0xFFFF0000FFFF0000ull);
+            CM_SPEC_LEVEL(P2, nb2, 0xFF00FF00FF00FF00ull);
+            CM_SPEC_LEVEL(P3, nb3, 0xF0F0F0F0F0F0F0F0ull);
+            CM_SPEC_LEVEL(P4, nb4, 0xCCCCCCCCCCCCCCCCull);
+            CM_SPEC_LEVEL(P5, nb5, 0xAAAAAAAAAAAAAAAAull);
+            bool bit6, bit7;
+            CM_REAL_LEVEL(P6, bit6);
+            const u32 P7 = bit6 ? P7b : P7a;
+            CM_REAL_LEVEL(P7, bit7);
+            const int w = __ffsll((unsigned long long)valid) - 1;  // exactly one lane survives
+            low_u = cm_readlane(low, w);
+            range_u = cm_readlane(range, w);
+            c = cm_readlane((ul << 2) | ((u32)bit6 << 1) | (u32)bit7, w);
+        } else {
+            c = 'e';
+        }
+        if (writer) {
             if ((u32)lane == (i & 63u)) staged = c;
             if ((i & 63u) == 63u || i + 1 == n) {
                 const u32 first = i & ~63u;
                 if (first + lane <= i) out[first + lane] = (u8)staged;
             }
         }
-        __syncthreads();
-        const u32 c = cm_uniform(s_byte);
-        if (!coder && debug != 1) {
+        if (debug != 1) {
             // the 8 lanes whose node is on the decoded path update their counters (branch-free, see cm_upd)
             if ((hibit | (c >> shr)) == node) {
                 const u32 mk = 0u - ((c >> bitpos) & 1u);
@@ -477,6 +517,9 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
         c1 = c;
     }
 #undef CM_NEXT_BYTE
+#undef CM_RENORM
+#undef CM_SPEC_LEVEL
+#undef CM_REAL_LEVEL
 }
 
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s) {
@@ -484,7 +527,7 @@ void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s) {
 }
 
 void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s) {
-    if (njobs) launch(k_cm_decode, dim3(njobs), dim3(320), 0, s, d_jobs);
+    if (njobs) launch(k_cm_decode, dim3(njobs), dim3(256), 0, s, d_jobs);
 }
 
 }  // namespace bz3
