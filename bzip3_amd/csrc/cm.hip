@@ -362,13 +362,51 @@ __global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restric
 //  walk    : every wave then decodes the byte by itself -- redundantly, so nobody has to be told the result.
 //            The 8 serial decisions are SPECULATED across lanes: lane l assumes that the first six bits of the
 //            byte are l and runs the (low, range) recurrence along that path without waiting for any
-//            comparison; the comparisons only clear bits of a wave-wide `valid` mask (scalar unit).  After six
-//            levels exactly one lane is left; every lane then decodes its last two bits for real.  Per level
-//            the dependent chain is v_mul_hi_u32 + one add instead of a compare/select/readlane round trip.
-//            Renormalisation (:470-474) is needed on the surviving path only about once per 50 bits; it is
-//            done out of line on the scalar unit, from the state of a valid lane.
+//            comparison; the comparisons are only shifted into a per-lane accumulator.  The lane whose
+//            accumulator spells its own number took no wrong turn (induction over the levels: its first
+//            comparison used the true state), so it holds the true coder state; every lane decodes its last two
+//            bits for real.  Per level the dependent chain is v_mul_hi_u32 + v_xad_u32, with no branch.
+//            Renormalisation (:470-474) is needed on the true path only about once per 50 bits: the fast walk
+//            just tracks the smallest range it saw, and if the surviving lane ever went below 2^24 the byte is
+//            decoded again by the checked walk, which renormalises on the scalar unit after every level.
 //  update  : the 8 lanes whose node lies on the decoded path update their counters.
 // ------------------------------------------------------------------------------------------------
+template <u32 V>
+struct CmConst {
+    static constexpr u32 value = V;
+};
+
+// (a ^ b) + c in one instruction
+__device__ __forceinline__ u32 cm_xad(u32 a, u32 b, u32 c) {
+#ifdef BZ3_EMU
+    return (a ^ b) + c;
+#else
+    u32 r;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#endif
+}
+// acc = 2 * acc + bit, the bit given as a wave-wide vote mask (v_addc_co_u32 with the mask as carry-in)
+__device__ __forceinline__ u32 cm_shift_in(u32 acc, u64 vote, bool bit) {
+#ifdef BZ3_EMU
+    (void)vote;
+    return acc + acc + (bit ? 1u : 0u);
+#else
+    (void)bit;
+    u64 carry_out;
+    asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(acc), "=s"(carry_out) : "s"(vote));
+    return acc;
+#endif
+}
+
+__device__ __forceinline__ u64 cm_clock() {
+#ifdef BZ3_EMU
+    return 0;
+#else
+    return (u64)__builtin_readcyclecounter();
+#endif
+}
+
 __global__ void __launch_bounds__(256) k_cm_decode(const CmDecodeJob * __restrict__ jobs) {
     const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 in_size = jobs[blockIdx.x].in_size;
@@ -384,7 +422,7 @@ __global__ void __launch_bounds__(256) k_cm_decode(const CmDecodeJob * __restric
     }
     __syncthreads();
     const int lane = lane_id();
-    const bool writer = cm_uniform((u32)wave_id()) == 0;
+    const bool writer = cm_uniform((u32)wave_id()) == 3;
     // model side: one tree node per lane; the node's C0 counter lives in a register
     const u32 node = threadIdx.x;
     const u32 lvl = node ? (u32)(31 - __clz((int)node)) : 0u;
@@ -392,8 +430,8 @@ __global__ void __launch_bounds__(256) k_cm_decode(const CmDecodeJob * __restric
     u32 c0 = 32768u, q_p1 = 0, q_w = 0, q_a1 = 0, q_ci = 0;
     // walk side: lane l assumes bits b0..b5 = l; nbK = all-ones where the assumed bit of level K is 0
     const u32 ul = (u32)lane;
-    const u32 nb0 = ((ul >> 5) & 1u) - 1u, nb1 = ((ul >> 4) & 1u) - 1u, nb2 = ((ul >> 3) & 1u) - 1u;
-    const u32 nb3 = ((ul >> 2) & 1u) - 1u, nb4 = ((ul >> 1) & 1u) - 1u, nb5 = (ul & 1u) - 1u;
+    const bool as0 = (ul >> 5) & 1u, as1 = (ul >> 4) & 1u, as2 = (ul >> 3) & 1u, as3 = (ul >> 2) & 1u, as4 = (ul >> 1) & 1u, as5 = ul & 1u;
+    const u32 nb0 = (u32)as0 - 1u, nb1 = (u32)as1 - 1u, nb2 = (u32)as2 - 1u, nb3 = (u32)as3 - 1u, nb4 = (u32)as4 - 1u, nb5 = (u32)as5 - 1u;
     const u32 ix0 = 1u, ix1 = 2u | (ul >> 5), ix2 = 4u | (ul >> 4), ix3 = 8u | (ul >> 3), ix4 = 16u | (ul >> 2), ix5 = 32u | (ul >> 1);
     const u32 ix6 = 64u | ul, ix7 = 128u | (ul << 1);
     u32 low_u = 0, range_u = 0xFFFFFFFFu, code = 0, c1 = 0, c2 = 0, run = 0;
@@ -413,6 +451,7 @@ __global__ void __launch_bounds__(256) k_cm_decode(const CmDecodeJob * __restric
         CM_NEXT_BYTE(b);
         code = (code << 8) + b;
     }
+// ---- checked walk (slow path) -------------------------------------------------------------------------------
 // Renormalisation of the surviving path (:470-474).  All valid lanes carry the same (low, range): take them from one
 // of those lanes, shift on the scalar unit, and hand the result to every lane (the others are dead anyway).
 #define CM_RENORM()                                                                                   \
@@ -456,11 +495,41 @@ __global__ void __launch_bounds__(256) k_cm_decode(const CmDecodeJob * __restric
         low = BIT ? low : mid_ + 1u;                                                                  \
         CM_RENORM();                                                                                  \
     } while (0)
+// ---- fast walk: no branches, no renormalisation ------------------------------------------------------------------
+// Works on d = code - low instead of low (the comparison becomes d <= t; equivalent as long as code >= low, which is
+// checked per byte: a truncated stream feeds -1 bytes (:345) and can push `code` below `low`).  Every lane shifts
+// the outcome of its comparisons into `acc`; the lane whose `acc` spells its own number took no wrong turn
+// (induction over the levels: its first comparison used the true state), so it holds the true coder state.
+// Intervals are nested while nothing is renormalised, so "a renormalisation was due at some level" is equivalent to
+// "the final interval lies within one 2^24 bucket": one scalar test on the surviving lane's final state.
+#define CM_FAST_SPEC(P, NB, AS)                                                                       \
+    do {                                                                                              \
+        const u32 keep_ = range & (NB);                                                               \
+        const u32 t_ = (u32)(((u64)range * (P)) >> 32);            /* (range * p18) >> 18, :464 */    \
+        const bool bit_ = d <= t_;                                                                    \
+        acc = cm_shift_in(acc, __ballot(bit_), bit_);                                                 \
+        range = cm_xad(t_, (NB), keep_);                           /* t  |  range - t - 1 */          \
+        const u32 d0_ = d + ~t_;                                                                      \
+        d = (AS) ? d : d0_;                                        /* d  |  d - t - 1     */          \
+    } while (0)
+#define CM_FAST_REAL(P, BIT)                                                                          \
+    do {                                                                                              \
+        const u32 t_ = (u32)(((u64)range * (P)) >> 32);                                               \
+        BIT = d <= t_;                                                                                \
+        cbits = cm_shift_in(cbits, __ballot(BIT), BIT);                                               \
+        range = BIT ? t_ : range + ~t_;                                                               \
+        d = BIT ? d : d + ~t_;                                                                        \
+    } while (0)
     u32 staged = 0;
-    for (u32 i = 0; i < n; i++) {
+    u64 prof_model = 0, prof_barrier = 0, prof_walk = 0, prof_update = 0, prof_slow = 0;  // debug == 3: cycles per phase
+    // One byte.  BUF (compile time) is the half of the double-buffered probability table this byte uses.
+    auto decode_byte = [&](const u32 i, auto buf_tag) __attribute__((always_inline)) {
+        constexpr u32 BUF = decltype(buf_tag)::value;
+        u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if (debug == 3) t0 = cm_clock();
         run = (c1 == c2) ? run + 1 : 0;
         const u32 f = run > 2 ? 1u : 0u;
-        u32 * __restrict__ pt = ptab[i & 1u];
+        u32 * __restrict__ pt = ptab[BUF];
         if (debug != 1) {
             // probabilities of all 255 nodes for this byte (:377-388); node 0 computes a dummy
             q_a1 = c1 * 256u + node;
@@ -473,31 +542,59 @@ __global__ void __launch_bounds__(256) k_cm_decode(const CmDecodeJob * __restric
             const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);
             pt[node] = (u32)(ssep * 3 + p) << 14;
         }
+        if (debug == 3) t1 = cm_clock();
         __syncthreads();
+        if (debug == 3) t2 = cm_clock();
         u32 c;
         if (debug != 2) {
             const u32 P0 = pt[ix0], P1 = pt[ix1], P2 = pt[ix2], P3 = pt[ix3], P4 = pt[ix4], P5 = pt[ix5], P6 = pt[ix6];
             const u32 P7a = pt[ix7], P7b = pt[ix7 + 1u];
-            u32 low = low_u, range = range_u;  // per-lane copies of the wave-uniform coder state
-            u64 valid = ~0ull;
-            CM_SPEC_LEVEL(P0, nb0, 0xFFFFFFFF00000000ull);  // :453-489
-            CM_SPEC_LEVEL(P1, nb1, 0xFFFF0000FFFF0000ull);
-            CM_SPEC_LEVEL(P2, nb2, 0xFF00FF00FF00FF00ull);
-            CM_SPEC_LEVEL(P3, nb3, 0xF0F0F0F0F0F0F0F0ull);
-            CM_SPEC_LEVEL(P4, nb4, 0xCCCCCCCCCCCCCCCCull);
-            CM_SPEC_LEVEL(P5, nb5, 0xAAAAAAAAAAAAAAAAull);
+            u32 range = range_u, low;  // per-lane copies of the wave-uniform coder state
+            u32 d = code - low_u;
+            const bool inside = code >= low_u;  // always, unless a truncated stream fed -1 bytes (:345)
+            u32 acc = 0;
             bool bit6, bit7;
-            CM_REAL_LEVEL(P6, bit6);
-            const u32 P7 = bit6 ? P7b : P7a;
-            CM_REAL_LEVEL(P7, bit7);
-            const int w = __ffsll((unsigned long long)valid) - 1;  // exactly one lane survives
-            low_u = cm_readlane(low, w);
-            range_u = cm_readlane(range, w);
-            c = cm_readlane((ul << 2) | ((u32)bit6 << 1) | (u32)bit7, w);
+            CM_FAST_SPEC(P0, nb0, as0);  // :453-489
+            CM_FAST_SPEC(P1, nb1, as1);
+            CM_FAST_SPEC(P2, nb2, as2);
+            CM_FAST_SPEC(P3, nb3, as3);
+            CM_FAST_SPEC(P4, nb4, as4);
+            CM_FAST_SPEC(P5, nb5, as5);
+            const u64 ok = __ballot(acc == ul);  // exactly one lane decoded the six bits it had assumed
+            u32 cbits = acc;
+            CM_FAST_REAL(P6, bit6);
+            const u32 P7f = bit6 ? P7b : P7a;
+            CM_FAST_REAL(P7f, bit7);
+            const int w = __ffsll((unsigned long long)ok) - 1;
+            const u32 low_f = code - cm_readlane(d, w), range_f = cm_readlane(range, w);
+            if (__builtin_expect(inside && (low_f ^ (low_f + range_f)) >= (1u << 24), 1)) {
+                low_u = low_f;
+                range_u = range_f;
+                c = cm_readlane(cbits, w);
+            } else {  // a renormalisation was due on the true path: decode this byte again, checking every level
+                prof_slow++;
+                low = low_u;
+                range = range_u;
+                u64 valid = ~0ull;
+                CM_SPEC_LEVEL(P0, nb0, 0xFFFFFFFF00000000ull);
+                CM_SPEC_LEVEL(P1, nb1, 0xFFFF0000FFFF0000ull);
+                CM_SPEC_LEVEL(P2, nb2, 0xFF00FF00FF00FF00ull);
+                CM_SPEC_LEVEL(P3, nb3, 0xF0F0F0F0F0F0F0F0ull);
+                CM_SPEC_LEVEL(P4, nb4, 0xCCCCCCCCCCCCCCCCull);
+                CM_SPEC_LEVEL(P5, nb5, 0xAAAAAAAAAAAAAAAAull);
+                CM_REAL_LEVEL(P6, bit6);
+                const u32 P7 = bit6 ? P7b : P7a;
+                CM_REAL_LEVEL(P7, bit7);
+                const int w2 = __ffsll((unsigned long long)valid) - 1;  // exactly one lane survives
+                low_u = cm_readlane(low, w2);
+                range_u = cm_readlane(range, w2);
+                c = cm_readlane((ul << 2) | ((u32)bit6 << 1) | (u32)bit7, w2);
+            }
         } else {
             c = 'e';
         }
-        if (writer) {
+        if (debug == 3) t3 = cm_clock();
+        if (writer) {  // wave 3: it has the least model work
             if ((u32)lane == (i & 63u)) staged = c;
             if ((i & 63u) == 63u || i + 1 == n) {
                 const u32 first = i & ~63u;
@@ -515,11 +612,34 @@ __global__ void __launch_bounds__(256) k_cm_decode(const CmDecodeJob * __restric
         }
         c2 = c1;
         c1 = c;
+        if (debug == 3) {
+            const u64 t4 = cm_clock();
+            prof_model += t1 - t0;
+            prof_barrier += t2 - t1;
+            prof_walk += t3 - t2;
+            prof_update += t4 - t3;
+        }
+    };
+    u32 i = 0;
+    for (; i + 1 < n; i += 2) {
+        decode_byte(i, CmConst<0>{});
+        decode_byte(i + 1, CmConst<1>{});
+    }
+    if (i < n) decode_byte(i, CmConst<0>{});
+    if (debug == 3 && n >= 64 && threadIdx.x == 0) {  // profiling only: the first 40 output bytes become the counters
+        u64 * o = reinterpret_cast<u64 *>(out);
+        o[0] = prof_model;
+        o[1] = prof_barrier;
+        o[2] = prof_walk;
+        o[3] = prof_update;
+        o[4] = prof_slow;
     }
 #undef CM_NEXT_BYTE
 #undef CM_RENORM
 #undef CM_SPEC_LEVEL
 #undef CM_REAL_LEVEL
+#undef CM_FAST_SPEC
+#undef CM_FAST_REAL
 }
 
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s) {

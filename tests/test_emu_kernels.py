@@ -6,6 +6,7 @@ import ctypes as C
 import os
 import sys
 
+import numpy as np
 import pytest
 
 import bzip3_amd
@@ -79,6 +80,18 @@ def test_cm_decode_of_truncated_stream_matches_reference_semantics(emu, oracle):
     for frac in (2, 3, 7):
         cc = c[: len(c) // frac]
         assert g.cm_decode(cc, len(u)) == oracle.cm_decode(cc, len(u))
+
+
+def test_cm_decode_of_arbitrary_bytes_matches_reference(emu, oracle):
+    # The decoder must mirror decode_bytes (src/libbz3.c:436-494) on ANY input: random bytes drive it through
+    # improbable symbols, long renormalisation runs and (after the end of the stream) the `code < low` states.
+    g = bzip3_amd.StageApi(emu)
+    rng = np.random.default_rng(11)
+    for size, n in ((0, 300), (3, 500), (400, 1500), (3000, 2500)):
+        junk = bytes(rng.integers(0, 256, size=size, dtype=np.uint8))
+        assert g.cm_decode(junk, n) == oracle.cm_decode(junk, n)
+    skew = bytes(rng.choice(np.array([0, 255, 1, 128], dtype=np.uint8), size=1500, p=[0.6, 0.3, 0.05, 0.05]))
+    assert g.cm_decode(skew, 4000) == oracle.cm_decode(skew, 4000)
 
 
 def test_decoder_error_codes(emu, oracle):

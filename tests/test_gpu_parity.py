@@ -5,6 +5,7 @@ import hashlib
 import os
 import struct
 
+import numpy as np
 import pytest
 
 import bzip3_amd
@@ -90,6 +91,18 @@ def test_cfg1_known_answer_on_gpu(gpu_lib, text):
         assert st.decode_block(blk, len(text)) == (len(text), 0, text)
         t = st.timings()
         assert t["cm"] > 0
+
+
+def test_cm_decode_of_arbitrary_bytes_matches_reference(gpu_lib, oracle):
+    # decode_bytes (src/libbz3.c:436-494) is defined on ANY input; random / skewed bytes exercise improbable symbols,
+    # renormalisation runs and the `code < low` states a stream that ends early produces.
+    g = bzip3_amd.StageApi(gpu_lib)
+    rng = np.random.default_rng(12)
+    for size, n in ((0, 1000), (5, 70000), (50000, 200000), (300000, 400000)):
+        junk = bytes(rng.integers(0, 256, size=size, dtype=np.uint8))
+        assert g.cm_decode(junk, n) == oracle.cm_decode(junk, n)
+    skew = bytes(rng.choice(np.array([0, 255, 1, 128], dtype=np.uint8), size=100000, p=[0.6, 0.3, 0.05, 0.05]))
+    assert g.cm_decode(skew, 500000) == oracle.cm_decode(skew, 500000)
 
 
 def test_decoder_error_codes(gpu_lib, oracle, text):

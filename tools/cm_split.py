@@ -15,6 +15,15 @@ for mode in ("0", "1", "2", "0"):
 
 os.environ["BZ3_CM_DEBUG"] = "0"
 enc = g.cm_encode(u)
+if "--decode-phases" in sys.argv:
+    import struct
+    os.environ["BZ3_CM_DEBUG"] = "3"
+    t = time.time(); out = g.cm_decode(enc, n); dt = time.time() - t
+    v = struct.unpack("<5Q", out[:40])
+    names = ("model", "barrier", "walk", "update")
+    print(f"decode phases (wave 0, cycle counter ticks per byte; instrumented run {dt/n*1e9:.0f} ns/B): "
+          + "  ".join(f"{k} {x / n:.1f}" for k, x in zip(names, v)) + f"  slow-path bytes {v[4] / n * 100:.1f}%", flush=True)
+    os.environ["BZ3_CM_DEBUG"] = "0"
 for mode in ("0", "1", "2", "0"):
     os.environ["BZ3_CM_DEBUG"] = mode
     t = time.time(); out = g.cm_decode(enc, n); dt = time.time() - t
