@@ -30,6 +30,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from a rocprofv3 --pmc pass (tools/rocpd_summary.py --pmc)
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 ALG_BYTES_ROUND_TRIP = 32.4  # 17.2 B/B encode + 15.2 B/B decode
 ALG_BYTES_BWT = 11.0
@@ -269,6 +270,15 @@ def main():
         cm_dec_ms = stage["dec"]["cm"]
         cm_bytes = n_dec + comp_total[0] / nblk  # CM decode kernel: reads the coded bytes, writes n' bytes
         bwt_ms = stage["enc"]["bwt"]
+        # HBM traffic of the dominant kernel from the PMC pass (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs,
+        # corrected as MI355X_MICROARCH.md prescribes), recorded per decoded byte and scaled to this launch.
+        traffic = None
+        try:
+            with open(PMC_TRAFFIC_FILE) as fh:
+                pm = json.load(fh)["k_cm_decode"]
+            traffic = int((pm["fetch_bytes_per_decoded_byte"] + pm["write_bytes_per_decoded_byte"]) * n_dec * nblk)
+        except Exception:
+            pass
         out = {
             "metric": "MiB/s encode+decode round-trip, 256 MiB blocks",
             "value": round(value, 3),
@@ -296,13 +306,13 @@ def main():
             "roofline": {
                 "kernel": "k_cm_decode",
                 "bound": "hbm",
-                "achieved": round(cm_bytes / (cm_dec_ms * 1e-3) / 1e9, 6),
+                "achieved": round(cm_bytes * nblk / (cm_dec_ms * 1e-3) / 1e9, 6),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
-                "frac": round(cm_bytes / (cm_dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 9),
-                "traffic": None,
+                "frac": round(cm_bytes * nblk / (cm_dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 9),
+                "traffic": traffic,
                 "launch_ms": cm_dec_ms,
-                "algorithmic_bytes_per_launch": int(cm_bytes),
+                "algorithmic_bytes_per_launch": int(cm_bytes * nblk),
             },
             "path_roofline": {
                 "achieved": round(ALG_BYTES_ROUND_TRIP * total_bytes * a.steps / elapsed / 1e9, 4),

@@ -869,42 +869,84 @@ BZIP3_API int32_t bz3_decode_block(struct bz3_state * st, uint8_t * buffer, size
     return st->result;
 }
 
-// ---- frame API (src/libbz3.c:876-997): thin loops over the block API, same header and error codes ----
+// ---- frame API (src/libbz3.c:876-997): same header, chunk layout and error codes.  The reference walks the
+// blocks of a frame one after the other on one state; here a WINDOW of blocks goes through bz3_encode_blocks /
+// bz3_decode_blocks at once (one state per block, blocks spread over the visible GPUs, one CM launch per GPU), because
+// the serial CM stage only pays off with many blocks in flight.  Blocks are still committed in order, so the first
+// failing block decides the return value exactly as in the sequential loop.
+namespace {
+
+struct FrameWindow {
+    std::vector<bz3_state *> states;
+    std::vector<u8 *> bufs;
+    size_t cap = 0;
+    ~FrameWindow() {
+        for (bz3_state * s : states) bz3_free(s);
+        for (u8 * b : bufs) free(b);
+    }
+    // Up to `want` states + host buffers of bz3_bound(block_size) bytes; at least one or false.
+    bool init(u32 block_size, size_t want) {
+        cap = bz3_bound(block_size);
+        const int ndev = device_count();
+        size_t limit = (size_t)(ndev > 0 ? ndev : 1) * 256;             // one CU per block during the CM stage
+        const size_t by_mem = ((size_t)16 << 30) / (cap ? cap : 1);      // host staging budget of the window
+        if (limit > by_mem) limit = by_mem;
+        if (limit < 1) limit = 1;
+        if (want > limit) want = limit;
+        if (want < 1) want = 1;
+        for (size_t i = 0; i < want; i++) {
+            bz3_state * st = bz3_new((int32_t)block_size);
+            u8 * b = st ? (u8 *)malloc(cap) : nullptr;
+            if (!st || !b) {
+                if (st) bz3_free(st);
+                free(b);
+                break;
+            }
+            states.push_back(st);
+            bufs.push_back(b);
+        }
+        return !states.empty();
+    }
+};
+
+}  // namespace
+
 BZIP3_API int bz3_compress(uint32_t block_size, const uint8_t * in, uint8_t * out, size_t in_size, size_t * out_size) {
     if (block_size > in_size) block_size = (uint32_t)bz3_bound(in_size);  // :877
     block_size = block_size <= (uint32_t)KiB65 ? (uint32_t)KiB65 : block_size;
-    struct bz3_state * state = bz3_new((int32_t)block_size);
-    if (!state) return BZ3_ERR_INIT;
-    u8 * cbuf = (u8 *)malloc(bz3_bound(block_size));
-    if (!cbuf) { bz3_free(state); return BZ3_ERR_INIT; }
-    const size_t buf_max = *out_size;
-    *out_size = 0;
     u32 n_blocks = (u32)(in_size / block_size);
     if (in_size % block_size) n_blocks++;
-    if (buf_max < 13 || buf_max < bz3_bound(in_size)) { bz3_free(state); free(cbuf); return BZ3_ERR_DATA_TOO_BIG; }
+    FrameWindow w;
+    if (!w.init(block_size, n_blocks)) return BZ3_ERR_INIT;  // :879-886 (allocation precedes the size check)
+    const size_t buf_max = *out_size;
+    *out_size = 0;
+    if (buf_max < 13 || buf_max < bz3_bound(in_size)) return BZ3_ERR_DATA_TOO_BIG;
     memcpy(out, "BZ3v1", 5);
     wr_le32(out + 5, block_size);
     wr_le32(out + 9, n_blocks);
     *out_size += 13;
     size_t in_off = 0;
-    for (u32 i = 0; i < n_blocks; i++) {
-        s32 size = (s32)block_size;
-        if (i == n_blocks - 1) size = (s32)(in_size % block_size);  // (sic) :914 -- 0 when in_size is a multiple
-        memcpy(cbuf, in + in_off, (size_t)size);
-        const s32 osz = bz3_encode_block(state, cbuf, size);
-        if (bz3_last_error(state) != BZ3_OK) {
-            const s8 e = state->last_error;
-            bz3_free(state); free(cbuf);
-            return e;
+    const u32 W = (u32)w.states.size();
+    std::vector<s32> sizes(W), orig(W);
+    for (u32 i0 = 0; i0 < n_blocks; i0 += W) {
+        const u32 cnt = n_blocks - i0 < W ? n_blocks - i0 : W;
+        for (u32 k = 0; k < cnt; k++) {
+            s32 size = (s32)block_size;
+            if (i0 + k == n_blocks - 1) size = (s32)(in_size % block_size);  // (sic) :914 -- 0 when in_size is a multiple
+            memcpy(w.bufs[k], in + in_off, (size_t)size);
+            sizes[k] = orig[k] = size;
+            in_off += (size_t)size;
         }
-        memcpy(out + *out_size + 8, cbuf, (size_t)osz);
-        wr_le32(out + *out_size, (u32)osz);
-        wr_le32(out + *out_size + 4, (u32)size);
-        *out_size += (size_t)osz + 8;
-        in_off += (size_t)size;
+        bz3_encode_blocks(w.states.data(), w.bufs.data(), sizes.data(), (int32_t)cnt);
+        for (u32 k = 0; k < cnt; k++) {
+            if (bz3_last_error(w.states[k]) != BZ3_OK) return w.states[k]->last_error;  // :917-922
+            const s32 osz = sizes[k];
+            memcpy(out + *out_size + 8, w.bufs[k], (size_t)osz);
+            wr_le32(out + *out_size, (u32)osz);
+            wr_le32(out + *out_size + 4, (u32)orig[k]);
+            *out_size += (size_t)osz + 8;
+        }
     }
-    bz3_free(state);
-    free(cbuf);
     return BZ3_OK;
 }
 
@@ -915,35 +957,49 @@ BZIP3_API int bz3_decompress(const uint8_t * in, uint8_t * out, size_t in_size, 
     const u32 n_blocks = rd_le32(in + 9);
     in_size -= 13;
     in += 13;
-    struct bz3_state * state = bz3_new((int32_t)block_size);
-    if (!state) return BZ3_ERR_INIT;
-    const size_t cap = bz3_bound(block_size);
-    u8 * cbuf = (u8 *)malloc(cap);
-    if (!cbuf) { bz3_free(state); return BZ3_ERR_INIT; }
+    FrameWindow w;
+    {
+        // never more states than chunks that can possibly be present (8 header bytes each)
+        const size_t possible = in_size / 8 + 1;
+        if (!w.init(block_size, n_blocks < possible ? n_blocks : possible)) return BZ3_ERR_INIT;  // :953-960
+    }
     const size_t buf_max = *out_size;
     *out_size = 0;
-    for (u32 i = 0; i < n_blocks; i++) {
-        if (in_size < 8) { bz3_free(state); free(cbuf); return BZ3_ERR_MALFORMED_HEADER; }
-        const s32 size = (s32)rd_le32(in);
-        if (size < 0 || (u32)size > block_size) { bz3_free(state); free(cbuf); return BZ3_ERR_MALFORMED_HEADER; }
-        if (in_size < (size_t)size + 8) { bz3_free(state); free(cbuf); return BZ3_ERR_TRUNCATED_DATA; }
-        const s32 orig_size = (s32)rd_le32(in + 4);
-        if (orig_size < 0) { bz3_free(state); free(cbuf); return BZ3_ERR_MALFORMED_HEADER; }
-        if (buf_max < *out_size + (size_t)orig_size) { bz3_free(state); free(cbuf); return BZ3_ERR_DATA_TOO_BIG; }
-        memcpy(cbuf, in + 8, (size_t)size);
-        bz3_decode_block(state, cbuf, cap, size, orig_size);
-        if (bz3_last_error(state) != BZ3_OK) {
-            const s8 e = state->last_error;
-            bz3_free(state); free(cbuf);
-            return e;
+    const u32 W = (u32)w.states.size();
+    std::vector<s32> sizes(W), orig(W);
+    std::vector<size_t> caps(W, w.cap);
+    u32 i = 0;
+    while (i < n_blocks) {
+        // Collect chunks until the window is full or a chunk header is bad.  The reference would have decoded the
+        // chunks before the bad one first, so they run (and may fail) before the header error is reported.
+        u32 cnt = 0;
+        int header_error = BZ3_OK;
+        size_t planned = *out_size;
+        while (cnt < W && i + cnt < n_blocks) {
+            if (in_size < 8) { header_error = BZ3_ERR_MALFORMED_HEADER; break; }                 // :963
+            const s32 size = (s32)rd_le32(in);
+            if (size < 0 || (u32)size > block_size) { header_error = BZ3_ERR_MALFORMED_HEADER; break; }  // :969
+            if (in_size < (size_t)size + 8) { header_error = BZ3_ERR_TRUNCATED_DATA; break; }    // :974
+            const s32 orig_size = (s32)rd_le32(in + 4);
+            if (orig_size < 0) { header_error = BZ3_ERR_MALFORMED_HEADER; break; }               // :980
+            if (buf_max < planned + (size_t)orig_size) { header_error = BZ3_ERR_DATA_TOO_BIG; break; }  // :985
+            memcpy(w.bufs[cnt], in + 8, (size_t)size);
+            sizes[cnt] = size;
+            orig[cnt] = orig_size;
+            planned += (size_t)orig_size;
+            in += size + 8;
+            in_size -= (size_t)size + 8;
+            cnt++;
         }
-        memcpy(out + *out_size, cbuf, (size_t)orig_size);
-        *out_size += (size_t)orig_size;
-        in += size + 8;
-        in_size -= (size_t)size + 8;
+        if (cnt) bz3_decode_blocks(w.states.data(), w.bufs.data(), caps.data(), sizes.data(), orig.data(), (int32_t)cnt);
+        for (u32 k = 0; k < cnt; k++) {
+            if (bz3_last_error(w.states[k]) != BZ3_OK) return w.states[k]->last_error;  // :989-993
+            memcpy(out + *out_size, w.bufs[k], (size_t)orig[k]);
+            *out_size += (size_t)orig[k];
+        }
+        if (header_error != BZ3_OK) return header_error;
+        i += cnt;
     }
-    bz3_free(state);
-    free(cbuf);
     return BZ3_OK;
 }
 

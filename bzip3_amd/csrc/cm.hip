@@ -234,6 +234,44 @@ __device__ __forceinline__ void cm_model_chunk(CmLds & m, CmEvent * __restrict__
     }
 }
 
+// Coder steps K0 .. K0+CNT-1 of one byte without renormalisation.  Returns true when the result must not be used:
+// the final interval lies within one 2^24 bucket (=> a renormalisation was due after one of the bits, :390), or the
+// interval shrank to a single value on the way (a renormalisation was due there, and a 0 bit coded from that state
+// wraps the range, after which the intervals are no longer nested).
+template <int K0, int CNT>
+__device__ __forceinline__ bool cm_code_bits(const uint4 (&ev)[8], u32 & r, u32 & l) {
+    u32 rmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int kk = K0; kk < K0 + CNT; kk++) {
+        const uint4 e = ev[kk];  // (-s, -s, M, s): see the header comment
+        const u64 prod = (u64)r * e.z + (((u64)e.y << 32) | e.x);
+        const u32 r2 = (u32)(prod >> 18);
+        l += (r - r2) & e.x;
+        r = r2;
+        rmin = r < rmin ? r : rmin;
+    }
+    return (l ^ (l + r)) < (1u << 24) || rmin == 0u;
+}
+// The same steps with the reference's test after every bit (:390-394).
+template <int K0, int CNT>
+__device__ __forceinline__ void cm_code_bits_checked(const uint4 (&ev)[8], u32 & range, u32 & low, u8 * __restrict__ out, u32 & op) {
+#pragma unroll
+    for (int kk = K0; kk < K0 + CNT; kk++) {
+        const uint4 e = ev[kk];
+        const u64 prod = (u64)range * e.z + (((u64)e.y << 32) | e.x);
+        const u32 r2 = (u32)(prod >> 18);
+        low += (range - r2) & e.x;
+        range = r2;
+        if (__builtin_expect(__ballot(range < (1u << 24)) != 0ull, 0)) {  // necessary for (low ^ high) < 2^24; the exact test follows
+            while (__ballot((low ^ (low + range)) < (1u << 24)) != 0ull) {  // :390-394
+                out[op++] = (u8)(low >> 24);
+                low <<= 8;
+                range = (range << 8) | 0xFFu;
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restrict__ jobs) {
     // one workgroup per block: blockIdx.x selects the job
     const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
@@ -325,22 +363,32 @@ __global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restric
         uint4 ev[8];
 #pragma unroll
         for (int kk = 0; kk < 8; kk++) ev[kk] = evp[kk];
-#pragma unroll
-        for (int kk = 0; kk < 8; kk++) {
-            const uint4 e = ev[kk];  // (-s, -s, M, s): see the header comment
-            const u64 prod = (u64)range * e.z + (((u64)e.y << 32) | e.x);
-            const u32 r2 = (u32)(prod >> 18);
-            low += (range - r2) & e.x;
-            range = r2;
-            // Branch on a wave-uniform condition (ballot of the single live lane -> s_cbranch_vccnz): a divergent
-            // `if` would save/restore EXEC around every bit, and every EXEC write stalls the following VALU op.
-            // __builtin_expect keeps the renormalisation out of line: the common case must FALL THROUGH, a taken
-            // branch per coded bit costs an instruction-fetch redirect (~40 cycles on a lone wave).
-            if (__builtin_expect(__ballot(range < (1u << 24)) != 0ull, 0)) {  // necessary for (low ^ high) < 2^24; the exact test follows
-                while (__ballot((low ^ (low + range)) < (1u << 24)) != 0ull) {  // :390-394
-                    out[op++] = (u8)(low >> 24);
-                    low <<= 8;
-                    range = (range << 8) | 0xFFu;
+        // Fast path: all 8 bits of the byte without a single test.  While nothing is renormalised the intervals are
+        // nested, so "a renormalisation was due after some bit" is equivalent to "the final interval lies within one
+        // 2^24 bucket" (:390): one test per byte.  If it fires (about one byte in four) the byte is coded again in two
+        // halves of 4 bits, each first without tests and only then, if its own test fires, bit by bit.
+        // Branches are on wave-uniform conditions (ballot of the single live lane -> s_cbranch_vccnz): a divergent
+        // `if` would save/restore EXEC, and every EXEC write stalls the following VALU op.  __builtin_expect keeps
+        // the slow paths out of line: the common case must FALL THROUGH (a taken branch costs ~40 cycles on a lone wave).
+        {
+            u32 r = range, l = low;
+            if (__builtin_expect(__ballot(cm_code_bits<0, 8>(ev, r, l)) == 0ull, 1)) {
+                range = r;
+                low = l;
+            } else {
+                r = range, l = low;
+                if (__ballot(cm_code_bits<0, 4>(ev, r, l)) == 0ull) {
+                    range = r;
+                    low = l;
+                } else {
+                    cm_code_bits_checked<0, 4>(ev, range, low, out, op);
+                }
+                r = range, l = low;
+                if (__ballot(cm_code_bits<4, 4>(ev, r, l)) == 0ull) {
+                    range = r;
+                    low = l;
+                } else {
+                    cm_code_bits_checked<4, 4>(ev, range, low, out, op);
                 }
             }
         }
@@ -496,8 +544,9 @@ __global__ void __launch_bounds__(256) k_cm_decode(const CmDecodeJob * __restric
         CM_RENORM();                                                                                  \
     } while (0)
 // ---- fast walk: no branches, no renormalisation ------------------------------------------------------------------
-// Works on d = code - low instead of low (the comparison becomes d <= t; equivalent as long as code >= low, which is
-// checked per byte: a truncated stream feeds -1 bytes (:345) and can push `code` below `low`).  Every lane shifts
+// Works on d = code - low instead of low (the comparison becomes d <= t; equivalent as long as low <= code <= high,
+// which is checked per byte: a truncated stream feeds -1 bytes (:345) and can push `code` out of the interval; inside
+// it, d <= range holds along the true path, so the range never wraps there).  Every lane shifts
 // the outcome of its comparisons into `acc`; the lane whose `acc` spells its own number took no wrong turn
 // (induction over the levels: its first comparison used the true state), so it holds the true coder state.
 // Intervals are nested while nothing is renormalised, so "a renormalisation was due at some level" is equivalent to
@@ -551,7 +600,7 @@ __global__ void __launch_bounds__(256) k_cm_decode(const CmDecodeJob * __restric
             const u32 P7a = pt[ix7], P7b = pt[ix7 + 1u];
             u32 range = range_u, low;  // per-lane copies of the wave-uniform coder state
             u32 d = code - low_u;
-            const bool inside = code >= low_u;  // always, unless a truncated stream fed -1 bytes (:345)
+            const bool inside = d <= range_u;  // low <= code <= high: always, unless a truncated stream fed -1 bytes (:345)
             u32 acc = 0;
             bool bit6, bit7;
             CM_FAST_SPEC(P0, nb0, as0);  // :453-489

@@ -12,6 +12,12 @@
 //      the segment length (latency-bound, ~n/1024-way parallel random 4-byte reads).
 //   3. The ~n/1024-element splitter list is ranked by pointer jumping (log2 rounds, tiny).
 //   4. Each lane re-walks its segment and writes the text bytes at their now-known positions.
+//   5. Input that is NOT a genuine BWT (a corrupted block) must still decode to what the reference produces, because
+//      the CRC / LZP / size checks that follow decide the error code.  psi(0) = idx puts rows 0 and idx on one
+//      cycle, so the chain from idx always ends at row 0, after D <= n bytes (D = n for a genuine BWT); the text is
+//      laid out from position 0 and k_ub_tail reproduces what the reference's bigram chase emits once it is stuck
+//      on its zero-filled table entries (oracle/bz3_oracle.c orc_unbwt spells the rules out; pinned against the
+//      reference on random inputs).
 // HBM layout: psi u32[n+1], splitter-id u32[n+1], a few arrays of n/1024 words.
 // Algorithmic traffic: 11 B per byte; the walks are random 4-byte reads.
 #include "prims.hpp"
@@ -92,7 +98,8 @@ __global__ void __launch_bounds__(UB_BLOCK) k_ub_jump(const u32 * __restrict__ s
 
 // Walk 2: emit the text of every segment.  seg_len was saved before the jumping rounds.
 __global__ void __launch_bounds__(UB_BLOCK) k_ub_walk_emit(const u32 * __restrict__ psi, const u32 * __restrict__ split_row, const u32 * __restrict__ seg_len,
-                                                          const u32 * __restrict__ dist, const u32 * __restrict__ cum, u32 nsplit, u32 n, u8 * __restrict__ out) {
+                                                          const u32 * __restrict__ dist, const u32 * __restrict__ succ, const u32 * __restrict__ sid, u32 idx,
+                                                          const u32 * __restrict__ cum, u32 nsplit, u32 n, u8 * __restrict__ out) {
     __shared__ u32 c[257];
     for (int k = threadIdx.x; k < 257; k += UB_BLOCK) c[k] = cum[k];
     __syncthreads();
@@ -101,8 +108,13 @@ __global__ void __launch_bounds__(UB_BLOCK) k_ub_walk_emit(const u32 * __restric
     u32 r = split_row[j];
     const u32 len = seg_len[j];
     const u32 d = dist[j];
-    if (d > n) return;  // not on the chain that reaches the terminal (only possible for corrupt input)
-    u64 pos = (u64)n - d;
+    // On the chain idx -> ... -> row 0?  After the jumping rounds every chain element points at the terminal; splitters
+    // of other cycles (corrupt input only) never do.  D = bytes on the chain (n for a genuine BWT).
+    if (succ[j] != sid[0]) return;
+    const u32 D = dist[sid[idx]];
+    if (d > D) return;
+    const u32 limit = n & ~1u;  // the reference's loop writes 2 * (n / 2) bytes, then U[n-1] separately (:5155)
+    u64 pos = (u64)D - d;
     for (u32 t = 0; t < len; t++) {
         const u32 nr = psi[r];  // issue the dependent load first; the symbol search below overlaps it
         // F[r]: largest symbol s with c[s] <= r   (r >= 1 here: row 0 is never emitted)
@@ -112,10 +124,52 @@ __global__ void __launch_bounds__(UB_BLOCK) k_ub_walk_emit(const u32 * __restric
             const u32 mid = (lo + hi) >> 1;
             if (c[mid] <= r) lo = mid; else hi = mid;
         }
-        if (pos < n) out[pos] = (u8)lo;
+        if (pos < limit) out[pos] = (u8)lo;
         pos++;
         r = nr;
     }
+}
+
+__device__ __forceinline__ u32 ub_first_symbol(const u32 * __restrict__ cum, u32 r) {  // F[r], r >= 1
+    u32 lo = 0, hi = 256;
+    for (int b = 0; b < 8; b++) {
+        const u32 mid = (lo + hi) >> 1;
+        if (cum[mid] <= r) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// What the reference leaves behind the chain (nothing for a genuine BWT, where D = n), and U[n-1] = first BWT byte.
+// Rules and their derivation from include/libsais.h:4534-4636: oracle/bz3_oracle.c, orc_unbwt.
+__global__ void __launch_bounds__(UB_BLOCK) k_ub_tail(const u8 * __restrict__ in, const u32 * __restrict__ psi, const u32 * __restrict__ cum,
+                                                     const u32 * __restrict__ dist, const u32 * __restrict__ sid, u32 idx, u32 n, u8 * __restrict__ out) {
+    const u32 D = dist[sid[idx]];
+    const u32 limit = n & ~1u;
+    const u32 lastc = in[0];
+    const u32 E = cum[lastc];  // row of the suffix that is the last character alone = LF(0)
+    const u32 gid = blockIdx.x * UB_BLOCK + threadIdx.x;
+    u32 start = D;
+    if (D < limit && (D & 1u)) {  // E was hit on an even step of the bigram chase
+        int shift = 0;
+        while ((n >> shift) > (1u << 17)) shift++;
+        const bool same_group = E >= 2 && ((E - 1) >> shift) == (E >> shift);
+        if (gid == 0) {
+            if (same_group || E + 1 > n) {
+                out[D] = 0;
+            } else {
+                out[D - 1] = (u8)ub_first_symbol(cum, E + 1);
+                out[D] = (u8)ub_first_symbol(cum, psi[E + 1]);
+            }
+        }
+        start = D + 1;
+    }
+    if (start < limit) {  // stuck at table entry 0: the bigram of the first non-empty bucket, over and over
+        const u32 q0 = (E == 1) ? 2u : 1u;
+        const u32 hi = ub_first_symbol(cum, q0), lo = ub_first_symbol(cum, psi[q0]);
+        for (u64 j = (u64)start + gid; j < limit; j += (u64)gridDim.x * UB_BLOCK)
+            if (j != n - 1) out[j] = (u8)((j & 1u) ? lo : hi);  // U[n-1] belongs to thread 0 below
+    }
+    if (gid == 0) out[n - 1] = (u8)lastc;
 }
 
 size_t unbwt_workspace_bytes(u64 n) { return (n + 64) * 8 + radix_temp_bytes(n) + scan_temp_words(n + 1) * 4 + ((n >> 8) + 4096) * 32 + (1u << 20); }
@@ -165,8 +219,9 @@ void bwt_inverse(const u8 * d_in, u32 n, u32 idx, u8 * d_out, Arena & tmp, hipSt
         cur ^= 1;
     }
     // 4. emit
-    launch(k_ub_walk_emit, gs, dim3(UB_BLOCK), 0, s, (const u32 *)psi, (const u32 *)split_row, (const u32 *)seg_len, (const u32 *)dist[cur], (const u32 *)cum, nsplit, n,
-           d_out);
+    launch(k_ub_walk_emit, gs, dim3(UB_BLOCK), 0, s, (const u32 *)psi, (const u32 *)split_row, (const u32 *)seg_len, (const u32 *)dist[cur], (const u32 *)succ[cur],
+           (const u32 *)sid, idx, (const u32 *)cum, nsplit, n, d_out);
+    launch(k_ub_tail, dim3(256), dim3(UB_BLOCK), 0, s, d_in, (const u32 *)psi, (const u32 *)cum, (const u32 *)dist[cur], (const u32 *)sid, idx, n, d_out);
     HIP_CHECK(hipStreamSynchronize(s));
     tmp.release(mk);
 }

@@ -332,6 +332,17 @@ ORC_API s32 orc_bwt(const u8 * T, u8 * U, s32 n) {
  * LF(r) = C[L[r]] + rank of r among equal symbols, T[n-1-k] = L[LF^k(0)].
  * Returns 0, or -1 for an index outside (0, n]. */
 ORC_API s32 orc_unbwt(const u8 * U, u8 * T, s32 n, s32 idx) {
+    /* Restates libsais_unbwt (include/libsais.h:5260-5262 -> :5210-5232, init :4593-4617, decode :4618-4636,
+     * :5133-5156) for ANY input, not only for a genuine BWT.  Rows 0..n: row 0 is the empty suffix, row idx is the
+     * row whose preceding character is the (virtual) sentinel, L[r] = U[r < idx ? r : r - 1] otherwise.
+     *   LF(r)  = C[L[r]] + #{r' < r : L[r'] = L[r]}  (C[c] = 1 + #{bytes < c}),  LF(idx) = 0;   psi = LF^-1, psi(0) = idx.
+     * The reference chases the bigram table P = psi o psi from p = idx for n/2 steps and emits (F[p], F[psi(p)]) per
+     * step (:4618-4636), which is F[psi^j(idx)] byte by byte.  psi(0) = idx puts rows 0 and idx on one cycle, so the
+     * chase always runs into E = LF(0) (the suffix made of the last character alone) after D <= n bytes; for a genuine
+     * BWT D = n.  For anything else the table holds zeros there: P[E] was never written (the caller zeroes the work
+     * array, src/libbz3.c:756), P[LF(E)] = 0 legitimately and P[0] = 0, so the chase is stuck at p = 0 and repeats the
+     * bigram of the first non-empty bucket (fastbits[0], :4534-4553).  If E itself is hit on an even step its bucket
+     * lookup (:4626-4631) yields the pair (last character, 0x00).  Finally U[n-1] = first BWT byte (:5155). */
     if (n < 0) return -1;
     if (n <= 1) {
         if (idx != n) return -1;
@@ -339,24 +350,56 @@ ORC_API s32 orc_unbwt(const u8 * U, u8 * T, s32 n, s32 idx) {
         return 0;
     }
     if (idx <= 0 || idx > n) return -1;
-    u32 C[257];
+    u32 C[257], cum[257];
     memset(C, 0, sizeof C);
     for (s32 i = 0; i < n; i++) C[U[i] + 1]++;
     C[0] = 1; /* row 0 of F is the sentinel */
     for (int c = 0; c < 256; c++) C[c + 1] += C[c];
-    u32 * LF = (u32 *)malloc(((size_t)n + 1) * 4);
-    if (!LF) return -1;
+    memcpy(cum, C, sizeof cum); /* cum[c] = first row whose suffix starts with c; cum[256] = n + 1 */
+    u32 * psi = (u32 *)malloc(((size_t)n + 1) * 4);
+    u8 * F = (u8 *)malloc((size_t)n + 1);
+    if (!psi || !F) { free(psi); free(F); return -1; }
+    psi[0] = (u32)idx;
     for (s32 r = 0; r <= n; r++) {
-        if (r == idx) { LF[r] = 0; continue; } /* the sentinel row maps to F-row 0 */
+        if (r == idx) continue; /* the sentinel row maps to F-row 0: psi[0] = idx */
         u8 c = U[r < idx ? r : r - 1];
-        LF[r] = C[c]++;
+        psi[C[c]++] = (u32)r;
     }
-    u32 r = 0;
-    for (s32 k = 0; k < n; k++) {
-        T[n - 1 - k] = U[r < (u32)idx ? r : r - 1];
-        r = LF[r];
+    F[0] = 0;
+    for (int c = 0; c < 256; c++)
+        for (u32 r = cum[c]; r < cum[c + 1]; r++) F[r] = (u8)c;
+    const u8 lastc = U[0];
+    const u32 E = cum[lastc];
+    const s32 limit = 2 * (n / 2);
+    s32 j = 0;
+    u32 r = (u32)idx;
+    while (j < limit && r != 0) {
+        T[j++] = F[r];
+        r = psi[r];
     }
-    free(LF);
+    if (j < limit) { /* the chain ended after D = j bytes (not a genuine BWT) */
+        if (j & 1) {
+            /* E was hit on an even step, and E lies in no bucket.  The lookup (:4626-4631) starts at fastbits[E >> shift],
+             * the first non-empty bucket that reaches into E's group of 2^shift rows: if that is a bucket before E (row
+             * E-1 is in the same group) the scan walks up to the empty-or-not bucket (lastc, 0x00) right behind the
+             * reserved row; otherwise it is already the bucket of row E+1.  (E = n leaves fastbits unset: undefined.) */
+            int shift = 0;
+            while ((n >> shift) > (1 << 17)) shift++;
+            const int same_group = E >= 2 && ((E - 1) >> shift) == (E >> shift);
+            if (same_group || E + 1 > (u32)n) {
+                T[j++] = 0;
+            } else {
+                T[j - 1] = F[E + 1];
+                T[j++] = F[psi[E + 1]];
+            }
+        }
+        const u32 q0 = (E == 1) ? 2u : 1u; /* smallest row that has a bigram */
+        const u8 hi = F[q0], lo = F[psi[q0]];
+        for (; j < limit; j++) T[j] = (j & 1) ? lo : hi;
+    }
+    T[n - 1] = lastc;
+    free(psi);
+    free(F);
     return 0;
 }
 

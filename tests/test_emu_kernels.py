@@ -94,6 +94,19 @@ def test_cm_decode_of_arbitrary_bytes_matches_reference(emu, oracle):
     assert g.cm_decode(skew, 4000) == oracle.cm_decode(skew, 4000)
 
 
+def test_unbwt_of_arbitrary_bytes_matches_reference(emu, oracle):
+    # libsais_unbwt is defined (up to one corner that reads unset memory) on ANY (bytes, index); what it returns for a
+    # block whose payload is corrupt decides which error the caller reports (oracle pinned in test_oracle.py)
+    g = bzip3_amd.StageApi(emu)
+    rng = np.random.default_rng(21)
+    for trial in range(24):
+        n = int(rng.integers(2, 60)) if trial % 2 else int(rng.integers(60, 9000))
+        k = [1, 2, 3, 256][trial % 4]
+        u = bytes(rng.integers(0, k, size=n, dtype=np.uint8))
+        for idx in sorted({1, n, int(rng.integers(1, n + 1))}):
+            assert g.unbwt(u, idx) == oracle.unbwt(u, idx), (n, k, idx)
+
+
 def test_decoder_error_codes(emu, oracle):
     bs = 65 * 1024
     blk = oracle.encode_block(datagen.shakespeare()[:20000], bs)[2]
@@ -142,3 +155,14 @@ def test_batch_api_and_frame_api(emu, oracle):
     bsz2 = C.c_size_t(len(back))
     assert emu.bz3_decompress(out, back, osz.value, C.byref(bsz2)) == 0
     assert bytes(back[: bsz2.value]) == data
+
+
+def test_frame_api_multi_block_matches_reference(emu):
+    """bz3_compress / bz3_decompress (src/libbz3.c:876-997) run the blocks of a frame as one batch here; the frame
+    bytes, the return codes and the bytes committed before an error must equal the reference's sequential loop.
+    (Repetitive data: LZP collapses it, so the emulated CM stage stays small; the GPU suite runs the same cases on text.)"""
+    import frame_cases
+
+    rng = np.random.default_rng(4)
+    unit = bytes(rng.integers(0, 256, size=997, dtype=np.uint8))
+    frame_cases.check(emu, (unit * 400)[: 4 * 65 * 1024 + 1234], 65 * 1024)

@@ -105,6 +105,33 @@ def test_cm_decode_of_arbitrary_bytes_matches_reference(gpu_lib, oracle):
     assert g.cm_decode(skew, 500000) == oracle.cm_decode(skew, 500000)
 
 
+def test_unbwt_of_arbitrary_bytes_matches_reference(gpu_lib, oracle):
+    # libsais_unbwt on input that is not a genuine BWT (a corrupted block): the bytes it leaves decide the error code
+    g = bzip3_amd.StageApi(gpu_lib)
+    rng = np.random.default_rng(22)
+    for trial in range(40):
+        n = int(rng.integers(2, 100)) if trial % 4 == 0 else int(rng.integers(100, 700000))
+        k = [1, 2, 3, 256, 7][trial % 5]
+        u = bytes(rng.integers(0, k, size=n, dtype=np.uint8))
+        for idx in sorted({1, n, int(rng.integers(1, n + 1)), int(rng.integers(1, n + 1))}):
+            assert g.unbwt(u, idx) == oracle.unbwt(u, idx), (n, k, idx)
+
+
+def test_corrupted_payload_error_codes(gpu_lib, oracle, text):
+    """Bit flips inside the coded payload: CM -> unBWT -> LZP -> mRLE -> CRC all run on garbage and the return value /
+    last_error must still be the reference's (the oracle is pinned against it on the same cases, tests/test_oracle.py)."""
+    bs = 65 * 1024
+    with bzip3_amd.State(bs, gpu_lib) as st:
+        for data in (text[:60000], (text[:500] * 200)[:66000], datagen.low_entropy(50000)):
+            blk = oracle.encode_block(data, bs)[2]
+            for pos in (20, 25, 40, 100, len(blk) // 2, len(blk) - 3):
+                for bit in (1, 0x40):
+                    if pos >= len(blk):
+                        continue
+                    m = blk[:pos] + bytes([blk[pos] ^ bit]) + blk[pos + 1 :]
+                    assert st.decode_block(m, len(data))[:2] == oracle.decode_block(m, len(data), bs)[:2], (len(data), pos, bit)
+
+
 def test_decoder_error_codes(gpu_lib, oracle, text):
     bs = 65 * 1024
     blk = oracle.encode_block(text[:30000], bs)[2]
@@ -184,6 +211,15 @@ def test_frame_api_round_trip_and_reference_interop(gpu_lib, text):
     bsz = C.c_size_t(len(back))
     assert gpu_lib.bz3_decompress(out, back, osz.value, C.byref(bsz)) == 0
     assert bytes(back[: bsz.value]) == data
+
+
+def test_frame_api_multi_block_matches_reference(gpu_lib, text):
+    """bz3_compress / bz3_decompress (src/libbz3.c:876-997) batch the blocks of a frame; frames, return codes and the
+    bytes committed before an error must equal the reference's sequential loop (good + 15 malformed frames)."""
+    import frame_cases
+
+    frame_cases.check(gpu_lib, text[: 4 * 65 * 1024 + 1234], 65 * 1024)
+    frame_cases.check(gpu_lib, (text * 3)[: 4 * (1 << 20) + 777], 1 << 20)
 
 
 def test_large_block_round_trip_properties(gpu_lib, oracle):

@@ -107,6 +107,48 @@ def test_decoder_error_codes_match_reference(oracle, ref_lib, text):
         assert a[:2] == b[:2], (bsz, cs, osz)
 
 
+def test_oracle_matches_reference_on_hostile_stage_inputs(oracle, ref_stages):
+    """Input no encoder would produce (what a corrupted block feeds into the later stages): the restatement must still
+    equal the reference, because the bytes these stages leave decide which error code the block API reports."""
+    import numpy as np
+
+    rng = np.random.default_rng(5)
+    # inverse BWT of arbitrary bytes with an arbitrary (valid-range) primary index, small and > 2^17 (fastbits shift >= 1)
+    for trial in range(400):
+        n = int(rng.integers(2, 50)) if trial % 3 else int(rng.integers(50, 4000))
+        k = [1, 2, 3, 256][trial % 4]
+        u = bytes(rng.integers(0, k, size=n, dtype=np.uint8))
+        for idx in sorted({1, n, int(rng.integers(1, n + 1)), int(rng.integers(1, n + 1))}):
+            assert oracle.unbwt(u, idx) == ref_stages.unbwt(u, idx), (n, k, idx)
+    for trial in range(8):
+        n = int(rng.integers(140000, 500000))
+        u = bytes(rng.integers(0, [2, 3, 7, 256][trial % 4], size=n, dtype=np.uint8))
+        for idx in sorted({1, n, int(rng.integers(1, n + 1))}):
+            assert oracle.unbwt(u, idx) == ref_stages.unbwt(u, idx), (n, idx)
+    # CM decoder and LZP decoder on arbitrary bytes
+    for size, n in ((0, 300), (3, 2000), (5000, 20000), (60000, 90000)):
+        junk = bytes(rng.integers(0, 256, size=size, dtype=np.uint8))
+        assert oracle.cm_decode(junk, n) == ref_stages.cm_decode(junk, n)
+    for trial in range(40):
+        n = int(rng.integers(5, 30000))
+        a = rng.choice(np.array([0xF2, 0xFF, 0xFE, 0, 1, 65, 66], dtype=np.uint8), size=n, p=[.15, .05, .1, .2, .1, .2, .2]) if trial % 2 else \
+            rng.integers(0, 256, size=n, dtype=np.uint8)
+        z = bytes(a)
+        for max_out in (n + 100, 70000, 3000):
+            assert oracle.lzp_decode(z, max_out) == ref_stages.lzp_decode(z, max_out), (trial, max_out)
+
+
+def test_corrupted_payload_error_codes_match_reference(oracle, ref_lib, text):
+    """Flip bytes inside the coded payload (after the header): CM -> unBWT -> LZP -> mRLE -> CRC all run on garbage."""
+    bs = 65 * 1024
+    for data in (text[:60000], (text[:500] * 200)[:66000]):
+        blk = oracle.encode_block(data, bs)[2]
+        for pos in (20, 25, 40, 100, len(blk) // 2, len(blk) - 3):
+            for bit in (1, 0x40):
+                m = blk[:pos] + bytes([blk[pos] ^ bit]) + blk[pos + 1 :]
+                assert oracle.decode_block(m, len(data), bs)[:2] == ref_lib.decode_block(m, len(data), bs)[:2], (pos, bit)
+
+
 def test_oracle_builds_without_reference_tree():
     # the restatement itself must not depend on /root/reference (absent on the GPU box)
     src = open(os.path.join(ORACLE_DIR, "bz3_oracle.c")).read()
