@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--blocks", type=int, default=int(os.environ.get("BZ3_BENCH_BLOCKS", "240")), help="256 MiB blocks per GPU")
+    ap.add_argument("--blocks", type=int, default=int(os.environ.get("BZ3_BENCH_BLOCKS", "256")), help="256 MiB blocks per GPU")
     ap.add_argument("--block-mib", type=float, default=float(os.environ.get("BZ3_BENCH_BLOCK_MIB", "256")))
     ap.add_argument("--kind", default="text", choices=["text", "random"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -276,7 +276,7 @@ def main():
         try:
             with open(PMC_TRAFFIC_FILE) as fh:
                 pm = json.load(fh)["k_cm_decode"]
-            traffic = int((pm["fetch_bytes_per_decoded_byte"] + pm["write_bytes_per_decoded_byte"]) * n_dec * nblk)
+            traffic = int(pm["fetch_bytes_per_coded_byte"] * comp_total[0] + pm["write_bytes_per_decoded_byte"] * n_dec * nblk)
         except Exception:
             pass
         out = {

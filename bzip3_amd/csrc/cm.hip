@@ -402,22 +402,28 @@ __global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// decode: four waves, one tree node per lane (node = thread), ONE barrier per byte.
+// decode: five waves.  Wave 0 ("walker") runs the coder; waves 1..4 ("model waves") hold one tree node per lane
+// (node = thread - 64) and run AHEAD of it on a guess.
 //
-//  model   : before every byte each lane evaluates its node's 18-bit probability (the 255 nodes of the next
-//            byte depend only on state that is fixed once the previous byte is known) and leaves it, pre-shifted
-//            by 14 so that ((range * P) >> 18) is a single v_mul_hi_u32, in an LDS table (double-buffered).
-//  walk    : every wave then decodes the byte by itself -- redundantly, so nobody has to be told the result.
-//            The 8 serial decisions are SPECULATED across lanes: lane l assumes that the first six bits of the
-//            byte are l and runs the (low, range) recurrence along that path without waiting for any
-//            comparison; the comparisons are only shifted into a per-lane accumulator.  The lane whose
-//            accumulator spells its own number took no wrong turn (induction over the levels: its first
-//            comparison used the true state), so it holds the true coder state; every lane decodes its last two
-//            bits for real.  Per level the dependent chain is v_mul_hi_u32 + v_xad_u32, with no branch.
-//            Renormalisation (:470-474) is needed on the true path only about once per 50 bits: the fast walk
-//            just tracks the smallest range it saw, and if the surviving lane ever went below 2^24 the byte is
-//            decoded again by the checked walk, which renormalises on the scalar unit after every level.
-//  update  : the 8 lanes whose node lies on the decoded path update their counters.
+//  model   : for byte i every lane evaluates its node's 18-bit probability (the 255 nodes of a byte depend only on
+//            state that is fixed once byte i-1 is known) and leaves it, pre-shifted by 14 so that ((range * P) >> 18)
+//            is a single v_mul_hi_u32, in an LDS table (double-buffered).  The model waves do not wait for byte i-1:
+//            they ASSUME it repeats byte i-2 (the coder's input is BWT output: ~65 % of its bytes repeat their
+//            predecessor), apply that byte's counter update and evaluate byte i while the walker is still decoding
+//            byte i-1.  The update only touches cells owned by the updating lane and its old values stay in
+//            registers, so a wrong guess is undone with three stores, the real update applied, and the table
+//            evaluated again.  s_ready[w] = 2i+1 announces the speculative table of byte i, 2i+2 the corrected one.
+//  walk    : the walker decodes byte i from table i.  The 8 serial decisions are SPECULATED across lanes: lane l
+//            assumes that the first six bits of the byte are l and runs the (d = code - low, range) recurrence along
+//            that path without waiting for any comparison; the comparisons are only shifted into a per-lane
+//            accumulator.  The lane whose accumulator spells its own number took no wrong turn (induction over the
+//            levels: its first comparison used the true state), so it holds the true coder state; every lane decodes
+//            its last two bits for real.  Per level the dependent chain is v_mul_hi_u32 + v_xad_u32, with no branch.
+//            Intervals are nested while nothing is renormalised, so "a renormalisation (:470-474) was due at some
+//            level" is equivalent to "the final interval lies within one 2^24 bucket": one scalar test on the
+//            surviving lane's final state; if it fires (about one byte in four) the byte is decoded again by the
+//            checked walk, which renormalises on the scalar unit after every level.
+//            The byte goes to the model waves through s_done (tag of the byte index in the upper bits).
 // ------------------------------------------------------------------------------------------------
 template <u32 V>
 struct CmConst {
@@ -455,34 +461,140 @@ __device__ __forceinline__ u64 cm_clock() {
 #endif
 }
 
-__global__ void __launch_bounds__(256) k_cm_decode(const CmDecodeJob * __restrict__ jobs) {
+struct CmEval {  // what a model lane remembers of its node's last evaluation (the inputs of the counter update)
+    u32 a1;  // index of C1[c1][node]
+    u32 p1;  // its value
+    u32 ci;  // index of the first of the two C2 cells
+    u32 w;   // both cells, x1 | x2 << 16
+};
+
+// Probability of one node (:377-388) into the table, given the two order-1 counters p1 = C1[c1][node] (at index a1)
+// and p2 = C1[c2][node]; returns what the update of that byte will need.
+__device__ __forceinline__ CmEval cm_evaluate(const CmLds & m, u32 * __restrict__ pt, u32 node, u32 c0, u32 a1, u32 p1, u32 p2, u32 f) {
+    CmEval e;
+    e.a1 = a1;
+    e.p1 = p1;
+    const int p = (int)(((c0 + p1) * 7u + 2u * p2) >> 4);
+    e.ci = (2u * node + f) * CM_C2_STRIDE + (u32)(p >> 12);
+    e.w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[e.ci]));
+    const int x1 = (int)(e.w & 0xFFFFu), x2 = (int)(e.w >> 16);
+    const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);
+    pt[node] = (u32)(ssep * 3 + p) << 14;
+    return e;
+}
+
+__global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restrict__ jobs) {
     const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 in_size = jobs[blockIdx.x].in_size;
     u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
     const u32 n = jobs[blockIdx.x].n;
-    const u32 debug = jobs[blockIdx.x].debug;
+    const u32 debug = jobs[blockIdx.x].debug;  // 3: cycle counters instead of the first output bytes (profiling only)
     __shared__ CmLds m;
     __shared__ u32 ptab[2][256];  // (18-bit probability of node) << 14
+    __shared__ u32 s_ready[4];    // per model wave: 2i+1 = speculative table of byte i is there, 2i+2 = corrected one
+    __shared__ u32 s_done;        // ((i + 1) & 0xFFFFFF) << 8 | byte i, written by the walker
+    if (threadIdx.x < 4) s_ready[threadIdx.x] = 0;
+    if (threadIdx.x == 4) s_done = 0;
     cm_model_init(m);
-    if (debug == 1) {  // profiling mode "walk only": defined probabilities
-        ptab[0][threadIdx.x] = 1u << 31;
-        ptab[1][threadIdx.x] = 1u << 31;
-    }
-    __syncthreads();
+    if (n == 0) return;
     const int lane = lane_id();
-    const bool writer = cm_uniform((u32)wave_id()) == 3;
-    // model side: one tree node per lane; the node's C0 counter lives in a register
-    const u32 node = threadIdx.x;
-    const u32 lvl = node ? (u32)(31 - __clz((int)node)) : 0u;
-    const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
-    u32 c0 = 32768u, q_p1 = 0, q_w = 0, q_a1 = 0, q_ci = 0;
-    // walk side: lane l assumes bits b0..b5 = l; nbK = all-ones where the assumed bit of level K is 0
+    const u32 role = cm_uniform((u32)wave_id());
+    if (role != 0) {
+        // ---- model waves ------------------------------------------------------------------------------------
+        const u32 node = threadIdx.x - 64u;
+        const u32 lvl = node ? (u32)(31 - __clz((int)node)) : 0u;
+        const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
+        u32 c0 = 32768u;  // the node's C0 counter lives in a register
+        u64 prof_spec = 0, prof_wait = 0, prof_redo = 0, prof_miss = 0;
+        // byte 0: nothing to guess (c1 = c2 = 0, run = 1, :367-372)
+        CmEval prev = cm_evaluate(m, ptab[0], node, c0, node, m.c1[node], m.c1[node], 0u);
+        lds_release();
+        if (lane == 0) LDS_POKE(s_ready[role - 1], 2u);
+        u32 k1 = 0;        // newest confirmed byte (byte i-2 inside the loop; the initial c1 = 0 before the block starts)
+        u32 run_prev = 1;  // run counter the evaluation of byte i-1 was made with
+        for (u32 i = 1; i < n; i++) {
+            u64 t0 = 0, t1 = 0, t2 = 0;
+            if (debug == 3) t0 = cm_clock();
+            u32 * __restrict__ pt = ptab[i & 1u];
+            // -- speculate: byte i-1 == k1.  Update of byte i-1 (:396-399, :411-414; branch-free, see cm_upd) ...
+            const u32 g = k1;
+            const bool on_g = (hibit | (g >> shr)) == node;
+            const u32 c0_old = c0;
+            u32 cell = prev.p1;  // C1[k1][node]: byte i-1 was evaluated with c1 = k1, so this is the cell its update moves
+            if (on_g) {
+                const u32 mk = 0u - ((g >> bitpos) & 1u);
+                c0 = cm_upd(c0, 2, mk & 16383u);
+                cell = cm_upd(prev.p1, 4, mk & 4095u);
+                m.c1[prev.a1] = (u16)cell;
+                reinterpret_cast<PackedU32 *>(&m.c2[prev.ci])->v = cm_upd_pair6(prev.w, mk & 0x03FF03FFu);
+            }
+            // ... and the table of byte i with c1 = g, c2 = k1.  They are equal: both order-1 counters are `cell` (no LDS
+            // read), and the run counter goes up.
+            CmEval cur = cm_evaluate(m, pt, node, c0, prev.a1, cell, cell, run_prev + 1u > 2u ? 1u : 0u);
+            lds_release();
+            if (lane == 0) LDS_POKE(s_ready[role - 1], 2u * i + 1u);
+            if (debug == 3) t1 = cm_clock();
+            // -- the walker's verdict on byte i-1
+            u32 word;
+            const u32 tag = i & 0xFFFFFFu;
+            for (;;) {
+                word = cm_uniform(LDS_PEEK(s_done));
+                if ((word >> 8) == tag) break;
+                BZ3_SPIN_TIGHT();
+            }
+            const u32 c = word & 0xFFu;
+            if (debug == 3) t2 = cm_clock();
+            if (c != g) {
+                // wrong guess: put the old counters back (the old values are still in `prev`), apply the real update
+                // and evaluate again.  The new c1 row differs from the row being repaired, so its read goes first.
+                const u32 a1 = c * 256u + node;
+                const u32 p1 = m.c1[a1];
+                u32 cell2 = prev.p1;
+                if (on_g) {
+                    c0 = c0_old;
+                    reinterpret_cast<PackedU32 *>(&m.c2[prev.ci])->v = prev.w;
+                }
+                if ((hibit | (c >> shr)) == node) {
+                    const u32 mk = 0u - ((c >> bitpos) & 1u);
+                    c0 = cm_upd(c0, 2, mk & 16383u);
+                    cell2 = cm_upd(prev.p1, 4, mk & 4095u);
+                    reinterpret_cast<PackedU32 *>(&m.c2[prev.ci])->v = cm_upd_pair6(prev.w, mk & 0x03FF03FFu);
+                }
+                if (on_g || cell2 != prev.p1) m.c1[prev.a1] = (u16)cell2;
+                cur = cm_evaluate(m, pt, node, c0, a1, p1, cell2, 0u);  // c != k1: the run counter restarts
+                lds_release();
+                if (lane == 0) LDS_POKE(s_ready[role - 1], 2u * i + 2u);
+                run_prev = 0;
+                prof_miss++;
+            } else {
+                run_prev++;
+            }
+            prev = cur;
+            k1 = c;
+            if (debug == 3) {
+                const u64 t3 = cm_clock();
+                prof_spec += t1 - t0;
+                prof_wait += t2 - t1;
+                prof_redo += t3 - t2;
+            }
+        }
+        if (debug == 3 && n >= 256 && threadIdx.x == 64) {
+            u64 * o = reinterpret_cast<u64 *>(out) + 8;
+            o[0] = prof_spec;
+            o[1] = prof_wait;
+            o[2] = prof_redo;
+            o[3] = prof_miss;
+        }
+        return;
+    }
+    // ---- walker ---------------------------------------------------------------------------------------------
+    // lane l assumes bits b0..b5 = l; nbK = all-ones where the assumed bit of level K is 0
     const u32 ul = (u32)lane;
     const bool as0 = (ul >> 5) & 1u, as1 = (ul >> 4) & 1u, as2 = (ul >> 3) & 1u, as3 = (ul >> 2) & 1u, as4 = (ul >> 1) & 1u, as5 = ul & 1u;
     const u32 nb0 = (u32)as0 - 1u, nb1 = (u32)as1 - 1u, nb2 = (u32)as2 - 1u, nb3 = (u32)as3 - 1u, nb4 = (u32)as4 - 1u, nb5 = (u32)as5 - 1u;
     const u32 ix0 = 1u, ix1 = 2u | (ul >> 5), ix2 = 4u | (ul >> 4), ix3 = 8u | (ul >> 3), ix4 = 16u | (ul >> 2), ix5 = 32u | (ul >> 1);
     const u32 ix6 = 64u | ul, ix7 = 128u | (ul << 1);
-    u32 low_u = 0, range_u = 0xFFFFFFFFu, code = 0, c1 = 0, c2 = 0, run = 0;
+    u32 low_u = 0, range_u = 0xFFFFFFFFu, code = 0, c1 = 0, c2 = 0;
     u32 ip = 0, ibase = 0;
     u32 window = (ibase + lane < in_size) ? in[ibase + lane] : 0xFFFFFFFFu;
 #define CM_NEXT_BYTE(dst)                                                              \
@@ -546,11 +658,7 @@ __global__ void __launch_bounds__(256) k_cm_decode(const CmDecodeJob * __restric
 // ---- fast walk: no branches, no renormalisation ------------------------------------------------------------------
 // Works on d = code - low instead of low (the comparison becomes d <= t; equivalent as long as low <= code <= high,
 // which is checked per byte: a truncated stream feeds -1 bytes (:345) and can push `code` out of the interval; inside
-// it, d <= range holds along the true path, so the range never wraps there).  Every lane shifts
-// the outcome of its comparisons into `acc`; the lane whose `acc` spells its own number took no wrong turn
-// (induction over the levels: its first comparison used the true state), so it holds the true coder state.
-// Intervals are nested while nothing is renormalised, so "a renormalisation was due at some level" is equivalent to
-// "the final interval lies within one 2^24 bucket": one scalar test on the surviving lane's final state.
+// it, d <= range holds along the true path, so the range never wraps there).
 #define CM_FAST_SPEC(P, NB, AS)                                                                       \
     do {                                                                                              \
         const u32 keep_ = range & (NB);                                                               \
@@ -566,36 +674,33 @@ __global__ void __launch_bounds__(256) k_cm_decode(const CmDecodeJob * __restric
         const u32 t_ = (u32)(((u64)range * (P)) >> 32);                                               \
         BIT = d <= t_;                                                                                \
         cbits = cm_shift_in(cbits, __ballot(BIT), BIT);                                               \
-        range = BIT ? t_ : range + ~t_;                                                               \
+        range = BIT ? t_ : range + ~t_;                            /* t  |  range - t - 1 */          \
         d = BIT ? d : d + ~t_;                                                                        \
     } while (0)
     u32 staged = 0;
-    u64 prof_model = 0, prof_barrier = 0, prof_walk = 0, prof_update = 0, prof_slow = 0;  // debug == 3: cycles per phase
+    u64 prof_wait = 0, prof_walk = 0, prof_slow = 0, prof_miss = 0;  // debug == 3
     // One byte.  BUF (compile time) is the half of the double-buffered probability table this byte uses.
     auto decode_byte = [&](const u32 i, auto buf_tag) __attribute__((always_inline)) {
         constexpr u32 BUF = decltype(buf_tag)::value;
-        u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        u64 t0 = 0, t1 = 0;
         if (debug == 3) t0 = cm_clock();
-        run = (c1 == c2) ? run + 1 : 0;
-        const u32 f = run > 2 ? 1u : 0u;
-        u32 * __restrict__ pt = ptab[BUF];
-        if (debug != 1) {
-            // probabilities of all 255 nodes for this byte (:377-388); node 0 computes a dummy
-            q_a1 = c1 * 256u + node;
-            q_p1 = m.c1[q_a1];
-            const u32 p2 = m.c1[c2 * 256u + node];
-            const int p = (int)(((c0 + q_p1) * 7u + 2u * p2) >> 4);
-            q_ci = (2u * node + f) * CM_C2_STRIDE + (u32)(p >> 12);
-            q_w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[q_ci]));  // x1 | x2 << 16
-            const int x1 = (int)(q_w & 0xFFFFu), x2 = (int)(q_w >> 16);
-            const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);
-            pt[node] = (u32)(ssep * 3 + p) << 14;
+        // the table of byte i: the speculative one will do if byte i-1 repeated byte i-2 (that was the guess)
+        const bool hit = i >= 1u && c1 == c2;
+        const u32 needed = hit ? 2u * i + 1u : 2u * i + 2u;
+        for (;;) {
+            const u32 r0 = LDS_PEEK(s_ready[0]), r1 = LDS_PEEK(s_ready[1]), r2 = LDS_PEEK(s_ready[2]), r3 = LDS_PEEK(s_ready[3]);
+            const u32 ra = r0 < r1 ? r0 : r1, rb = r2 < r3 ? r2 : r3;
+            if (cm_uniform(ra < rb ? ra : rb) >= needed) break;
+            BZ3_SPIN_TIGHT();
         }
-        if (debug == 3) t1 = cm_clock();
-        __syncthreads();
-        if (debug == 3) t2 = cm_clock();
+        lds_acquire();
+        if (debug == 3) {
+            t1 = cm_clock();
+            prof_miss += hit ? 0u : 1u;
+        }
+        const u32 * __restrict__ pt = ptab[BUF];
         u32 c;
-        if (debug != 2) {
+        {
             const u32 P0 = pt[ix0], P1 = pt[ix1], P2 = pt[ix2], P3 = pt[ix3], P4 = pt[ix4], P5 = pt[ix5], P6 = pt[ix6];
             const u32 P7a = pt[ix7], P7b = pt[ix7 + 1u];
             u32 range = range_u, low;  // per-lane copies of the wave-uniform coder state
@@ -639,34 +744,19 @@ __global__ void __launch_bounds__(256) k_cm_decode(const CmDecodeJob * __restric
                 range_u = cm_readlane(range, w2);
                 c = cm_readlane((ul << 2) | ((u32)bit6 << 1) | (u32)bit7, w2);
             }
-        } else {
-            c = 'e';
         }
-        if (debug == 3) t3 = cm_clock();
-        if (writer) {  // wave 3: it has the least model work
-            if ((u32)lane == (i & 63u)) staged = c;
-            if ((i & 63u) == 63u || i + 1 == n) {
-                const u32 first = i & ~63u;
-                if (first + lane <= i) out[first + lane] = (u8)staged;
-            }
-        }
-        if (debug != 1) {
-            // the 8 lanes whose node is on the decoded path update their counters (branch-free, see cm_upd)
-            if ((hibit | (c >> shr)) == node) {
-                const u32 mk = 0u - ((c >> bitpos) & 1u);
-                c0 = cm_upd(c0, 2, mk & 16383u);
-                m.c1[q_a1] = (u16)cm_upd(q_p1, 4, mk & 4095u);
-                reinterpret_cast<PackedU32 *>(&m.c2[q_ci])->v = cm_upd_pair6(q_w, mk & 0x03FF03FFu);
-            }
+        if (lane == 0) LDS_POKE(s_done, (((i + 1u) & 0xFFFFFFu) << 8) | c);
+        if ((u32)lane == (i & 63u)) staged = c;
+        if ((i & 63u) == 63u || i + 1 == n) {
+            const u32 first = i & ~63u;
+            if (first + lane <= i) out[first + lane] = (u8)staged;
         }
         c2 = c1;
         c1 = c;
         if (debug == 3) {
-            const u64 t4 = cm_clock();
-            prof_model += t1 - t0;
-            prof_barrier += t2 - t1;
-            prof_walk += t3 - t2;
-            prof_update += t4 - t3;
+            const u64 t2 = cm_clock();
+            prof_wait += t1 - t0;
+            prof_walk += t2 - t1;
         }
     };
     u32 i = 0;
@@ -675,13 +765,12 @@ __global__ void __launch_bounds__(256) k_cm_decode(const CmDecodeJob * __restric
         decode_byte(i + 1, CmConst<1>{});
     }
     if (i < n) decode_byte(i, CmConst<0>{});
-    if (debug == 3 && n >= 64 && threadIdx.x == 0) {  // profiling only: the first 40 output bytes become the counters
+    if (debug == 3 && n >= 256 && lane == 0) {  // profiling only: output bytes 0..39 and 64..95 become counters
         u64 * o = reinterpret_cast<u64 *>(out);
-        o[0] = prof_model;
-        o[1] = prof_barrier;
-        o[2] = prof_walk;
-        o[3] = prof_update;
-        o[4] = prof_slow;
+        o[0] = prof_wait;
+        o[1] = prof_walk;
+        o[2] = prof_slow;
+        o[3] = prof_miss;
     }
 #undef CM_NEXT_BYTE
 #undef CM_RENORM
@@ -696,7 +785,7 @@ void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s) {
 }
 
 void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s) {
-    if (njobs) launch(k_cm_decode, dim3(njobs), dim3(256), 0, s, d_jobs);
+    if (njobs) launch(k_cm_decode, dim3(njobs), dim3(320), 0, s, d_jobs);
 }
 
 }  // namespace bz3

@@ -18,10 +18,12 @@
 #include "hip_emu.hpp"
 #define BZ3_DYN_SMEM(name) char * name = emu::dyn_smem()
 #define BZ3_SPIN_PAUSE() emu::yield()
+#define BZ3_SPIN_TIGHT() emu::yield()
 #else
 #include <hip/hip_runtime.h>
 #define BZ3_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define BZ3_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
+#define BZ3_SPIN_TIGHT() ((void)0)  // latency-critical hand-offs poll without sleeping
 #endif
 
 typedef uint8_t u8;

@@ -19,12 +19,13 @@ if "--decode-phases" in sys.argv:
     import struct
     os.environ["BZ3_CM_DEBUG"] = "3"
     t = time.time(); out = g.cm_decode(enc, n); dt = time.time() - t
-    v = struct.unpack("<5Q", out[:40])
-    names = ("model", "barrier", "walk", "update")
-    print(f"decode phases (wave 0, cycle counter ticks per byte; instrumented run {dt/n*1e9:.0f} ns/B): "
-          + "  ".join(f"{k} {x / n:.1f}" for k, x in zip(names, v)) + f"  slow-path bytes {v[4] / n * 100:.1f}%", flush=True)
+    w = struct.unpack("<4Q", out[:32])
+    m = struct.unpack("<4Q", out[64:96])
+    print(f"decode phases, cycle counter ticks per byte (instrumented run {dt/n*1e9:.0f} ns/B):\n"
+          f"   walker: wait for table {w[0]/n:.1f}  walk+publish {w[1]/n:.1f}  slow-path bytes {w[2]/n*100:.1f}%  wrong guesses {w[3]/n*100:.1f}%\n"
+          f"   model wave 1: speculate {m[0]/n:.1f}  wait for byte {m[1]/n:.1f}  undo+redo {m[2]/n:.1f}  wrong guesses {m[3]/n*100:.1f}%", flush=True)
     os.environ["BZ3_CM_DEBUG"] = "0"
-for mode in ("0", "1", "2", "0"):
+for mode in ("0", "0"):
     os.environ["BZ3_CM_DEBUG"] = mode
     t = time.time(); out = g.cm_decode(enc, n); dt = time.time() - t
     print(f"decode BZ3_CM_DEBUG={mode}: {dt*1e3:.0f} ms for {n} bytes = {dt/n*1e9:.0f} ns/B ({dt/n*2.4e9:.0f} cycles/B)", flush=True)
