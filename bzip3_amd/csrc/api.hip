@@ -353,9 +353,19 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     for (s32 i = 0; i < n; i++)
         if (sizes[i] > 0 && (u64)sizes[i] > n_max) n_max = (u64)sizes[i];
     const size_t ctx_bytes = lzp_encode_ctx_bytes(n_max + 64);
-    s32 window = (s32)(((size_t)40 << 30) / ctx_bytes);
+    // window = as many contexts as fit into half of the memory that is free right now (at most 64 blocks, 96 GB)
+    size_t budget = (size_t)40 << 30;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t have = lead->ctx->ws_cap;  // the arena already holds this much
+            budget = (free_b + have > need) ? (free_b + have - need) / 2 : 0;
+            if (budget > ((size_t)96 << 30)) budget = (size_t)96 << 30;
+        }
+    }
+    s32 window = (s32)(budget / (ctx_bytes + 65536));
     if (window < 1) window = 1;
-    if (window > 32) window = 32;
+    if (window > 64) window = 64;
     if (window > n) window = n;
     Arena arena = lead->ctx->arena_for(need + (size_t)window * (ctx_bytes + 65536) + (size_t)n * sizeof(CmEncodeJob) + 65536);
     CmEncodeJob * d_jobs = arena.take<CmEncodeJob>((size_t)n);

@@ -461,6 +461,15 @@ __device__ __forceinline__ u64 cm_clock() {
 #endif
 }
 
+__device__ __forceinline__ u32 cm_min4(u32 a, u32 b, u32 c, u32 d) {
+    const u32 x = a < b ? a : b, y = c < d ? c : d;
+    return x < y ? x : y;
+}
+#ifndef BZ3_EMU
+typedef u32 cm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32 cm_min4v(cm_u32x4 v) { return cm_min4(v.x, v.y, v.z, v.w); }
+#endif
+
 struct CmEval {  // what a model lane remembers of its node's last evaluation (the inputs of the counter update)
     u32 a1;  // index of C1[c1][node]
     u32 p1;  // its value
@@ -491,7 +500,7 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
     const u32 debug = jobs[blockIdx.x].debug;  // 3: cycle counters instead of the first output bytes (profiling only)
     __shared__ CmLds m;
     __shared__ u32 ptab[2][256];  // (18-bit probability of node) << 14
-    __shared__ u32 s_ready[4];    // per model wave: 2i+1 = speculative table of byte i is there, 2i+2 = corrected one
+    __shared__ __attribute__((aligned(16))) u32 s_ready[4];  // per model wave: 2i+1 = speculative table of byte i is there, 2i+2 = corrected one
     __shared__ u32 s_done;        // ((i + 1) & 0xFFFFFF) << 8 | byte i, written by the walker
     if (threadIdx.x < 4) s_ready[threadIdx.x] = 0;
     if (threadIdx.x == 4) s_done = 0;
@@ -509,7 +518,7 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
         // byte 0: nothing to guess (c1 = c2 = 0, run = 1, :367-372)
         CmEval prev = cm_evaluate(m, ptab[0], node, c0, node, m.c1[node], m.c1[node], 0u);
         lds_release();
-        if (lane == 0) LDS_POKE(s_ready[role - 1], 2u);
+        LDS_POKE(s_ready[role - 1], 2u);  // (every lane stores the same word: cheaper than masking the wave down to one lane)
         u32 k1 = 0;        // newest confirmed byte (byte i-2 inside the loop; the initial c1 = 0 before the block starts)
         u32 run_prev = 1;  // run counter the evaluation of byte i-1 was made with
         for (u32 i = 1; i < n; i++) {
@@ -532,7 +541,7 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
             // read), and the run counter goes up.
             CmEval cur = cm_evaluate(m, pt, node, c0, prev.a1, cell, cell, run_prev + 1u > 2u ? 1u : 0u);
             lds_release();
-            if (lane == 0) LDS_POKE(s_ready[role - 1], 2u * i + 1u);
+            LDS_POKE(s_ready[role - 1], 2u * i + 1u);
             if (debug == 3) t1 = cm_clock();
             // -- the walker's verdict on byte i-1
             u32 word;
@@ -563,7 +572,7 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
                 if (on_g || cell2 != prev.p1) m.c1[prev.a1] = (u16)cell2;
                 cur = cm_evaluate(m, pt, node, c0, a1, p1, cell2, 0u);  // c != k1: the run counter restarts
                 lds_release();
-                if (lane == 0) LDS_POKE(s_ready[role - 1], 2u * i + 2u);
+                LDS_POKE(s_ready[role - 1], 2u * i + 2u);
                 run_prev = 0;
                 prof_miss++;
             } else {
@@ -679,30 +688,33 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
     } while (0)
     u32 staged = 0;
     u64 prof_wait = 0, prof_walk = 0, prof_slow = 0, prof_miss = 0;  // debug == 3
-    // One byte.  BUF (compile time) is the half of the double-buffered probability table this byte uses.
+    u32 P0, P1, P2, P3, P4, P5, P6, P7a, P7b;  // this lane's slice of the table of the byte being decoded
+// min over the four model waves of what they have announced (one 16-byte LDS read)
+#ifdef BZ3_EMU
+#define CM_READY_MIN() cm_min4(s_ready[0], s_ready[1], s_ready[2], s_ready[3])
+#else
+#define CM_READY_MIN() cm_min4v(*(const volatile __attribute__((address_space(3))) cm_u32x4 *)(s_ready))  // LDS address space: ds_read_b128, not a flat load
+#endif
+// Wait until every model wave has announced at least `need`, then fetch this lane's nine probabilities from table BUF.
+// `seen` is an earlier CM_READY_MIN() (announcements only grow): when it already suffices nothing is polled.
+#define CM_FETCH_TABLE(BUF, seen, need)                                                               \
+    do {                                                                                              \
+        if (cm_uniform(seen) < (need)) {                                                              \
+            while (cm_uniform(CM_READY_MIN()) < (need)) BZ3_SPIN_TIGHT();                             \
+        }                                                                                             \
+        lds_acquire();                                                                                \
+        const u32 * __restrict__ pt_ = ptab[BUF];                                                     \
+        P0 = pt_[ix0]; P1 = pt_[ix1]; P2 = pt_[ix2]; P3 = pt_[ix3]; P4 = pt_[ix4]; P5 = pt_[ix5];     \
+        P6 = pt_[ix6]; P7a = pt_[ix7]; P7b = pt_[ix7 + 1u];                                           \
+    } while (0)
+    // One byte.  BUF (compile time) is the half of the double-buffered probability table this byte uses; its table
+    // has been fetched already, and the table of the next byte is fetched before the byte is stored.
     auto decode_byte = [&](const u32 i, auto buf_tag) __attribute__((always_inline)) {
         constexpr u32 BUF = decltype(buf_tag)::value;
         u64 t0 = 0, t1 = 0;
         if (debug == 3) t0 = cm_clock();
-        // the table of byte i: the speculative one will do if byte i-1 repeated byte i-2 (that was the guess)
-        const bool hit = i >= 1u && c1 == c2;
-        const u32 needed = hit ? 2u * i + 1u : 2u * i + 2u;
-        for (;;) {
-            const u32 r0 = LDS_PEEK(s_ready[0]), r1 = LDS_PEEK(s_ready[1]), r2 = LDS_PEEK(s_ready[2]), r3 = LDS_PEEK(s_ready[3]);
-            const u32 ra = r0 < r1 ? r0 : r1, rb = r2 < r3 ? r2 : r3;
-            if (cm_uniform(ra < rb ? ra : rb) >= needed) break;
-            BZ3_SPIN_TIGHT();
-        }
-        lds_acquire();
-        if (debug == 3) {
-            t1 = cm_clock();
-            prof_miss += hit ? 0u : 1u;
-        }
-        const u32 * __restrict__ pt = ptab[BUF];
-        u32 c;
+        u32 c, seen;
         {
-            const u32 P0 = pt[ix0], P1 = pt[ix1], P2 = pt[ix2], P3 = pt[ix3], P4 = pt[ix4], P5 = pt[ix5], P6 = pt[ix6];
-            const u32 P7a = pt[ix7], P7b = pt[ix7 + 1u];
             u32 range = range_u, low;  // per-lane copies of the wave-uniform coder state
             u32 d = code - low_u;
             const bool inside = d <= range_u;  // low <= code <= high: always, unless a truncated stream fed -1 bytes (:345)
@@ -720,6 +732,7 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
             const u32 P7f = bit6 ? P7b : P7a;
             CM_FAST_REAL(P7f, bit7);
             const int w = __ffsll((unsigned long long)ok) - 1;
+            seen = CM_READY_MIN();  // issued here, needed only after the byte is known: is the next table there already?
             const u32 low_f = code - cm_readlane(d, w), range_f = cm_readlane(range, w);
             if (__builtin_expect(inside && (low_f ^ (low_f + range_f)) >= (1u << 24), 1)) {
                 low_u = low_f;
@@ -745,20 +758,29 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
                 c = cm_readlane((ul << 2) | ((u32)bit6 << 1) | (u32)bit7, w2);
             }
         }
-        if (lane == 0) LDS_POKE(s_done, (((i + 1u) & 0xFFFFFFu) << 8) | c);
+        LDS_POKE(s_done, (((i + 1u) & 0xFFFFFFu) << 8) | c);  // every lane stores the same word: no EXEC juggling on the critical path
+        if (debug == 3) t1 = cm_clock();
+        c2 = c1;
+        c1 = c;
+        if (i + 1u < n) {
+            // The table of byte i+1: the speculative one will do if byte i repeated byte i-1 (that was the guess);
+            // otherwise the model waves announce a corrected one.
+            const bool hit = c1 == c2;
+            if (debug == 3) prof_miss += hit ? 0u : 1u;
+            CM_FETCH_TABLE(BUF ^ 1u, seen, 2u * (i + 1u) + (hit ? 1u : 2u));
+        }
         if ((u32)lane == (i & 63u)) staged = c;
         if ((i & 63u) == 63u || i + 1 == n) {
             const u32 first = i & ~63u;
             if (first + lane <= i) out[first + lane] = (u8)staged;
         }
-        c2 = c1;
-        c1 = c;
         if (debug == 3) {
             const u64 t2 = cm_clock();
-            prof_wait += t1 - t0;
-            prof_walk += t2 - t1;
+            prof_walk += t1 - t0;
+            prof_wait += t2 - t1;
         }
     };
+    CM_FETCH_TABLE(0, 0u, 2u);  // byte 0: nothing to guess
     u32 i = 0;
     for (; i + 1 < n; i += 2) {
         decode_byte(i, CmConst<0>{});
@@ -778,6 +800,8 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
 #undef CM_REAL_LEVEL
 #undef CM_FAST_SPEC
 #undef CM_FAST_REAL
+#undef CM_FETCH_TABLE
+#undef CM_READY_MIN
 }
 
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s) {

@@ -24,14 +24,14 @@ def frame_calls(L, bs, data, mutate=None, out_room=None):
     return rc, frame, rc2, C.string_at(back, bsz.value)
 
 
-def check(lib, five, bs):
+def check(lib, five, bs, only=None):
     """`five`: data that makes 5 chunks at block size bs (the last one short)."""
     ref = RefLib()
     if not ref.available:
         pytest.skip("oracle/_ref not built")
     assert 4 * bs < len(five) < 5 * bs
     exact = five[: 2 * bs]  # multiple of the block size: the (sic) empty last chunk of src/libbz3.c:914
-    for data in (five, exact, five[:100], b""):
+    for data in ((five, exact, five[:100], b"") if only is None else (five, exact)):
         a, b = frame_calls(lib, bs, data), frame_calls(ref.lib, bs, data)
         assert a == b, ("good frame", len(data), a[0], b[0], a[2], b[2])
 
@@ -54,6 +54,8 @@ def check(lib, five, bs):
             "n_blocks_9": poke32(9, 9), "n_blocks_max": poke32(9, 0xFFFFFFFF), "n_blocks_2": poke32(9, 2), "block_size_bad": poke32(5, 1000),
             "magic": flip(0)}
     for name, m in muts.items():
+        if only is not None and name not in only:
+            continue
         a, b = frame_calls(lib, bs, five, m), frame_calls(ref.lib, bs, five, m)
         assert a[2] == b[2] and a[3] == b[3], (name, a[2], b[2], len(a[3]), len(b[3]))
     a, b = frame_calls(lib, bs, five, None, out_room=3 * bs), frame_calls(ref.lib, bs, five, None, out_room=3 * bs)
