@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--block-mib", type=float, default=float(os.environ.get("BZ3_BENCH_BLOCK_MIB", "256")))
     ap.add_argument("--kind", default="text", choices=["text", "random"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-mib", type=float, default=16.0)
+    ap.add_argument("--cpu-sample-mib", type=float, default=32.0)
+    ap.add_argument("--cpu-threads", type=int, default=64)
     return ap.parse_args()
 
 
@@ -330,7 +331,7 @@ def main():
         }
         if not a.no_cpu_baseline:
             try:
-                ncores = min(os.cpu_count() or 1, 32)
+                ncores = max(1, min(os.cpu_count() or 1, a.cpu_threads))
                 smp = int(a.cpu_sample_mib * (1 << 20))
                 smp = min(smp, block_size)
                 host = bufs[0][:block_size].cpu().numpy().tobytes()
