@@ -149,6 +149,17 @@ def test_corrupted_payload_error_codes_match_reference(oracle, ref_lib, text):
                 assert oracle.decode_block(m, len(data), bs)[:2] == ref_lib.decode_block(m, len(data), bs)[:2], (pos, bit)
 
 
+def test_mutated_blocks_decode_like_the_reference(oracle, ref_lib):
+    """1500 mutated blocks (tests/mutants.py): return value, last_error and the decoded bytes equal the reference's."""
+    import mutants
+
+    data = mutants.seeds()
+    blocks = [oracle.encode_block(d, mutants.BS)[2] for d in data]
+    for m, osz in mutants.mutants(blocks, [len(d) for d in data], 1500):
+        a, b = oracle.decode_block(m, osz, mutants.BS), ref_lib.decode_block(m, osz, mutants.BS)
+        assert a[:2] == b[:2] and (a[0] < 0 or a[2] == b[2]), (len(m), osz, a[:2], b[:2])
+
+
 def test_oracle_builds_without_reference_tree():
     # the restatement itself must not depend on /root/reference (absent on the GPU box)
     src = open(os.path.join(ORACLE_DIR, "bz3_oracle.c")).read()
