@@ -132,6 +132,41 @@ def test_corrupted_payload_error_codes(gpu_lib, oracle, text):
                     assert st.decode_block(m, len(data))[:2] == oracle.decode_block(m, len(data), bs)[:2], (len(data), pos, bit)
 
 
+def test_random_mixtures_encode_identically(gpu_lib, oracle):
+    """40 random concatenations of text / runs / repeats / noise / low-entropy pieces (sizes 0 .. 300 KB): the encoded block
+    is byte-identical to the oracle's and decodes back (every stage flag combination of :609-632 shows up)."""
+    rng = np.random.default_rng(77)
+    bs = 320 * 1024
+    text = datagen.shakespeare()
+    models = set()
+    with bzip3_amd.State(bs, gpu_lib) as st:
+        for trial in range(40):
+            parts = []
+            for _ in range(int(rng.integers(1, 6))):
+                n = int(rng.integers(0, 60000))
+                kind = int(rng.integers(0, 6))
+                if kind == 0:
+                    o = int(rng.integers(0, len(text) - n)); parts.append(text[o : o + n])
+                elif kind == 1:
+                    parts.append(bytes([int(rng.integers(0, 256))]) * n)
+                elif kind == 2:
+                    unit = bytes(rng.integers(0, 256, size=int(rng.integers(1, 300)), dtype=np.uint8)); parts.append((unit * (n // len(unit) + 1))[:n])
+                elif kind == 3:
+                    parts.append(bytes(rng.integers(0, 256, size=n, dtype=np.uint8)))
+                elif kind == 4:
+                    parts.append(bytes(rng.choice(np.array([0xF2, 0xFF, 0, 65], dtype=np.uint8), size=n)))
+                else:
+                    parts.append(datagen.low_entropy(n) if n else b"")
+            d = b"".join(parts)[: bs]
+            a, b = st.encode_block(d), oracle.encode_block(d, bs)
+            assert a == b, (trial, len(d))
+            if a[0] > 8 and len(d) >= 64:
+                models.add(a[2][8])
+            k, err, back = st.decode_block(a[2], len(d))
+            assert (err == 0 and back == d) or len(d) == 0, (trial, len(d))
+    assert len(models) >= 3, models
+
+
 def test_mutated_blocks_decode_like_the_reference(gpu_lib, oracle):
     """Decoder hardening: 800 mutated blocks through the GPU path; return value, last_error and decoded
     bytes equal the oracle's, which test_oracle.py pins against the real reference on the same generator (1500 mutants)."""
