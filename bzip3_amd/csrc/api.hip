@@ -45,6 +45,7 @@ struct DeviceCtx {
     CrcTables * d_crc = nullptr;
     char * ws = nullptr;
     size_t ws_cap = 0;
+    int cus = 256;          // compute units: one full-model CM workgroup fits per CU
 
     Arena arena_for(size_t bytes) {  // caller holds mu
         if (bytes > ws_cap) {
@@ -68,6 +69,7 @@ std::vector<DeviceCtx *> g_ctx;
 int g_device_count = -1;
 std::atomic<int> g_bound_device{-2};  // -2 = not initialised from the environment yet, -1 = round robin
 std::atomic<unsigned> g_rr{0};
+std::atomic<unsigned> g_cm_given_up{0};  // blocks the row-cache CM kernels handed back to the full-model kernels (statistics)
 
 int device_count() {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -93,6 +95,10 @@ DeviceCtx * get_ctx(int dev) {
         crc_build_tables(t);
         HIP_CHECK(hipMalloc((void **)&c->d_crc, sizeof(CrcTables)));
         HIP_CHECK(hipMemcpy(c->d_crc, &t, sizeof t, hipMemcpyHostToDevice));
+#ifndef BZ3_EMU
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) c->cus = cus;
+#endif
         g_ctx[dev] = c;
     }
     return g_ctx[dev];
@@ -117,6 +123,83 @@ size_t workspace_bytes_for(u64 n) {
     size_t c = (size_t)n * 26 + radix_temp_bytes(n) + (4u << 20);  // LZP: prev, mlen, bitmap, sort buffers
     size_t m = a > b ? a : b;
     return m > c ? m : c;
+}
+
+// ---- CM kernel variant -------------------------------------------------------------------------------
+// The full-model CM kernels need a whole CU's LDS per block; the row-cache kernels (cm.hip) need half of it, so two
+// blocks share a CU, but they give up blocks whose order-1 working set does not fit (binary data).  Policy
+// (BZ3_HIP_CM_MODE=auto|full|rows, bz3_hip_set_cm_mode): auto = row-cache kernels only when a batch has more blocks
+// than the GPU has CUs -- with fewer, every block gets a CU of its own anyway.
+std::atomic<int> g_cm_mode{-2};  // -2 = not read from the environment yet, -1 = auto, else CM_VARIANT_*
+
+int cm_mode() {
+    int m = g_cm_mode.load();
+    if (m == -2) {
+        const char * e = getenv("BZ3_HIP_CM_MODE");
+        m = -1;
+        if (e && !strcmp(e, "full")) m = CM_VARIANT_FULL;
+        else if (e && !strcmp(e, "rows")) m = CM_VARIANT_ROWS;
+#ifdef BZ3_EMU
+        else if (e && !strcmp(e, "rows-test")) m = CM_VARIANT_ROWS_TEST;
+#endif
+        g_cm_mode.store(m);
+    }
+    return m;
+}
+
+int cm_variant_for(const DeviceCtx * ctx, size_t njobs) {
+    const int m = cm_mode();
+    if (m >= 0) return m;
+    return njobs > (size_t)ctx->cus ? CM_VARIANT_ROWS : CM_VARIANT_FULL;
+}
+
+size_t cm_scratch_bytes(size_t njobs) { return njobs * (CM_SPILL_BYTES + 256) + 4096; }
+
+// Runs the CM kernel over `jobs` (host copies; d_jobs has room for all of them) and returns the kernel time in ms.
+// Row-cache variants: blocks the kernel gave up are coded again by the full-model kernel in a second launch.
+template <class Job, class Launch>
+float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs, Job * d_jobs, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, Launch && go) {
+    if (jobs.empty()) return 0.f;
+    const int variant = cm_variant_for(ctx, jobs.size());
+    const size_t mk = arena.mark();
+    u32 * d_status = nullptr;
+    if (variant != CM_VARIANT_FULL) {
+        u8 * spill = arena.take<u8>(jobs.size() * CM_SPILL_BYTES);
+        d_status = arena.take<u32>(jobs.size());
+        HIP_CHECK(hipMemsetAsync(d_status, 0, jobs.size() * 4, s));
+        for (size_t i = 0; i < jobs.size(); i++) {
+            jobs[i].spill = dev_addr(spill + i * CM_SPILL_BYTES);
+            jobs[i].status = dev_addr(d_status + i);
+            jobs[i].miss_base = variant == CM_VARIANT_ROWS_TEST ? 64u : 256u;
+            jobs[i].miss_shift = variant == CM_VARIANT_ROWS_TEST ? 3u : 8u;  // give up beyond 0.4 % misses (test variant: 12.5 %)
+        }
+    }
+    float ms = 0.f, ms2 = 0.f;
+    HIP_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipEventRecord(ev0, s));
+    go(d_jobs, (u32)jobs.size(), s, variant);
+    HIP_CHECK(hipEventRecord(ev1, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    if (variant != CM_VARIANT_FULL) {
+        std::vector<u32> status(jobs.size());
+        HIP_CHECK(hipMemcpyAsync(status.data(), d_status, jobs.size() * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        std::vector<Job> again;
+        for (size_t i = 0; i < jobs.size(); i++)
+            if (status[i]) again.push_back(jobs[i]);
+        g_cm_given_up.fetch_add((unsigned)again.size());
+        if (!again.empty()) {
+            HIP_CHECK(hipMemcpyAsync(d_jobs, again.data(), sizeof(Job) * again.size(), hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipEventRecord(ev0, s));
+            go(d_jobs, (u32)again.size(), s, (int)CM_VARIANT_FULL);
+            HIP_CHECK(hipEventRecord(ev1, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            (void)hipEventElapsedTime(&ms2, ev0, ev1);
+        }
+    }
+    arena.release(mk);
+    return ms + ms2;
 }
 
 // ---- small kernels of the orchestration layer ---------------------------------------------------
@@ -367,7 +450,7 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     if (window < 1) window = 1;
     if (window > 64) window = 64;
     if (window > n) window = n;
-    Arena arena = lead->ctx->arena_for(need + (size_t)window * (ctx_bytes + 65536) + (size_t)n * sizeof(CmEncodeJob) + 65536);
+    Arena arena = lead->ctx->arena_for(need + (size_t)window * (ctx_bytes + 65536) + (size_t)n * sizeof(CmEncodeJob) + cm_scratch_bytes((size_t)n) + 65536);
     CmEncodeJob * d_jobs = arena.take<CmEncodeJob>((size_t)n);
     std::vector<CmEncodeJob> jobs;
     for (s32 w0 = 0; w0 < n; w0 += window) {
@@ -395,16 +478,8 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         }
         arena.release(mk);
     }
-    float cm_ms = 0.f;
-    if (!jobs.empty()) {
-        hipStream_t s = lead->stream;
-        HIP_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(CmEncodeJob) * jobs.size(), hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipEventRecord(lead->ev0, s));
-        cm_encode_batch(d_jobs, (u32)jobs.size(), s);
-        HIP_CHECK(hipEventRecord(lead->ev1, s));
-        HIP_CHECK(hipStreamSynchronize(s));
-        (void)hipEventElapsedTime(&cm_ms, lead->ev0, lead->ev1);
-    }
+    const float cm_ms = run_cm_jobs(lead->ctx, arena, jobs, d_jobs, lead->stream, lead->ev0, lead->ev1,
+                                    [](const CmEncodeJob * j, u32 nj, hipStream_t st, int variant) { cm_encode_batch(j, nj, st, variant); });
     for (s32 i = 0; i < n; i++) encode_finish(sts[i], cm_ms);
 }
 
@@ -579,16 +654,12 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     size_t n_lzp = 0;
     for (s32 i = 0; i < n; i++)
         if (sts[i]->pending == bz3_state::DEC_CODED && (sts[i]->model & 2)) n_lzp++;
-    Arena arena = lead->ctx->arena_for(need + n_lzp * LZP_LUT_WORDS * 4 + (size_t)n * 256 + 4096);
+    Arena arena = lead->ctx->arena_for(need + n_lzp * LZP_LUT_WORDS * 4 + (size_t)n * 256 + cm_scratch_bytes((size_t)n) + 4096);
     float cm_ms = 0.f;
     if (!cm_jobs.empty()) {
         CmDecodeJob * d_jobs = arena.take<CmDecodeJob>(cm_jobs.size());
-        HIP_CHECK(hipMemcpyAsync(d_jobs, cm_jobs.data(), sizeof(CmDecodeJob) * cm_jobs.size(), hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipEventRecord(lead->ev0, s));
-        cm_decode_batch(d_jobs, (u32)cm_jobs.size(), s);
-        HIP_CHECK(hipEventRecord(lead->ev1, s));
-        HIP_CHECK(hipStreamSynchronize(s));
-        (void)hipEventElapsedTime(&cm_ms, lead->ev0, lead->ev1);
+        cm_ms = run_cm_jobs(lead->ctx, arena, cm_jobs, d_jobs, s, lead->ev0, lead->ev1,
+                            [](const CmDecodeJob * j, u32 nj, hipStream_t st, int variant) { cm_decode_batch(j, nj, st, variant); });
     }
     // ---- phase 2: inverse BWT per block; collect the LZP jobs --------------------------------------------
     std::vector<LzpDecodeJob> lz_jobs;
@@ -1038,6 +1109,19 @@ BZIP3_API int bz3_hip_bind_device(int device) {
 
 BZIP3_API int bz3_hip_state_device(struct bz3_state * st) { return st->device; }
 
+BZIP3_API int bz3_hip_set_cm_mode(int mode) {
+#ifdef BZ3_EMU
+    const int top = CM_VARIANT_ROWS_TEST;
+#else
+    const int top = CM_VARIANT_ROWS;
+#endif
+    if (mode < -1 || mode > top) return -1;
+    g_cm_mode.store(mode);
+    return 0;
+}
+
+BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void) { return g_cm_given_up.load(); }
+
 BZIP3_API void bz3_hip_last_timings(struct bz3_state * st, float ms[BZ3_HIP_T_COUNT]) {
     for (int i = 0; i < BZ3_HIP_T_COUNT; i++) ms[i] = st->t[i];
 }
@@ -1208,6 +1292,28 @@ BZIP3_API int32_t bz3_hip_stage_unbwt(const uint8_t * in, uint8_t * out, int32_t
     });
 }
 
+// One CM job through the variant the current mode selects (auto = full model for a single block); a block the
+// row-cache kernel gives up is coded again by the full-model kernel, as in run_cm_jobs.
+extern "C++" template <class Job, class Launch>
+void stage_cm_job(StageEnv & e, Job job, Launch && go) {
+    const int variant = cm_variant_for(e.ctx, 1);
+    u32 * status = nullptr;
+    if (variant != CM_VARIANT_FULL) {
+        job.spill = dev_addr(e.dev(CM_SPILL_BYTES));
+        status = (u32 *)e.dev(64);
+        HIP_CHECK(hipMemset(status, 0, 64));
+        job.status = dev_addr(status);
+        job.miss_base = variant == CM_VARIANT_ROWS_TEST ? 64u : 256u;
+        job.miss_shift = variant == CM_VARIANT_ROWS_TEST ? 3u : 8u;
+    }
+    Job * d_job = (Job *)e.dev(sizeof job, &job, sizeof job);
+    go(d_job, 1u, e.s, variant);
+    if (variant != CM_VARIANT_FULL && e.word(status) != 0u) {
+        g_cm_given_up.fetch_add(1u);
+        go(d_job, 1u, e.s, (int)CM_VARIANT_FULL);
+    }
+}
+
 BZIP3_API int32_t bz3_hip_stage_cm_encode(const uint8_t * in, int32_t n, uint8_t * out) {
     return stage_guard([&]() -> s32 {
         StageEnv e;
@@ -1216,8 +1322,7 @@ BZIP3_API int32_t bz3_hip_stage_cm_encode(const uint8_t * in, int32_t n, uint8_t
         u32 * w = (u32 *)e.dev(64);
         const char * dbg = getenv("BZ3_CM_DEBUG");  // profiling only: 1 = coder alone, 2 = model alone (output invalid)
         CmEncodeJob job{dev_addr(d), dev_addr(o), dev_addr(w), (u32)n, dbg ? (u32)atoi(dbg) : 0u};
-        CmEncodeJob * d_job = (CmEncodeJob *)e.dev(sizeof job, &job, sizeof job);
-        cm_encode_batch(d_job, 1, e.s);
+        stage_cm_job(e, job, [](const CmEncodeJob * j, u32 nj, hipStream_t st, int variant) { cm_encode_batch(j, nj, st, variant); });
         const s32 size = (s32)e.word(w);
         e.down(out, o, (size_t)size);
         return size;
@@ -1231,8 +1336,7 @@ BZIP3_API void bz3_hip_stage_cm_decode(const uint8_t * in, int32_t in_size, uint
         u8 * o = e.dev((size_t)n + 64);
         const char * dbg = getenv("BZ3_CM_DEBUG");  // profiling only (output invalid)
         CmDecodeJob job{dev_addr(d), dev_addr(o), (u32)in_size, (u32)n, dbg ? (u32)atoi(dbg) : 0u, 0u};
-        CmDecodeJob * d_job = (CmDecodeJob *)e.dev(sizeof job, &job, sizeof job);
-        cm_decode_batch(d_job, 1, e.s);
+        stage_cm_job(e, job, [](const CmDecodeJob * j, u32 nj, hipStream_t st, int variant) { cm_decode_batch(j, nj, st, variant); });
         e.down(out, o, (size_t)n);
         return 0;
     });

@@ -23,11 +23,16 @@ namespace bz3 {
 
 constexpr int CM_C2_STRIDE = 17;
 
-struct CmLds {
-    u16 c1[256 * 256];
+// R = 0: the whole order-1 table (256 rows) in LDS, one block per CU.  R > 0: only R rows of the order-1 table are
+// resident ("row cache", see below), so that two workgroups share a CU's LDS.
+template <int R>
+struct CmLdsT {
+    static constexpr int ROWS = R ? R : 256;
+    u16 c1[ROWS * 256];
     u16 c0[256];
     u16 c2[512 * CM_C2_STRIDE];
 };
+using CmLds = CmLdsT<0>;
 
 __device__ __forceinline__ u32 cm_readlane(u32 v, int lane) {
 #ifdef BZ3_EMU
@@ -47,8 +52,9 @@ __device__ __forceinline__ u32 cm_uniform(u32 v) {
 #endif
 }
 
-__device__ __forceinline__ void cm_model_init(CmLds & m) {  // begin(): :350-358
-    for (int i = threadIdx.x; i < 256 * 256; i += blockDim.x) m.c1[i] = 32768;
+template <class M>
+__device__ __forceinline__ void cm_model_init(M & m) {  // begin(): :350-358
+    for (int i = threadIdx.x; i < M::ROWS * 256; i += blockDim.x) m.c1[i] = 32768;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) m.c0[i] = 32768;
     for (int i = threadIdx.x; i < 512 * CM_C2_STRIDE; i += blockDim.x) {
         const int k = i % CM_C2_STRIDE;
@@ -137,6 +143,85 @@ constexpr u32 CM_CHUNK = 32;  // bytes per model-wave chunk
 #define LDS_POKE(var, v) __hip_atomic_store(&(var), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #endif
 
+// ------------------------------------------------------------------------------------------------
+// Row cache (R > 0 kernels).  C1[c][node] is indexed by the previous byte c, and a block only ever touches the rows
+// of byte values it contains: BWT output of text uses ~64 values for 99.9 % of its bytes.  The R > 0 kernels keep R
+// rows in LDS and the others in a per-block 128 KiB spill area in global memory (u16[256][256]), so that TWO
+// workgroups fit into one CU's LDS and the latency-bound coder recurrences of two blocks interleave on one CU.
+// The cache is exact (it only decides where a row lives).  Every model lane owns the same tree node(s) in every
+// row, so a wave moves its own 64 (128) cells of a row with one coalesced global store + load and never needs the
+// other waves: each model wave keeps a PRIVATE copy of the cache directory and, because all of them see the same
+// byte sequence, they make the same decisions (slots are handed out in order of first use, then recycled FIFO,
+// skipping the rows the bytes in flight still need).
+// A block whose working set does not fit (binary data: 256 live rows) would thrash; the kernels count misses and
+// give the block up once misses > miss_base + (position >> miss_shift) -- status word = 1 -- and the host codes it
+// again with the R = 0 kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr u32 CM_ROW_SPILLED = 0xFEu;   // row_of[]: the row lives in the spill area
+constexpr u32 CM_ROW_VIRGIN = 0xFFu;    // row_of[]: never touched, every counter still 32768
+constexpr u32 CM_ABORT_MARK = 0xFFFFFFFEu;  // published instead of a position by a model wave that gave the block up
+
+template <int R>
+struct CmRowCache {
+    static constexpr int SLOTS = R ? R : 1;
+    u8 row_of[256];     // byte value -> slot | CM_ROW_SPILLED | CM_ROW_VIRGIN
+    u8 sym_of[SLOTS];   // slot -> byte value
+    u32 stamp[SLOTS];   // slot is pinned while stamp == the wave's current tick
+};
+
+struct CmRowState {  // wave-uniform registers of a model wave
+    u32 nused = 1;   // slots handed out so far (slot 0 = byte value 0: the context before the block starts, :367)
+    u32 hand = 0;    // FIFO pointer
+    u32 misses = 0;
+    u32 tick = 0;
+};
+
+template <int R>
+__device__ __forceinline__ void cm_rows_init(CmRowCache<R> & rc) {  // by one wave, for its own directory
+    const int lane = lane_id();
+    for (int i = lane; i < 256; i += WAVE) rc.row_of[i] = (u8)(i == 0 ? 0u : CM_ROW_VIRGIN);
+    for (int i = lane; i < CmRowCache<R>::SLOTS; i += WAVE) {
+        rc.sym_of[i] = 0;
+        rc.stamp[i] = 0;
+    }
+    wave_sync();
+}
+
+// Makes the row of byte value `sym` (state `st` = CM_ROW_SPILLED / CM_ROW_VIRGIN) resident and returns its slot.
+// NODES = tree nodes per lane (node0, node0 + 64).  Wave-uniform control flow; every lane moves its own cells.
+template <int R, int NODES, class M>
+__device__ __forceinline__ u32 cm_rows_fetch(M & m, CmRowCache<R> & rc, CmRowState & rs, u16 * __restrict__ spill, u32 sym, u32 st, u32 node0) {
+    const int lane = lane_id();
+    u32 slot, victim = 0;
+    const bool recycle = rs.nused >= (u32)R;
+    if (!recycle) {
+        slot = rs.nused++;
+    } else {
+        for (;;) {
+            slot = rs.hand;
+            rs.hand = rs.hand + 1u == (u32)R ? 0u : rs.hand + 1u;
+            if (cm_uniform(rc.stamp[slot]) != rs.tick) break;
+        }
+        victim = cm_uniform((u32)rc.sym_of[slot]);
+    }
+    wave_sync();  // every lane has read the directory before lane 0 changes it
+#pragma unroll
+    for (int k = 0; k < NODES; k++) {
+        const u32 cell = slot * 256u + node0 + 64u * (u32)k;
+        if (recycle) spill[victim * 256u + node0 + 64u * (u32)k] = m.c1[cell];
+        m.c1[cell] = st == CM_ROW_SPILLED ? spill[sym * 256u + node0 + 64u * (u32)k] : (u16)32768;
+    }
+    if (lane == 0) {
+        if (recycle) rc.row_of[victim] = (u8)CM_ROW_SPILLED;
+        rc.row_of[sym] = (u8)slot;
+        rc.sym_of[slot] = (u8)sym;
+        rc.stamp[slot] = rs.tick;
+    }
+    rs.misses++;
+    wave_sync();
+    return slot;
+}
+
 struct CmEvent {  // what the chain loop leaves for the event loop
     u32 px1;      // p | x1 << 16
     u32 x2b;      // x2 | bit << 16
@@ -162,8 +247,8 @@ __device__ __forceinline__ u32 cm_upd_pair6(u32 w, u32 k2) {
 }
 
 // One byte of the chain: wave-uniform (c, c1 << 8, c2 << 8, f) and the lanes of this wave whose node is on the path.
-template <int NSLOT>
-__device__ __forceinline__ void cm_chain_step(CmLds & m, CmEvent * __restrict__ ev_row, const CmLane & L, u32 c, u32 c1s, u32 c2s, u32 f,
+template <int NSLOT, class M>
+__device__ __forceinline__ void cm_chain_step(M & m, CmEvent * __restrict__ ev_row, const CmLane & L, u32 c, u32 c1s, u32 c2s, u32 f,
                                               u32 (&c0)[NSLOT]) {
     const u32 path = L.hibit | (c >> L.shr);  // the node of this lane's level on this byte's path
     bool hit = path == L.node;
@@ -198,8 +283,8 @@ __device__ __forceinline__ void cm_chain_step(CmLds & m, CmEvent * __restrict__ 
 }
 
 // One chunk of one model wave.  NSLOT = nodes per lane (1 or 2).  lvl_lo / nlvl = tree levels this wave owns.
-template <int NSLOT, bool FULL>
-__device__ __forceinline__ void cm_model_chunk(CmLds & m, CmEvent * __restrict__ ev, uint4 * __restrict__ ring, const u32 packed, const u32 fmask,
+template <int NSLOT, bool FULL, class M>
+__device__ __forceinline__ void cm_model_chunk(M & m, CmEvent * __restrict__ ev, uint4 * __restrict__ ring, const u32 packed, const u32 fmask,
                                                const u32 cnt, const u32 base, const CmLane & L, const u32 lvl_lo, const u32 nlvl, u32 (&c0)[NSLOT]) {
     const int lane = lane_id();
     CmEvent * __restrict__ ev_lvl = ev + (L.lvl - lvl_lo) * CM_CHUNK;
@@ -207,7 +292,7 @@ __device__ __forceinline__ void cm_model_chunk(CmLds & m, CmEvent * __restrict__
     if (FULL) {
 #pragma unroll
         for (int r = 0; r < (int)CM_CHUNK; r++) {
-            const u32 w = cm_readlane(packed, r);  // byte r | byte r-1 << 8 | byte r-2 << 16   (wave-uniform)
+            const u32 w = cm_readlane(packed, r);  // byte r | row of byte r-1 << 8 | row of byte r-2 << 16   (wave-uniform; row = byte value when R = 0)
             cm_chain_step<NSLOT>(m, ev_lvl + r, L, w & 0xFFu, w & 0xFF00u, (w >> 8) & 0xFF00u, (fmask >> r) & 1u, c0);
         }
     } else {
@@ -272,17 +357,51 @@ __device__ __forceinline__ void cm_code_bits_checked(const uint4 (&ev)[8], u32 &
     }
 }
 
-__global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restrict__ jobs) {
+// Brings the rows of a chunk's bytes into the cache (R > 0).  mine = this lane's byte (lanes < cnt), hrow1 / hrow2 =
+// slots of the two bytes before the chunk.  Returns the slot of this lane's byte.  The rows the chunk itself and the
+// two history bytes refer to are pinned (stamped with the chunk's tick) before any slot is recycled.
+template <int R, int NODES, class M>
+__device__ __forceinline__ u32 cm_rows_chunk(M & m, CmRowCache<R> & rc, CmRowState & rs, u16 * __restrict__ spill, u32 mine, u32 cnt, u32 hrow1, u32 hrow2,
+                                             u32 node0) {
+    const int lane = lane_id();
+    const bool live = (u32)lane < cnt;
+    u32 rowv = live ? (u32)rc.row_of[mine] : 0u;
+    u64 miss = __ballot(live && rowv >= CM_ROW_SPILLED);
+    if (__builtin_expect(miss != 0ull, 0)) {
+        rs.tick++;
+        if (live && rowv < CM_ROW_SPILLED) rc.stamp[rowv] = rs.tick;
+        if (lane == 0) {
+            rc.stamp[hrow1] = rs.tick;
+            rc.stamp[hrow2] = rs.tick;
+        }
+        wave_sync();
+        while (miss != 0ull) {
+            const int l = __ffsll((unsigned long long)miss) - 1;
+            const u32 sym = cm_readlane(mine, l);
+            const u32 st = cm_uniform((u32)rc.row_of[sym]);
+            const u32 slot = cm_rows_fetch<R, NODES>(m, rc, rs, spill, sym, st, node0);
+            const bool same = live && mine == sym;
+            rowv = same ? slot : rowv;
+            miss &= ~__ballot(same);
+        }
+    }
+    return rowv;
+}
+
+// One block.  R = 0: whole model in LDS; R > 0: row cache (see above).
+template <int R>
+__device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__ jobs) {
     // one workgroup per block: blockIdx.x selects the job
     const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 n = jobs[blockIdx.x].n;
     u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
     u32 * __restrict__ out_size = global_ptr<u32>(jobs[blockIdx.x].out_size);
     const u32 debug = jobs[blockIdx.x].debug;
-    __shared__ CmLds m;
+    __shared__ CmLdsT<R> m;
     __shared__ uint4 ring[CM_RING * 8];
     __shared__ CmEvent ev_a[6 * CM_CHUNK], ev_b[CM_CHUNK], ev_c[CM_CHUNK];
     __shared__ u32 s_prod[3], s_cons;
+    __shared__ CmRowCache<R> rcs[R ? 3 : 1];  // R > 0: one private directory per model wave
     if (threadIdx.x < 3) s_prod[threadIdx.x] = 0;
     if (threadIdx.x == 3) s_cons = 0;
     if (debug == 1)  // profiling only: a ring full of p = 1/2 events, so the lone coder emits exactly one byte per input byte
@@ -305,6 +424,13 @@ __global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restric
         u32 c0a[1] = {32768u}, c0b[2] = {32768u, 32768u};  // C0 of this lane's node(s) lives in registers
         u32 cons_seen = 0;
         u32 hist = 0;  // the 4 bytes before the chunk, oldest in the top byte (zeros before the block starts)
+        // R > 0: row cache of this wave
+        CmRowCache<R> & rc = rcs[R ? role - 1 : 0];
+        CmRowState rs;
+        u16 * __restrict__ spill = global_ptr<u16>(jobs[blockIdx.x].spill);
+        const u32 miss_base = jobs[blockIdx.x].miss_base, miss_shift = jobs[blockIdx.x].miss_shift;
+        u32 hrow1 = 0, hrow2 = 0;  // slots of bytes -1 and -2 (byte value 0 before the block starts: slot 0)
+        if (R) cm_rows_init<R>(rc);
         for (u32 base = 0; base < n; base += CM_CHUNK) {
             const u32 cnt = (n - base < CM_CHUNK) ? n - base : CM_CHUNK;
             while (debug != 2 && base + cnt - cons_seen > CM_RING) {  // ring full: wait for the coder
@@ -313,6 +439,17 @@ __global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restric
             }
             // lane r holds byte r of the chunk together with its 4 predecessors
             const u32 mine = ((u32)lane < cnt) ? in[base + lane] : 0u;
+            u32 rowv = 0;
+            if (R) {
+                rowv = role == 3 ? cm_rows_chunk<R, 2>(m, rc, rs, spill, mine, cnt, hrow1, hrow2, L.node)
+                                 : cm_rows_chunk<R, 1>(m, rc, rs, spill, mine, cnt, hrow1, hrow2, L.node);
+                if (__builtin_expect(rs.misses > miss_base + (base >> miss_shift), 0)) {
+                    // the working set does not fit: give the block up (every model wave gets here at the same chunk)
+                    if (role == 1 && lane == 0) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
+                    LDS_POKE(s_prod[role - 1], CM_ABORT_MARK);
+                    return;
+                }
+            }
             u32 prev4 = 0;  // bytes r-1, r-2, r-3, r-4 in bits 0-7, 8-15, 16-23, 24-31
 #pragma unroll
             for (int d = 1; d <= 4; d++) {
@@ -321,7 +458,13 @@ __global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restric
                 const u32 h = (hist >> (8u * (((u32)d - 1u - (u32)lane) & 3u))) & 0xFFu;
                 prev4 |= (((u32)lane >= (u32)d) ? up : h) << (8 * (d - 1));
             }
-            const u32 packed = mine | ((prev4 & 0xFFFFu) << 8);
+            u32 packed = mine | ((prev4 & 0xFFFFu) << 8);
+            if (R) {  // the chain indexes C1 by slot, not by byte value
+                u32 r1 = __shfl_up(rowv, 1u), r2 = __shfl_up(rowv, 2u);
+                r1 = lane >= 1 ? r1 : hrow1;
+                r2 = lane >= 2 ? r2 : (lane == 1 ? hrow1 : hrow2);
+                packed = mine | (r1 << 8) | (r2 << 16);
+            }
             // run flag of byte i (:367-372): set iff i >= 2 and the four preceding bytes are equal
             const u32 i = base + (u32)lane;
             const bool fr = (u32)lane < cnt && i >= 2 && (prev4 & 0xFFu) == ((prev4 >> 8) & 0xFFu) && (prev4 & 0xFFFFu) == (prev4 >> 16);
@@ -337,6 +480,10 @@ __global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restric
             if (cnt == CM_CHUNK) {
                 hist = cm_readlane(mine, (int)CM_CHUNK - 1) | (cm_readlane(mine, (int)CM_CHUNK - 2) << 8) | (cm_readlane(mine, (int)CM_CHUNK - 3) << 16) |
                        (cm_readlane(mine, (int)CM_CHUNK - 4) << 24);
+                if (R) {
+                    hrow1 = cm_readlane(rowv, (int)CM_CHUNK - 1);
+                    hrow2 = cm_readlane(rowv, (int)CM_CHUNK - 2);
+                }
             }
             lds_release();
             if (lane == 0) LDS_POKE(s_prod[role - 1], base + cnt);
@@ -357,6 +504,7 @@ __global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restric
             const u32 a = LDS_PEEK(s_prod[0]), b = LDS_PEEK(s_prod[1]), c = LDS_PEEK(s_prod[2]);
             prod_seen = a < b ? (a < c ? a : c) : (b < c ? b : c);
             if (prod_seen <= i) BZ3_SPIN_PAUSE();
+            if (R && prod_seen == CM_ABORT_MARK) return;  // all three model waves gave the block up; nothing of it is coded past their last chunk
         }
         lds_acquire();
         const uint4 * __restrict__ evp = &ring[(i & (CM_RING - 1)) * 8];
@@ -400,6 +548,18 @@ __global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restric
     }
     *out_size = op + 4;
 }
+
+constexpr int CM_ROWS_ENC = 96;   // 48 KiB of C1 rows: 79.5 KB of LDS per workgroup, two workgroups per CU
+constexpr int CM_ROWS_DEC = 112;  // 56 KiB of C1 rows: 80.6 KB of LDS per workgroup
+#ifdef BZ3_EMU
+constexpr int CM_ROWS_TEST = 40;  // emulator tests: small enough that short inputs recycle slots all the time
+#endif
+
+__global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<0>(jobs); }
+__global__ void __launch_bounds__(256) k_cm_encode_rows(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<CM_ROWS_ENC>(jobs); }
+#ifdef BZ3_EMU
+__global__ void __launch_bounds__(256) k_cm_encode_rows_test(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<CM_ROWS_TEST>(jobs); }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // decode: five waves.  Wave 0 ("walker") runs the coder; waves 1..4 ("model waves") hold one tree node per lane
@@ -479,7 +639,8 @@ struct CmEval {  // what a model lane remembers of its node's last evaluation (t
 
 // Probability of one node (:377-388) into the table, given the two order-1 counters p1 = C1[c1][node] (at index a1)
 // and p2 = C1[c2][node]; returns what the update of that byte will need.
-__device__ __forceinline__ CmEval cm_evaluate(const CmLds & m, u32 * __restrict__ pt, u32 node, u32 c0, u32 a1, u32 p1, u32 p2, u32 f) {
+template <class M>
+__device__ __forceinline__ CmEval cm_evaluate(const M & m, u32 * __restrict__ pt, u32 node, u32 c0, u32 a1, u32 p1, u32 p2, u32 f) {
     CmEval e;
     e.a1 = a1;
     e.p1 = p1;
@@ -492,18 +653,22 @@ __device__ __forceinline__ CmEval cm_evaluate(const CmLds & m, u32 * __restrict_
     return e;
 }
 
-__global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restrict__ jobs) {
+template <int R>
+__device__ __forceinline__ void cm_decode_block(const CmDecodeJob * __restrict__ jobs) {
     const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 in_size = jobs[blockIdx.x].in_size;
     u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
     const u32 n = jobs[blockIdx.x].n;
     const u32 debug = jobs[blockIdx.x].debug;  // 3: cycle counters instead of the first output bytes (profiling only)
-    __shared__ CmLds m;
+    __shared__ CmLdsT<R> m;
     __shared__ u32 ptab[2][256];  // (18-bit probability of node) << 14
     __shared__ __attribute__((aligned(16))) u32 s_ready[4];  // per model wave: 2i+1 = speculative table of byte i is there, 2i+2 = corrected one
     __shared__ u32 s_done;        // ((i + 1) & 0xFFFFFF) << 8 | byte i, written by the walker
+    __shared__ u32 s_abort;       // R > 0: the model waves gave the block up
+    __shared__ CmRowCache<R> rcs[R ? 4 : 1];  // R > 0: one private directory per model wave
     if (threadIdx.x < 4) s_ready[threadIdx.x] = 0;
     if (threadIdx.x == 4) s_done = 0;
+    if (threadIdx.x == 5) s_abort = 0;
     cm_model_init(m);
     if (n == 0) return;
     const int lane = lane_id();
@@ -521,6 +686,12 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
         LDS_POKE(s_ready[role - 1], 2u);  // (every lane stores the same word: cheaper than masking the wave down to one lane)
         u32 k1 = 0;        // newest confirmed byte (byte i-2 inside the loop; the initial c1 = 0 before the block starts)
         u32 run_prev = 1;  // run counter the evaluation of byte i-1 was made with
+        // R > 0: row cache of this wave (slot 0 = byte value 0, which the evaluation of byte 0 above has used)
+        CmRowCache<R> & rc = rcs[R ? role - 1 : 0];
+        CmRowState rs;
+        u16 * __restrict__ spill = global_ptr<u16>(jobs[blockIdx.x].spill);
+        const u32 miss_base = jobs[blockIdx.x].miss_base, miss_shift = jobs[blockIdx.x].miss_shift;
+        if (R) cm_rows_init<R>(rc);
         for (u32 i = 1; i < n; i++) {
             u64 t0 = 0, t1 = 0, t2 = 0;
             if (debug == 3) t0 = cm_clock();
@@ -556,7 +727,25 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
             if (c != g) {
                 // wrong guess: put the old counters back (the old values are still in `prev`), apply the real update
                 // and evaluate again.  The new c1 row differs from the row being repaired, so its read goes first.
-                const u32 a1 = c * 256u + node;
+                u32 row = c;
+                if (R) {
+                    row = cm_uniform((u32)rc.row_of[c]);
+                    if (__builtin_expect(row >= CM_ROW_SPILLED, 0)) {
+                        // the only row still needed is the one of byte i-2 (prev.a1 points into it): pin it
+                        rs.tick++;
+                        if (lane == 0) rc.stamp[cm_uniform(prev.a1 >> 8)] = rs.tick;
+                        wave_sync();
+                        row = cm_rows_fetch<R, 1>(m, rc, rs, spill, c, row, node);
+                        if (__builtin_expect(rs.misses > miss_base + (i >> miss_shift), 0)) {
+                            // the working set does not fit: give the block up (every model wave gets here at the same byte)
+                            if (threadIdx.x == 64) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
+                            LDS_POKE(s_abort, 1u);
+                            LDS_POKE(s_ready[role - 1], CM_ABORT_MARK);
+                            return;
+                        }
+                    }
+                }
+                const u32 a1 = row * 256u + node;
                 const u32 p1 = m.c1[a1];
                 u32 cell2 = prev.p1;
                 if (on_g) {
@@ -571,6 +760,7 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
                 }
                 if (on_g || cell2 != prev.p1) m.c1[prev.a1] = (u16)cell2;
                 cur = cm_evaluate(m, pt, node, c0, a1, p1, cell2, 0u);  // c != k1: the run counter restarts
+                if (R) wave_sync();  // (test emulation: a row fetch de-synchronises the fibers of a wave; no instruction on the GPU)
                 lds_release();
                 LDS_POKE(s_ready[role - 1], 2u * i + 2u);
                 run_prev = 0;
@@ -709,7 +899,7 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
     } while (0)
     // One byte.  BUF (compile time) is the half of the double-buffered probability table this byte uses; its table
     // has been fetched already, and the table of the next byte is fetched before the byte is stored.
-    auto decode_byte = [&](const u32 i, auto buf_tag) __attribute__((always_inline)) {
+    auto decode_byte = [&](const u32 i, auto buf_tag) __attribute__((always_inline)) -> bool {  // true: the block was given up (R > 0)
         constexpr u32 BUF = decltype(buf_tag)::value;
         u64 t0 = 0, t1 = 0;
         if (debug == 3) t0 = cm_clock();
@@ -773,20 +963,22 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
         if ((i & 63u) == 63u || i + 1 == n) {
             const u32 first = i & ~63u;
             if (first + lane <= i) out[first + lane] = (u8)staged;
+            if (R && LDS_PEEK(s_abort) != 0u) return true;  // given up (the bytes decoded since then are of no use)
         }
         if (debug == 3) {
             const u64 t2 = cm_clock();
             prof_walk += t1 - t0;
             prof_wait += t2 - t1;
         }
+        return false;
     };
     CM_FETCH_TABLE(0, 0u, 2u);  // byte 0: nothing to guess
     u32 i = 0;
     for (; i + 1 < n; i += 2) {
-        decode_byte(i, CmConst<0>{});
-        decode_byte(i + 1, CmConst<1>{});
+        if (decode_byte(i, CmConst<0>{})) return;
+        if (decode_byte(i + 1, CmConst<1>{})) return;
     }
-    if (i < n) decode_byte(i, CmConst<0>{});
+    if (i < n && decode_byte(i, CmConst<0>{})) return;
     if (debug == 3 && n >= 256 && lane == 0) {  // profiling only: output bytes 0..39 and 64..95 become counters
         u64 * o = reinterpret_cast<u64 *>(out);
         o[0] = prof_wait;
@@ -804,12 +996,28 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
 #undef CM_READY_MIN
 }
 
-void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s) {
-    if (njobs) launch(k_cm_encode, dim3(njobs), dim3(256), 0, s, d_jobs);
+__global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<0>(jobs); }
+__global__ void __launch_bounds__(320) k_cm_decode_rows(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<CM_ROWS_DEC>(jobs); }
+#ifdef BZ3_EMU
+__global__ void __launch_bounds__(320) k_cm_decode_rows_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<CM_ROWS_TEST>(jobs); }
+#endif
+
+void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant) {
+    if (!njobs) return;
+#ifdef BZ3_EMU
+    if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_encode_rows_test, dim3(njobs), dim3(256), 0, s, d_jobs);
+#endif
+    if (variant != CM_VARIANT_FULL) launch(k_cm_encode_rows, dim3(njobs), dim3(256), 0, s, d_jobs);
+    else launch(k_cm_encode, dim3(njobs), dim3(256), 0, s, d_jobs);
 }
 
-void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s) {
-    if (njobs) launch(k_cm_decode, dim3(njobs), dim3(320), 0, s, d_jobs);
+void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant) {
+    if (!njobs) return;
+#ifdef BZ3_EMU
+    if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_decode_rows_test, dim3(njobs), dim3(320), 0, s, d_jobs);
+#endif
+    if (variant != CM_VARIANT_FULL) launch(k_cm_decode_rows, dim3(njobs), dim3(320), 0, s, d_jobs);
+    else launch(k_cm_decode, dim3(njobs), dim3(320), 0, s, d_jobs);
 }
 
 }  // namespace bz3

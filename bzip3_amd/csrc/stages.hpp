@@ -98,6 +98,10 @@ struct CmEncodeJob {  // device addresses as integers: see prims.hpp global_ptr(
     u64 out_size;  // u32 *: receives the coded byte count
     u32 n;
     u32 debug;     // 0 = normal; profiling only (output invalid): 1 = coder wave alone, 2 = model waves alone
+    // row-cache variants only (CM_VARIANT_ROWS*):
+    u64 spill;     // u16[256][256] scratch of this block: the order-1 rows that are not resident in LDS
+    u64 status;    // u32 *, zeroed by the caller: set to 1 when the kernel gave the block up (code it again with CM_VARIANT_FULL)
+    u32 miss_base, miss_shift;  // give up once row misses > miss_base + (position >> miss_shift)
 };
 struct CmDecodeJob {
     u64 in;        // coded bytes; reads past in_size yield 0xFF.. like read_in (:345)
@@ -106,8 +110,14 @@ struct CmDecodeJob {
     u32 n;
     u32 debug;     // 0 = normal; profiling only (output invalid): 1 = coder work only, 2 = model work only
     u32 pad;
+    u64 spill, status;          // as above
+    u32 miss_base, miss_shift;
 };
-void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s);
-void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s);
+// Kernel variants: the whole 145.5 KiB model in LDS (one workgroup per CU), or the row-cache kernels (order-1 rows
+// cached in LDS, two workgroups per CU; they may give a block up, see status).
+enum { CM_VARIANT_FULL = 0, CM_VARIANT_ROWS = 1, CM_VARIANT_ROWS_TEST = 2 /* emulator builds only: tiny cache */ };
+constexpr size_t CM_SPILL_BYTES = 256 * 256 * 2;
+void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL);
+void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL);
 
 }  // namespace bz3

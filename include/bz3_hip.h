@@ -30,6 +30,15 @@ BZIP3_API int bz3_hip_bind_device(int device);
 /* Device a state is bound to. */
 BZIP3_API int bz3_hip_state_device(struct bz3_state * state);
 
+/* CM kernel variant (process-wide).  0 = the whole 145.5 KiB model in LDS, one block per CU; 1 = row-cache kernels
+ * (the order-1 rows a block uses are cached in LDS, the others spill to HBM: two blocks per CU; a block whose
+ * working set does not fit is handed back to variant 0 automatically); -1 = automatic (default): variant 1 only
+ * when a batch holds more blocks than the GPU has CUs.  Environment BZ3_HIP_CM_MODE=auto|full|rows has the same
+ * effect.  Output bytes do not depend on the variant.  Returns 0, or -1 for an invalid mode. */
+BZIP3_API int bz3_hip_set_cm_mode(int mode);
+/* Number of blocks the row-cache kernels have handed back to the full-model kernels so far (statistics). */
+BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void);
+
 /* Device-resident variants: `buffer` / `buffers[i]` are device addresses on the state's GPU with the
  * same capacities the host API requires (bz3_bound(size) for encode; buffer_size for decode). */
 BZIP3_API int32_t bz3_hip_encode_block_device(struct bz3_state * state, void * buffer, int32_t size);

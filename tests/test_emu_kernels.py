@@ -167,3 +167,81 @@ def test_frame_api_multi_block_matches_reference(emu):
     unit = bytes(rng.integers(0, 256, size=997, dtype=np.uint8))
     frame_cases.check(emu, (unit * 400)[: 4 * 65 * 1024 + 1234], 65 * 1024,
                       only=("cut9", "flip_chunk1", "size_plus1", "orig_small", "n_blocks_9", "n_blocks_2", "magic"))
+
+
+# ---- row-cache CM kernels (cm.hip, R > 0): same bytes as the full-model kernels and the oracle ---------------------
+def _skewed(rng, nsym, n, a=1.3):
+    p = 1.0 / np.arange(1, nsym + 1) ** a
+    syms = rng.permutation(256)[:nsym].astype(np.uint8)
+    return bytes(syms[rng.choice(nsym, size=n, p=p / p.sum())])
+
+
+@pytest.fixture()
+def cm_mode(emu):
+    yield lambda m: emu.bz3_hip_set_cm_mode(m)
+    emu.bz3_hip_set_cm_mode(-1)
+
+
+def test_cm_row_cache_kernels_match_oracle(emu, oracle, cm_mode):
+    """Mode 2 = the emulator-only 40-row instantiation (slots are recycled all the time on these inputs: eviction to
+    the spill area, reload, pinning of the rows in flight); mode 1 = the shipped 96/112-row kernels.  Inputs whose
+    working set does not fit are given up by the kernel and coded again by the full-model kernel: same bytes."""
+    g = bzip3_amd.StageApi(emu)
+    rng = np.random.default_rng(5)
+    cases = {
+        "text": (oracle.bwt(datagen.shakespeare()[100000:104000])[1], False),
+        "skew60": (_skewed(rng, 60, 3500), False),          # 60 live rows > 40 slots: recycles, but within the miss budget
+        "flat200": (_skewed(rng, 200, 2500, 0.3), True),    # thrashes: given up
+        "tiny": (b"ab" * 20, False),
+        "one": (b"x", False),
+    }
+    assert cm_mode(2) == 0
+    for name, (d, gives_up) in cases.items():
+        c = oracle.cm_encode(d)
+        n0 = emu.bz3_hip_cm_blocks_given_up()
+        assert g.cm_encode(d) == c, name
+        n1 = emu.bz3_hip_cm_blocks_given_up()
+        assert g.cm_decode(c, len(d)) == d, name
+        n2 = emu.bz3_hip_cm_blocks_given_up()
+        assert (n1 - n0, n2 - n1) == ((1, 1) if gives_up else (0, 0)), name
+        assert g.cm_decode(c[: len(c) // 2], len(d)) == oracle.cm_decode(c[: len(c) // 2], len(d)), name  # truncated stream
+    assert cm_mode(1) == 0
+    d = _skewed(rng, 130, 4000)  # 130 live rows > 96 / 112 slots
+    c = oracle.cm_encode(d)
+    n0 = emu.bz3_hip_cm_blocks_given_up()
+    assert g.cm_encode(d) == c and g.cm_decode(c, len(d)) == d
+    assert emu.bz3_hip_cm_blocks_given_up() == n0
+    junk = bytes(rng.integers(0, 256, size=900, dtype=np.uint8))  # arbitrary input: 256 live rows, handed back
+    assert g.cm_decode(junk, 2000) == oracle.cm_decode(junk, 2000)
+    assert emu.bz3_hip_set_cm_mode(7) == -1
+
+
+def test_batch_api_through_row_cache_kernels(emu, oracle, cm_mode):
+    """bz3_encode_blocks / bz3_decode_blocks with the row-cache variant forced: the blocks the kernel gives up (random
+    bytes) go through a second, full-model launch of the same batch call; every block equals the oracle's."""
+    assert cm_mode(2) == 0
+    bs = 65 * 1024
+    t = datagen.shakespeare()
+    blocks = [t[:3000], datagen.random_bytes(2500), t[5000:8000], b"tiny", datagen.random_bytes(1500, seed=9)]
+    n = len(blocks)
+    states = (C.c_void_p * n)(*[emu.bz3_new(bs) for _ in range(n)])
+    cap = emu.bz3_bound(bs) + 64
+    bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+    for b, d in zip(bufs, blocks):
+        C.memmove(b, d, len(d))
+    ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+    n0 = emu.bz3_hip_cm_blocks_given_up()
+    emu.bz3_encode_blocks(states, ptrs, sizes, n)
+    assert emu.bz3_hip_cm_blocks_given_up() - n0 == 2
+    for i, d in enumerate(blocks):
+        assert emu.bz3_last_error(states[i]) == 0
+        assert bytes(bufs[i][: sizes[i]]) == oracle.encode_block(d, bs)[2]
+    bsz = (C.c_size_t * n)(*[cap] * n)
+    orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+    emu.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+    assert emu.bz3_hip_cm_blocks_given_up() - n0 == 4
+    for i, d in enumerate(blocks):
+        assert emu.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: len(d)]) == d
+    for s in states:
+        emu.bz3_free(s)
