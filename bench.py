@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--blocks", type=int, default=int(os.environ.get("BZ3_BENCH_BLOCKS", "256")), help="256 MiB blocks per GPU")
     ap.add_argument("--block-mib", type=float, default=float(os.environ.get("BZ3_BENCH_BLOCK_MIB", "256")))
     ap.add_argument("--kind", default="text", choices=["text", "random"])
+    ap.add_argument("--cm-mode", default=os.environ.get("BZ3_BENCH_CM_MODE", "auto"), choices=["auto", "full", "rows", "rows3"],
+                    help="CM kernel variant (bz3_hip_set_cm_mode): auto = row-cache kernels (two blocks per CU) when blocks > CUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=float, default=32.0)
     ap.add_argument("--cpu-threads", type=int, default=64)
@@ -165,6 +167,7 @@ def main():
     lib = bzip3_amd.load()
     assert lib.bz3_hip_device_count() > 0, "no HIP device"
     assert lib.bz3_hip_bind_device(local_rank) == 0
+    assert lib.bz3_hip_set_cm_mode({"auto": -1, "full": 0, "rows": 1, "rows3": 2}[a.cm_mode]) == 0
 
     block_size = int(a.block_mib * (1 << 20))
     nblk = a.blocks
@@ -301,6 +304,8 @@ def main():
                 "blocks_per_gpu": nblk,
                 "parallelism": f"blocks sharded over {world} GPU(s), no collective",
                 "compressed_ratio": round(world * 0 + (nblk * block_size) / max(1, comp_total[0]), 3),
+                "cm_mode": a.cm_mode,
+                "cm_blocks_given_up": int(lib.bz3_hip_cm_blocks_given_up()),
             },
             # dominant kernel by time: the CM decoder (one workgroup per block; a serial integer recurrence,
             # latency-bound by construction -- SURVEY.md 7/H1), priced against the HBM roofline as the contract asks

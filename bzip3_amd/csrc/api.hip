@@ -127,9 +127,9 @@ size_t workspace_bytes_for(u64 n) {
 
 // ---- CM kernel variant -------------------------------------------------------------------------------
 // The full-model CM kernels need a whole CU's LDS per block; the row-cache kernels (cm.hip) need half of it, so two
-// blocks share a CU, but they give up blocks whose order-1 working set does not fit (binary data).  Policy
-// (BZ3_HIP_CM_MODE=auto|full|rows, bz3_hip_set_cm_mode): auto = row-cache kernels only when a batch has more blocks
-// than the GPU has CUs -- with fewer, every block gets a CU of its own anyway.
+// (a third) blocks share a CU, but they give up blocks whose order-1 working set does not fit (binary data).  Policy
+// (BZ3_HIP_CM_MODE=auto|full|rows|rows3, bz3_hip_set_cm_mode): auto = row-cache kernels only when a batch has more
+// blocks than the GPU has CUs (three per CU beyond twice that) -- with fewer, every block gets a CU of its own anyway.
 std::atomic<int> g_cm_mode{-2};  // -2 = not read from the environment yet, -1 = auto, else CM_VARIANT_*
 
 int cm_mode() {
@@ -139,6 +139,7 @@ int cm_mode() {
         m = -1;
         if (e && !strcmp(e, "full")) m = CM_VARIANT_FULL;
         else if (e && !strcmp(e, "rows")) m = CM_VARIANT_ROWS;
+        else if (e && !strcmp(e, "rows3")) m = CM_VARIANT_ROWS3;
 #ifdef BZ3_EMU
         else if (e && !strcmp(e, "rows-test")) m = CM_VARIANT_ROWS_TEST;
 #endif
@@ -150,7 +151,7 @@ int cm_mode() {
 int cm_variant_for(const DeviceCtx * ctx, size_t njobs) {
     const int m = cm_mode();
     if (m >= 0) return m;
-    return njobs > (size_t)ctx->cus ? CM_VARIANT_ROWS : CM_VARIANT_FULL;
+    return njobs > 2 * (size_t)ctx->cus ? CM_VARIANT_ROWS3 : njobs > (size_t)ctx->cus ? CM_VARIANT_ROWS : CM_VARIANT_FULL;
 }
 
 size_t cm_scratch_bytes(size_t njobs) { return njobs * (CM_SPILL_BYTES + 256) + 4096; }
@@ -1110,12 +1111,11 @@ BZIP3_API int bz3_hip_bind_device(int device) {
 BZIP3_API int bz3_hip_state_device(struct bz3_state * st) { return st->device; }
 
 BZIP3_API int bz3_hip_set_cm_mode(int mode) {
+    bool ok = mode >= -1 && mode <= CM_VARIANT_ROWS3;
 #ifdef BZ3_EMU
-    const int top = CM_VARIANT_ROWS_TEST;
-#else
-    const int top = CM_VARIANT_ROWS;
+    ok = ok || mode == CM_VARIANT_ROWS_TEST;
 #endif
-    if (mode < -1 || mode > top) return -1;
+    if (!ok) return -1;
     g_cm_mode.store(mode);
     return 0;
 }

@@ -551,12 +551,15 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
 
 constexpr int CM_ROWS_ENC = 96;   // 48 KiB of C1 rows: 79.5 KB of LDS per workgroup, two workgroups per CU
 constexpr int CM_ROWS_DEC = 112;  // 56 KiB of C1 rows: 80.6 KB of LDS per workgroup
+constexpr int CM_ROWS3_ENC = 44;  // 22 KiB of C1 rows: 52.9 KB of LDS per workgroup, three workgroups per CU (a chunk pins up to 34 rows)
+constexpr int CM_ROWS3_DEC = 56;  // 28 KiB of C1 rows: 50.8 KB of LDS per workgroup
 #ifdef BZ3_EMU
 constexpr int CM_ROWS_TEST = 40;  // emulator tests: small enough that short inputs recycle slots all the time
 #endif
 
 __global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<0>(jobs); }
 __global__ void __launch_bounds__(256) k_cm_encode_rows(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<CM_ROWS_ENC>(jobs); }
+__global__ void __launch_bounds__(256) k_cm_encode_rows3(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<CM_ROWS3_ENC>(jobs); }
 #ifdef BZ3_EMU
 __global__ void __launch_bounds__(256) k_cm_encode_rows_test(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<CM_ROWS_TEST>(jobs); }
 #endif
@@ -998,6 +1001,7 @@ __device__ __forceinline__ void cm_decode_block(const CmDecodeJob * __restrict__
 
 __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<0>(jobs); }
 __global__ void __launch_bounds__(320) k_cm_decode_rows(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<CM_ROWS_DEC>(jobs); }
+__global__ void __launch_bounds__(320) k_cm_decode_rows3(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<CM_ROWS3_DEC>(jobs); }
 #ifdef BZ3_EMU
 __global__ void __launch_bounds__(320) k_cm_decode_rows_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<CM_ROWS_TEST>(jobs); }
 #endif
@@ -1007,7 +1011,8 @@ void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int v
 #ifdef BZ3_EMU
     if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_encode_rows_test, dim3(njobs), dim3(256), 0, s, d_jobs);
 #endif
-    if (variant != CM_VARIANT_FULL) launch(k_cm_encode_rows, dim3(njobs), dim3(256), 0, s, d_jobs);
+    if (variant == CM_VARIANT_ROWS3) launch(k_cm_encode_rows3, dim3(njobs), dim3(256), 0, s, d_jobs);
+    else if (variant != CM_VARIANT_FULL) launch(k_cm_encode_rows, dim3(njobs), dim3(256), 0, s, d_jobs);
     else launch(k_cm_encode, dim3(njobs), dim3(256), 0, s, d_jobs);
 }
 
@@ -1016,7 +1021,8 @@ void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int v
 #ifdef BZ3_EMU
     if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_decode_rows_test, dim3(njobs), dim3(320), 0, s, d_jobs);
 #endif
-    if (variant != CM_VARIANT_FULL) launch(k_cm_decode_rows, dim3(njobs), dim3(320), 0, s, d_jobs);
+    if (variant == CM_VARIANT_ROWS3) launch(k_cm_decode_rows3, dim3(njobs), dim3(320), 0, s, d_jobs);
+    else if (variant != CM_VARIANT_FULL) launch(k_cm_decode_rows, dim3(njobs), dim3(320), 0, s, d_jobs);
     else launch(k_cm_decode, dim3(njobs), dim3(320), 0, s, d_jobs);
 }
 

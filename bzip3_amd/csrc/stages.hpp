@@ -114,8 +114,8 @@ struct CmDecodeJob {
     u32 miss_base, miss_shift;
 };
 // Kernel variants: the whole 145.5 KiB model in LDS (one workgroup per CU), or the row-cache kernels (order-1 rows
-// cached in LDS, two workgroups per CU; they may give a block up, see status).
-enum { CM_VARIANT_FULL = 0, CM_VARIANT_ROWS = 1, CM_VARIANT_ROWS_TEST = 2 /* emulator builds only: tiny cache */ };
+// cached in LDS: two or three workgroups per CU; they may give a block up, see status).
+enum { CM_VARIANT_FULL = 0, CM_VARIANT_ROWS = 1, CM_VARIANT_ROWS3 = 2, CM_VARIANT_ROWS_TEST = 9 /* emulator builds only: tiny cache */ };
 constexpr size_t CM_SPILL_BYTES = 256 * 256 * 2;
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL);
 void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL);

@@ -30,11 +30,12 @@ BZIP3_API int bz3_hip_bind_device(int device);
 /* Device a state is bound to. */
 BZIP3_API int bz3_hip_state_device(struct bz3_state * state);
 
-/* CM kernel variant (process-wide).  0 = the whole 145.5 KiB model in LDS, one block per CU; 1 = row-cache kernels
- * (the order-1 rows a block uses are cached in LDS, the others spill to HBM: two blocks per CU; a block whose
- * working set does not fit is handed back to variant 0 automatically); -1 = automatic (default): variant 1 only
- * when a batch holds more blocks than the GPU has CUs.  Environment BZ3_HIP_CM_MODE=auto|full|rows has the same
- * effect.  Output bytes do not depend on the variant.  Returns 0, or -1 for an invalid mode. */
+/* CM kernel variant (process-wide).  0 = the whole 145.5 KiB model in LDS, one block per CU; 1 / 2 = row-cache
+ * kernels (the order-1 rows a block uses are cached in LDS -- 96/112 or 44/56 of them --, the others spill to HBM:
+ * two / three blocks per CU; a block whose working set does not fit is handed back to variant 0 automatically);
+ * -1 = automatic (default): variant 1 only when a batch holds more blocks than the GPU has CUs, variant 2 beyond
+ * twice that.  Environment BZ3_HIP_CM_MODE=auto|full|rows|rows3 has the same effect.  Output bytes do not depend on
+ * the variant.  Returns 0, or -1 for an invalid mode. */
 BZIP3_API int bz3_hip_set_cm_mode(int mode);
 /* Number of blocks the row-cache kernels have handed back to the full-model kernels so far (statistics). */
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void);

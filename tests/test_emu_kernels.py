@@ -183,8 +183,8 @@ def cm_mode(emu):
 
 
 def test_cm_row_cache_kernels_match_oracle(emu, oracle, cm_mode):
-    """Mode 2 = the emulator-only 40-row instantiation (slots are recycled all the time on these inputs: eviction to
-    the spill area, reload, pinning of the rows in flight); mode 1 = the shipped 96/112-row kernels.  Inputs whose
+    """Mode 9 = the emulator-only 40-row instantiation (slots are recycled all the time on these inputs: eviction to
+    the spill area, reload, pinning of the rows in flight); modes 1 / 2 = the shipped 96/112-row and 44/56-row kernels.  Inputs whose
     working set does not fit are given up by the kernel and coded again by the full-model kernel: same bytes."""
     g = bzip3_amd.StageApi(emu)
     rng = np.random.default_rng(5)
@@ -195,7 +195,7 @@ def test_cm_row_cache_kernels_match_oracle(emu, oracle, cm_mode):
         "tiny": (b"ab" * 20, False),
         "one": (b"x", False),
     }
-    assert cm_mode(2) == 0
+    assert cm_mode(9) == 0
     for name, (d, gives_up) in cases.items():
         c = oracle.cm_encode(d)
         n0 = emu.bz3_hip_cm_blocks_given_up()
@@ -211,6 +211,11 @@ def test_cm_row_cache_kernels_match_oracle(emu, oracle, cm_mode):
     n0 = emu.bz3_hip_cm_blocks_given_up()
     assert g.cm_encode(d) == c and g.cm_decode(c, len(d)) == d
     assert emu.bz3_hip_cm_blocks_given_up() == n0
+    assert cm_mode(2) == 0
+    d = _skewed(rng, 70, 3000)  # 70 live rows > 44 / 56 slots
+    c = oracle.cm_encode(d)
+    assert g.cm_encode(d) == c and g.cm_decode(c, len(d)) == d
+    assert emu.bz3_hip_cm_blocks_given_up() == n0
     junk = bytes(rng.integers(0, 256, size=900, dtype=np.uint8))  # arbitrary input: 256 live rows, handed back
     assert g.cm_decode(junk, 2000) == oracle.cm_decode(junk, 2000)
     assert emu.bz3_hip_set_cm_mode(7) == -1
@@ -219,7 +224,7 @@ def test_cm_row_cache_kernels_match_oracle(emu, oracle, cm_mode):
 def test_batch_api_through_row_cache_kernels(emu, oracle, cm_mode):
     """bz3_encode_blocks / bz3_decode_blocks with the row-cache variant forced: the blocks the kernel gives up (random
     bytes) go through a second, full-model launch of the same batch call; every block equals the oracle's."""
-    assert cm_mode(2) == 0
+    assert cm_mode(9) == 0
     bs = 65 * 1024
     t = datagen.shakespeare()
     blocks = [t[:3000], datagen.random_bytes(2500), t[5000:8000], b"tiny", datagen.random_bytes(1500, seed=9)]

@@ -222,6 +222,58 @@ def test_batch_api_host_buffers(gpu_lib, oracle, text):
         gpu_lib.bz3_free(s)
 
 
+def test_cm_row_cache_kernels_on_gpu(gpu_lib, oracle, text):
+    """The row-cache CM kernels (two workgroups per CU; bz3_hip_set_cm_mode(1)) must produce the bytes of the oracle:
+    stage hooks on BWT output of text (fits the cache), on a 150-symbol source (slots are recycled through the spill
+    area), on random bytes (given up by the kernel, coded again by the full-model kernel) and on a truncated stream;
+    then a host-buffer batch that mixes text and random blocks."""
+    g = bzip3_amd.StageApi(gpu_lib)
+    rng = np.random.default_rng(12)
+    def zipf(nsym, a, n):
+        p = 1.0 / np.arange(1, nsym + 1) ** a
+        return bytes(rng.permutation(256)[:nsym].astype(np.uint8)[rng.choice(nsym, size=n, p=p / p.sum())])
+
+    wide = zipf(150, 1.2, 400000)  # 4 % of the bytes outside the 96 / 112 cached rows: thrashes, may be given up
+    inputs = {"text": oracle.bwt(text[2000000 : 2000000 + (1 << 20)])[1], "wide150": wide, "wide130": zipf(130, 2.5, 400000),
+              "rand": datagen.random_bytes(200000, seed=3), "lowent": oracle.bwt(datagen.low_entropy(300000))[1], "tiny": b"abracadabra"}
+    given_up = {"text": 0, "wide130": 0, "rand": 2, "lowent": 0, "tiny": 0}
+    try:
+        assert gpu_lib.bz3_hip_set_cm_mode(1) == 0
+        for name, d in inputs.items():
+            c = oracle.cm_encode(d)
+            n0 = gpu_lib.bz3_hip_cm_blocks_given_up()
+            assert g.cm_encode(d) == c, name
+            assert g.cm_decode(c, len(d)) == d, name
+            if name in given_up:
+                assert gpu_lib.bz3_hip_cm_blocks_given_up() - n0 == given_up[name], name
+            cut = c[: len(c) // 3]
+            assert g.cm_decode(cut, len(d)) == oracle.cm_decode(cut, len(d)), name
+        bs = 1 << 20
+        blocks = [text[i * 500000 : i * 500000 + 400000] for i in range(6)] + [datagen.random_bytes(150000, seed=5), b"tiny", wide[:300000]]
+        n = len(blocks)
+        states = (C.c_void_p * n)(*[gpu_lib.bz3_new(bs) for _ in range(n)])
+        assert all(states)
+        cap = gpu_lib.bz3_bound(bs) + 64
+        bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+        for b, d in zip(bufs, blocks):
+            C.memmove(b, d, len(d))
+        ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+        sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+        gpu_lib.bz3_encode_blocks(states, ptrs, sizes, n)
+        for i, d in enumerate(blocks):
+            assert gpu_lib.bz3_last_error(states[i]) == 0
+            assert bytes(bufs[i][: sizes[i]]) == oracle.encode_block(d, bs)[2], i
+        bsz = (C.c_size_t * n)(*[cap] * n)
+        orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+        gpu_lib.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+        for i, d in enumerate(blocks):
+            assert gpu_lib.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: len(d)]) == d, i
+        for s in states:
+            gpu_lib.bz3_free(s)
+    finally:
+        gpu_lib.bz3_hip_set_cm_mode(-1)
+
+
 def test_device_resident_api(gpu_lib, oracle, text):
     import torch
 
