@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--kind", default="text", choices=["text", "random"])
     ap.add_argument("--cm-mode", default=os.environ.get("BZ3_BENCH_CM_MODE", "auto"), choices=["auto", "full", "rows", "rows3"],
                     help="CM kernel variant (bz3_hip_set_cm_mode): auto = row-cache kernels (two blocks per CU) when blocks > CUs")
+    ap.add_argument("--lean", action="store_true", default=os.environ.get("BZ3_BENCH_LEAN", "0") == "1",
+                    help="lean states (bz3_hip_set_lean_states): no per-state swap buffer, in-place CM encode -- room for ~3x256 blocks of 256 MiB")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=float, default=32.0)
     ap.add_argument("--cpu-threads", type=int, default=64)
@@ -168,6 +170,7 @@ def main():
     assert lib.bz3_hip_device_count() > 0, "no HIP device"
     assert lib.bz3_hip_bind_device(local_rank) == 0
     assert lib.bz3_hip_set_cm_mode({"auto": -1, "full": 0, "rows": 1, "rows3": 2}[a.cm_mode]) == 0
+    assert lib.bz3_hip_set_lean_states(1 if a.lean else 0) == 0
 
     block_size = int(a.block_mib * (1 << 20))
     nblk = a.blocks
@@ -305,6 +308,7 @@ def main():
                 "parallelism": f"blocks sharded over {world} GPU(s), no collective",
                 "compressed_ratio": round(world * 0 + (nblk * block_size) / max(1, comp_total[0]), 3),
                 "cm_mode": a.cm_mode,
+                "lean_states": bool(a.lean),
                 "cm_blocks_given_up": int(lib.bz3_hip_cm_blocks_given_up()),
             },
             # dominant kernel by time: the CM decoder (one workgroup per block; a serial integer recurrence,

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <mutex>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/bz3_hip.h"
@@ -47,6 +48,40 @@ struct DeviceCtx {
     size_t ws_cap = 0;
     int cus = 256;          // compute units: one full-model CM workgroup fits per CU
 
+    // Swap buffers lent to "lean" states for the duration of a stage sequence (see bz3_hip_set_lean_states).
+    std::mutex temp_mu;
+    std::vector<std::pair<u8 *, size_t>> temps_free;
+    std::vector<std::pair<u8 *, size_t>> temps_out;
+    u8 * temp_get(size_t cap) {
+        std::lock_guard<std::mutex> lk(temp_mu);
+        for (size_t k = 0; k < temps_free.size(); k++)
+            if (temps_free[k].second >= cap) {
+                auto t = temps_free[k];
+                temps_free.erase(temps_free.begin() + (long)k);
+                temps_out.push_back(t);
+                return t.first;
+            }
+        u8 * p = nullptr;
+        HIP_CHECK(hipMalloc((void **)&p, cap));
+        temps_out.push_back({p, cap});
+        return p;
+    }
+    void temp_put(u8 * p) {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(temp_mu);
+        for (size_t k = 0; k < temps_out.size(); k++)
+            if (temps_out[k].first == p) {
+                temps_free.push_back(temps_out[k]);
+                temps_out.erase(temps_out.begin() + (long)k);
+                return;
+            }
+    }
+    void temp_trim() {  // hand the idle swap buffers back to the driver
+        std::lock_guard<std::mutex> lk(temp_mu);
+        for (auto & t : temps_free) (void)hipFree(t.first);
+        temps_free.clear();
+    }
+
     Arena arena_for(size_t bytes) {  // caller holds mu
         if (bytes > ws_cap) {
             if (ws) HIP_CHECK(hipFree(ws));
@@ -69,6 +104,7 @@ std::vector<DeviceCtx *> g_ctx;
 int g_device_count = -1;
 std::atomic<int> g_bound_device{-2};  // -2 = not initialised from the environment yet, -1 = round robin
 std::atomic<unsigned> g_rr{0};
+std::atomic<int> g_lean{-1};  // -1 = not read from the environment yet; see bz3_hip_set_lean_states
 std::atomic<unsigned> g_cm_given_up{0};  // blocks the row-cache CM kernels handed back to the full-model kernels (statistics)
 
 int device_count() {
@@ -126,10 +162,14 @@ size_t workspace_bytes_for(u64 n) {
 }
 
 // ---- CM kernel variant -------------------------------------------------------------------------------
-// The full-model CM kernels need a whole CU's LDS per block; the row-cache kernels (cm.hip) need half of it, so two
-// (a third) blocks share a CU, but they give up blocks whose order-1 working set does not fit (binary data).  Policy
-// (BZ3_HIP_CM_MODE=auto|full|rows|rows3, bz3_hip_set_cm_mode): auto = row-cache kernels only when a batch has more
-// blocks than the GPU has CUs (three per CU beyond twice that) -- with fewer, every block gets a CU of its own anyway.
+// The full-model CM kernels need a whole CU's LDS per block; the row-cache kernels (cm.hip) need half or a third of
+// it, so two or three blocks share a CU, but they give up blocks whose order-1 working set does not fit (binary
+// data).  Policy (BZ3_HIP_CM_MODE=auto|full|rows|rows3, bz3_hip_set_cm_mode): auto follows what was measured on
+// MI355X (profiles/r01_cm_rows_probe.txt; C = number of CUs, time of a launch relative to one block per CU):
+//   encode  two blocks per CU 1.30x, three 1.59x  -> row-cache kernels as soon as a batch has more than C blocks;
+//   decode  two blocks per CU 2.07x, three 2.2x   -> two per CU gain nothing over two rounds of the full-model
+//           kernel, so the row-cache decoder is only used beyond 2 C blocks (three per CU).
+// With at most C blocks every block gets a CU of its own and the full-model kernels are the fastest.
 std::atomic<int> g_cm_mode{-2};  // -2 = not read from the environment yet, -1 = auto, else CM_VARIANT_*
 
 int cm_mode() {
@@ -148,10 +188,22 @@ int cm_mode() {
     return m;
 }
 
-int cm_variant_for(const DeviceCtx * ctx, size_t njobs) {
+bool lean_states() {
+    int v = g_lean.load();
+    if (v < 0) {
+        const char * e = getenv("BZ3_HIP_LEAN");
+        v = (e && *e && strcmp(e, "0")) ? 1 : 0;
+        g_lean.store(v);
+    }
+    return v != 0;
+}
+
+int cm_variant_for(const DeviceCtx * ctx, size_t njobs, bool encode) {
     const int m = cm_mode();
     if (m >= 0) return m;
-    return njobs > 2 * (size_t)ctx->cus ? CM_VARIANT_ROWS3 : njobs > (size_t)ctx->cus ? CM_VARIANT_ROWS : CM_VARIANT_FULL;
+    const size_t c = (size_t)ctx->cus;
+    if (njobs > 2 * c) return CM_VARIANT_ROWS3;
+    return (encode && njobs > c) ? CM_VARIANT_ROWS : CM_VARIANT_FULL;
 }
 
 size_t cm_scratch_bytes(size_t njobs) { return njobs * (CM_SPILL_BYTES + 256) + 4096; }
@@ -161,7 +213,7 @@ size_t cm_scratch_bytes(size_t njobs) { return njobs * (CM_SPILL_BYTES + 256) + 
 template <class Job, class Launch>
 float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs, Job * d_jobs, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, Launch && go) {
     if (jobs.empty()) return 0.f;
-    const int variant = cm_variant_for(ctx, jobs.size());
+    const int variant = cm_variant_for(ctx, jobs.size(), std::is_same<Job, CmEncodeJob>::value);
     const size_t mk = arena.mark();
     u32 * d_status = nullptr;
     if (variant != CM_VARIANT_FULL) {
@@ -175,6 +227,8 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
             jobs[i].miss_shift = variant == CM_VARIANT_ROWS_TEST ? 3u : 8u;  // give up beyond 0.4 % misses (test variant: 12.5 %)
         }
     }
+    if (const char * t = getenv("BZ3_CM_TUNE"))  // kernel experiments (cm.hip `tune`); no effect on the output bytes
+        for (Job & j : jobs) j.debug |= (u32)atoi(t) << 4;
     float ms = 0.f, ms2 = 0.f;
     HIP_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipEventRecord(ev0, s));
@@ -244,7 +298,8 @@ struct bz3_state {
     DeviceCtx * ctx = nullptr;
     hipStream_t stream = nullptr;  // owned
     hipStream_t xs = nullptr;      // execution stream of the current call: the lead state's stream of its device group
-    u8 * d_swap = nullptr;  // the reference's swap_buffer, in HBM
+    u8 * d_swap = nullptr;  // the reference's swap_buffer, in HBM (lean states: borrowed from the device's pool while a call needs it)
+    bool lean = false;      // see bz3_hip_set_lean_states
     u8 * d_io = nullptr;    // staging for the host-buffer API (lazy)
     size_t cap = 0;         // bz3_bound(block_size) rounded up
     u32 * d_words = nullptr;  // [0..1] crc scratch/result, [2] cm coded size, [4] rle total, [5] lzp result
@@ -260,6 +315,7 @@ struct bz3_state {
     u32 n_cm = 0;         // bytes entering / leaving the CM stage
     const u8 * cm_in = nullptr;
     u32 cm_in_size = 0;
+    u8 * side = nullptr;  // lean encode: this block's slice of the in-place coder's side buffer
     // decode
     size_t buffer_size = 0;
     u32 crc = 0;
@@ -278,7 +334,8 @@ void state_release(bz3_state * st) {
     if (st->stream) (void)hipStreamSynchronize(st->stream);
     if (st->ev0) (void)hipEventDestroy(st->ev0);
     if (st->ev1) (void)hipEventDestroy(st->ev1);
-    if (st->d_swap) (void)hipFree(st->d_swap);
+    if (st->d_swap && st->lean && st->ctx) st->ctx->temp_put(st->d_swap);
+    else if (st->d_swap) (void)hipFree(st->d_swap);
     if (st->d_io) (void)hipFree(st->d_io);
     if (st->d_words) (void)hipFree(st->d_words);
     if (st->stream) (void)hipStreamDestroy(st->stream);
@@ -300,6 +357,18 @@ inline bool sizes_fit(size_t buffer_size, s32 lzp_size, s32 rle_size, s32 orig_s
     const size_t a = lzp_size < 0 ? 0 : (size_t)lzp_size, b = rle_size < 0 ? 0 : (size_t)rle_size, c = orig_size < 0 ? 0 : (size_t)orig_size;
     return a <= buffer_size && b <= buffer_size && c <= buffer_size;
 }
+
+// Lean states own no swap buffer: they borrow one from the device's pool while a stage sequence needs it.
+inline void lean_borrow(bz3_state * st) {
+    if (st->lean && !st->d_swap) st->d_swap = st->ctx->temp_get(st->cap);
+}
+inline void lean_return(bz3_state * st) {
+    if (st->lean && st->d_swap) {
+        st->ctx->temp_put(st->d_swap);
+        st->d_swap = nullptr;
+    }
+}
+constexpr u32 CM_SIDE_BYTES = 64 * 1024;  // per block: where in-place CM output goes should it ever catch up with its input
 
 // ======================================================================================================
 // encode.  A call (one block or a batch) runs in three phases per GPU:
@@ -331,6 +400,7 @@ void encode_front_a(bz3_state * st, u8 * buf, s32 data_size, Arena & arena, LzpE
     st->t[BZ3_HIP_T_CRC] = (float)(now_ms() - t0);
 
     u32 n = (u32)data_size;
+    lean_borrow(st);
     u8 *b1 = buf, *b2 = st->d_swap;
     st->model = 0;
     st->rle_size = 0;
@@ -377,7 +447,22 @@ void encode_front_b(bz3_state * st, Arena & arena, const LzpEncodeCtx & c, float
     st->t[BZ3_HIP_T_LZP] += driver_ms + (float)(now_ms() - t0);
 
     t0 = now_ms();
-    const s32 bwt_idx = bwt_forward(b1, n, b2, arena, s, &st->bwt);  // :623-627
+    s32 bwt_idx;
+    if (!st->lean) {
+        bwt_idx = bwt_forward(b1, n, b2, arena, s, &st->bwt);  // :623-627
+    } else {
+        // Lean state: the coder will work IN PLACE in the caller's buffer (capacity bz3_bound(size), libbz3.h:172-174):
+        // the BWT output goes to the END of that buffer, the coded bytes grow from its start (cm.hip CmSink).
+        u8 * tail = st->user + bz3_bound((size_t)st->size) - n;
+        if (b1 != st->user) {
+            bwt_idx = bwt_forward(b1, n, tail, arena, s, &st->bwt);
+        } else {
+            bwt_idx = bwt_forward(b1, n, b2, arena, s, &st->bwt);
+            if (bwt_idx >= 0) HIP_CHECK(hipMemcpyAsync(tail, b2, n, hipMemcpyDeviceToDevice, s));
+        }
+        b1 = st->user;  // receives header + coded bytes
+        b2 = tail;      // CM input
+    }
     st->t[BZ3_HIP_T_BWT] = (float)(now_ms() - t0);
     if (bwt_idx < 0) {
         st->last_error = BZ3_ERR_BWT;
@@ -387,6 +472,10 @@ void encode_front_b(bz3_state * st, Arena & arena, const LzpEncodeCtx & c, float
     if (st->model & 2) overhead++;
     if (st->model & 4) overhead++;
     launch(k_write_header, dim3(1), dim3(64), 0, s, b1, (const u32 *)(st->d_words + 1), (u32)bwt_idx, (u32)st->model, (u32)lzp_size, (u32)st->rle_size);  // :641-647
+    if (st->lean) {
+        HIP_CHECK(hipStreamSynchronize(s));  // the swap buffer goes back to the pool: nothing may still be reading it
+        lean_return(st);
+    }
     st->b1 = b1;
     st->b2 = b2;
     st->n_cm = n;
@@ -405,7 +494,17 @@ void encode_finish(bz3_state * st, float cm_ms) {
     }
     st->t[BZ3_HIP_T_CM] = cm_ms;
     const u32 coded = read_word(st->xs, st->d_words + 2);
+    if (coded == 0xFFFFFFFFu) {  // in-place coding ran out of side buffer (the output outgrew bz3_bound's slack by > 64 KiB mid-block)
+        st->last_error = BZ3_ERR_BWT;
+        return;
+    }
     const s32 total = (s32)coded + st->overhead * 4 + 1;
+    if (st->lean) {
+        const u32 sw = read_word(st->xs, st->d_words + 3);
+        if (sw != 0xFFFFFFFFu && coded > sw)  // part of the coded bytes waited in the side buffer until the input was dead
+            HIP_CHECK(hipMemcpyAsync(st->user + st->overhead * 4 + 1 + sw, st->side, coded - sw, hipMemcpyDeviceToDevice, st->xs));
+        HIP_CHECK(hipStreamSynchronize(st->xs));
+    }
     st->last_error = BZ3_OK;  // :649
     if (st->b1 != st->user) {  // :651
         double t0 = now_ms();
@@ -451,8 +550,10 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     if (window < 1) window = 1;
     if (window > 64) window = 64;
     if (window > n) window = n;
-    Arena arena = lead->ctx->arena_for(need + (size_t)window * (ctx_bytes + 65536) + (size_t)n * sizeof(CmEncodeJob) + cm_scratch_bytes((size_t)n) + 65536);
+    Arena arena = lead->ctx->arena_for(need + (size_t)window * (ctx_bytes + 65536) + (size_t)n * (sizeof(CmEncodeJob) + CM_SIDE_BYTES + 256) +
+                                       cm_scratch_bytes((size_t)n) + 65536);
     CmEncodeJob * d_jobs = arena.take<CmEncodeJob>((size_t)n);
+    u8 * sides = arena.take<u8>((size_t)n * CM_SIDE_BYTES);  // lean states only
     std::vector<CmEncodeJob> jobs;
     for (s32 w0 = 0; w0 < n; w0 += window) {
         const s32 w1 = (w0 + window < n) ? w0 + window : n;
@@ -474,8 +575,17 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         }
         for (s32 i = w0; i < w1; i++) {
             encode_front_b(sts[i], arena, ctxs[(size_t)(i - w0)], driver_ms);
-            if (sts[i]->pending == bz3_state::ENC_CODED)
-                jobs.push_back(CmEncodeJob{dev_addr(sts[i]->b2), dev_addr(sts[i]->b1 + sts[i]->overhead * 4 + 1), dev_addr(sts[i]->d_words + 2), sts[i]->n_cm, 0u});  // :634-638
+            if (sts[i]->pending == bz3_state::ENC_CODED) {
+                CmEncodeJob j{dev_addr(sts[i]->b2), dev_addr(sts[i]->b1 + sts[i]->overhead * 4 + 1), dev_addr(sts[i]->d_words + 2), sts[i]->n_cm, 0u};  // :634-638
+                if (sts[i]->lean) {  // in place: input at the end of the caller's buffer, output behind the header
+                    sts[i]->side = sides + (size_t)i * CM_SIDE_BYTES;
+                    j.gap = (u32)(sts[i]->b2 - (sts[i]->b1 + sts[i]->overhead * 4 + 1));
+                    j.side = dev_addr(sts[i]->side);
+                    j.side_cap = CM_SIDE_BYTES;
+                }
+                jobs.push_back(j);
+            }
+            lean_return(sts[i]);  // blocks that left the pipeline early (stored, failed) still hold their swap buffer
         }
         arena.release(mk);
     }
@@ -569,6 +679,10 @@ bool decode_unbwt(bz3_state * st, Arena & arena, float cm_ms) {
         return false;
     }
     u8 *b1 = st->d_swap, *b2 = st->user;  // after the swap of :748
+    if (st->lean) {  // lean state: the coder wrote into the caller's buffer; the borrowed swap buffer receives the text
+        b1 = st->user;
+        b2 = st->d_swap;
+    }
     const double t0 = now_ms();
     // libsais_unbwt's own argument checks (include/libsais.h:5210-5232)
     if (n <= 1) {
@@ -641,71 +755,146 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     hipStream_t s = lead->stream;
     for (s32 i = 0; i < n; i++) sts[i]->xs = s;  // see encode_group
     size_t need = 0;
+    bool any_lean = false;
     for (s32 i = 0; i < n; i++) {
         const size_t w = workspace_bytes_for(bz3_bound((size_t)sts[i]->block_size) + 64);
         if (w > need) need = w;
+        any_lean = any_lean || sts[i]->lean;
     }
-    // ---- phase 1: headers, then ONE CM launch ------------------------------------------------------------
-    std::vector<CmDecodeJob> cm_jobs;
+    // ---- phase 1: headers ----------------------------------------------------------------------------------
+    std::vector<s32> coded;
     for (s32 i = 0; i < n; i++) {
         decode_front(sts[i], bufs[i], buffer_sizes[i], sizes[i], orig_sizes[i], hdrs + 17 * (size_t)i);
-        if (sts[i]->pending == bz3_state::DEC_CODED)
-            cm_jobs.push_back(CmDecodeJob{dev_addr(sts[i]->cm_in), dev_addr(sts[i]->d_swap), sts[i]->cm_in_size, (u32)sts[i]->size_before_bwt, 0u, 0u});
+        if (sts[i]->pending == bz3_state::DEC_CODED) coded.push_back(i);
     }
-    size_t n_lzp = 0;
-    for (s32 i = 0; i < n; i++)
-        if (sts[i]->pending == bz3_state::DEC_CODED && (sts[i]->model & 2)) n_lzp++;
-    Arena arena = lead->ctx->arena_for(need + n_lzp * LZP_LUT_WORDS * 4 + (size_t)n * 256 + cm_scratch_bytes((size_t)n) + 4096);
-    float cm_ms = 0.f;
-    if (!cm_jobs.empty()) {
-        CmDecodeJob * d_jobs = arena.take<CmDecodeJob>(cm_jobs.size());
-        cm_ms = run_cm_jobs(lead->ctx, arena, cm_jobs, d_jobs, s, lead->ev0, lead->ev1,
-                            [](const CmDecodeJob * j, u32 nj, hipStream_t st, int variant) { cm_decode_batch(j, nj, st, variant); });
-    }
-    // ---- phase 2: inverse BWT per block; collect the LZP jobs --------------------------------------------
-    std::vector<LzpDecodeJob> lz_jobs;
-    LzpDecodeJob * d_lz = n_lzp ? arena.take<LzpDecodeJob>(n_lzp) : nullptr;
-    u32 * luts = n_lzp ? arena.take<u32>(n_lzp * LZP_LUT_WORDS) : nullptr;
-    std::vector<char> alive((size_t)n, 0);
-    for (s32 i = 0; i < n; i++) {
-        bz3_state * st = sts[i];
-        if (st->pending == bz3_state::DEC_STORED) {  // :686-691
-            HIP_CHECK(hipStreamSynchronize(st->xs));
-            if (read_word(st->xs, st->d_words + 1) != st->crc) st->last_error = BZ3_ERR_CRC;
-            else st->result = st->size;  // last_error untouched (:691)
-            continue;
+    // A lean state's CM output goes straight into the caller's buffer, which also holds the coded payload: that
+    // payload (a fraction of the block) is staged in the workspace first.  Rounds: as many blocks per CM launch as
+    // the staging budget holds (normally all of them).
+    auto stage_bytes = [&](s32 i) { return sts[i]->lean ? (((size_t)sts[i]->cm_in_size + 64 + 255) & ~(size_t)255) : (size_t)0; };
+    size_t stage_budget = (size_t)48 << 30;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (any_lean && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t have = lead->ctx->ws_cap;
+            const size_t room = free_b + have > need ? free_b + have - need : 0;
+            stage_budget = room - room / 4;  // leave a quarter for the swap buffers of the tail windows
         }
-        if (st->pending != bz3_state::DEC_CODED) continue;
-        if (!decode_unbwt(st, arena, cm_ms)) continue;
-        alive[(size_t)i] = 1;
-        if (st->model & 2) {
-            if (st->lzp_size < 4) {  // lzp_decompress: `if (n < 4) return -1` (:252) -> BZ3_ERR_CRC (:769-771)
-                st->last_error = BZ3_ERR_CRC;
-                alive[(size_t)i] = 0;
+    }
+    std::vector<size_t> round_end;  // indices into `coded`
+    size_t max_round = 0;
+    for (size_t k = 0; k < coded.size();) {
+        size_t bytes = 0, e = k;
+        while (e < coded.size() && (e == k || bytes + stage_bytes(coded[e]) <= stage_budget)) bytes += stage_bytes(coded[e++]);
+        round_end.push_back(e);
+        if (bytes > max_round) max_round = bytes;
+        k = e;
+    }
+    // tail windows: all blocks at once when every state owns its swap buffer, else as many as borrow one at a time
+    const s32 tail_window = any_lean ? 32 : n;
+    size_t lzp_in_window = 0;
+    for (s32 w0 = 0; w0 < n; w0 += tail_window) {
+        size_t c = 0;
+        for (s32 i = w0; i < n && i < w0 + tail_window; i++)
+            if (sts[i]->pending == bz3_state::DEC_CODED && (sts[i]->model & 2)) c++;
+        if (c > lzp_in_window) lzp_in_window = c;
+    }
+    Arena arena = lead->ctx->arena_for(need + lzp_in_window * (LZP_LUT_WORDS * 4 + 256) + (size_t)n * 256 + cm_scratch_bytes(coded.size()) + max_round + 65536);
+    // ---- phase 2: the CM launches (one workgroup per block) ------------------------------------------------------
+    float cm_ms = 0.f;
+    for (size_t r = 0, k0 = 0; r < round_end.size(); k0 = round_end[r++]) {
+        const size_t mk = arena.mark();
+        std::vector<CmDecodeJob> cm_jobs;
+        for (size_t k = k0; k < round_end[r]; k++) {
+            bz3_state * st = sts[coded[k]];
+            const u8 * in = st->cm_in;
+            if (st->lean) {
+                u8 * stage = arena.take<u8>(stage_bytes(coded[k]));
+                if (st->cm_in_size) HIP_CHECK(hipMemcpyAsync(stage, st->cm_in, st->cm_in_size, hipMemcpyDeviceToDevice, s));
+                in = stage;
+            }
+            cm_jobs.push_back(CmDecodeJob{dev_addr(in), dev_addr(st->lean ? st->user : st->d_swap), st->cm_in_size, (u32)st->size_before_bwt, 0u, 0u});
+        }
+        CmDecodeJob * d_jobs = arena.take<CmDecodeJob>(cm_jobs.size());
+        cm_ms += run_cm_jobs(lead->ctx, arena, cm_jobs, d_jobs, s, lead->ev0, lead->ev1,
+                             [](const CmDecodeJob * j, u32 nj, hipStream_t st, int variant) { cm_decode_batch(j, nj, st, variant); });
+        arena.release(mk);
+    }
+    // ---- phases 3-5 per tail window: inverse BWT per block, ONE LZP-decode launch (one workgroup per block), mRLE + CRC ----
+    for (s32 w0 = 0; w0 < n; w0 += tail_window) {
+        const s32 w1 = (w0 + tail_window < n) ? w0 + tail_window : n;
+        const size_t mk = arena.mark();
+        size_t n_lzp = 0;
+        for (s32 i = w0; i < w1; i++)
+            if (sts[i]->pending == bz3_state::DEC_CODED && (sts[i]->model & 2)) n_lzp++;
+        std::vector<LzpDecodeJob> lz_jobs;
+        std::vector<s32> lz_owner;
+        LzpDecodeJob * d_lz = n_lzp ? arena.take<LzpDecodeJob>(n_lzp) : nullptr;
+        u32 * luts = n_lzp ? arena.take<u32>(n_lzp * LZP_LUT_WORDS) : nullptr;
+        std::vector<char> alive((size_t)(w1 - w0), 0);
+        for (s32 i = w0; i < w1; i++) {
+            bz3_state * st = sts[i];
+            if (st->pending == bz3_state::DEC_STORED) {  // :686-691
+                HIP_CHECK(hipStreamSynchronize(st->xs));
+                if (read_word(st->xs, st->d_words + 1) != st->crc) st->last_error = BZ3_ERR_CRC;
+                else st->result = st->size;  // last_error untouched (:691)
                 continue;
             }
-            const size_t bound = bz3_bound((size_t)st->block_size);
-            lz_jobs.push_back(LzpDecodeJob{dev_addr(st->b1), dev_addr(st->b2), dev_addr(luts + lz_jobs.size() * LZP_LUT_WORDS), dev_addr(st->d_words + 5),
-                                           (u32)st->lzp_size, (u32)bound});
+            if (st->pending != bz3_state::DEC_CODED) continue;
+            lean_borrow(st);
+            if (!decode_unbwt(st, arena, cm_ms)) continue;
+            alive[(size_t)(i - w0)] = 1;
+            if (st->model & 2) {
+                if (st->lzp_size < 4) {  // lzp_decompress: `if (n < 4) return -1` (:252) -> BZ3_ERR_CRC (:769-771)
+                    st->last_error = BZ3_ERR_CRC;
+                    alive[(size_t)(i - w0)] = 0;
+                    continue;
+                }
+                // The reference decodes into its swap buffer (bz3_bound(block_size) bytes) and compares with buffer_size
+                // afterwards (:767-781).  A lean state decodes into the caller's buffer, so the cap is the smaller of the two;
+                // decode_finish tells the two failures apart.
+                const size_t bound = bz3_bound((size_t)st->block_size);
+                const size_t room = st->lean && st->buffer_size < bound ? st->buffer_size : bound;
+                lz_jobs.push_back(LzpDecodeJob{dev_addr(st->b1), dev_addr(st->b2), dev_addr(luts + lz_jobs.size() * LZP_LUT_WORDS), dev_addr(st->d_words + 5),
+                                               (u32)st->lzp_size, (u32)room});
+                lz_owner.push_back(i);
+            }
         }
+        if (!lz_jobs.empty()) {
+            const double t0 = now_ms();
+            lzp_decode_batch(lz_jobs.data(), d_lz, (u32)lz_jobs.size(), s);
+            HIP_CHECK(hipStreamSynchronize(s));
+            const float ms = (float)(now_ms() - t0);
+            for (s32 i : lz_owner) sts[i]->t[BZ3_HIP_T_LZP] = ms;
+            // lean state whose buffer is smaller than the reference's swap buffer: the decoder stops at the cap (:211) and
+            // returns it, where the reference would have gone on to bz3_bound(block_size) and then either reported a larger
+            // size (-> BZ3_ERR_DATA_SIZE_TOO_SMALL, :776) or run into malformed input (-> BZ3_ERR_CRC): when the cap was
+            // reached, decode once more into a borrowed buffer of the reference's size and keep that verdict
+            for (size_t k = 0; k < lz_jobs.size(); k++) {
+                bz3_state * st = sts[lz_owner[k]];
+                const size_t bound = bz3_bound((size_t)st->block_size);
+                if (!st->lean || st->buffer_size >= bound || read_word(s, st->d_words + 5) != lz_jobs[k].max_out) continue;
+                u8 * big = st->ctx->temp_get(st->cap);
+                LzpDecodeJob again = lz_jobs[k];
+                again.out = dev_addr(big);
+                again.max_out = (u32)bound;
+                again.lut = dev_addr(luts);
+                lzp_decode_batch(&again, d_lz, 1u, s);
+                HIP_CHECK(hipStreamSynchronize(s));
+                st->ctx->temp_put(big);
+            }
+        }
+        for (s32 i = w0; i < w1; i++) {
+            if (alive[(size_t)(i - w0)]) decode_finish(sts[i], arena);
+            lean_return(sts[i]);
+        }
+        arena.release(mk);
     }
-    // ---- phase 3: ONE LZP-decode launch (one workgroup per block) -----------------------------------------
-    if (!lz_jobs.empty()) {
-        const double t0 = now_ms();
-        lzp_decode_batch(lz_jobs.data(), d_lz, (u32)lz_jobs.size(), s);
-        HIP_CHECK(hipStreamSynchronize(s));
-        const float ms = (float)(now_ms() - t0);
-        for (s32 i = 0; i < n; i++)
-            if (alive[(size_t)i] && (sts[i]->model & 2)) sts[i]->t[BZ3_HIP_T_LZP] = ms;
-    }
-    // ---- phase 4: mRLE, CRC ---------------------------------------------------------------------------------
-    for (s32 i = 0; i < n; i++)
-        if (alive[(size_t)i]) decode_finish(sts[i], arena);
     for (s32 i = 0; i < n; i++) sts[i]->pending = bz3_state::NONE;
 }
 
 void on_failure(bz3_state * st) {
     if (st) {
+        lean_return(st);
         st->last_error = BZ3_ERR_BWT;
         st->pending = bz3_state::NONE;
         st->result = -1;
@@ -822,7 +1011,8 @@ BZIP3_API struct bz3_state * bz3_new(int32_t block_size) {
         HIP_CHECK(hipEventCreate(&st->ev0));
         HIP_CHECK(hipEventCreate(&st->ev1));
         st->cap = (bz3_bound((size_t)block_size) + 4096 + 255) & ~(size_t)255;
-        HIP_CHECK(hipMalloc((void **)&st->d_swap, st->cap));
+        st->lean = lean_states();
+        if (!st->lean) HIP_CHECK(hipMalloc((void **)&st->d_swap, st->cap));
         HIP_CHECK(hipMalloc((void **)&st->d_words, 64 * sizeof(u32)));
         st->last_error = BZ3_OK;
         return st;
@@ -1122,6 +1312,29 @@ BZIP3_API int bz3_hip_set_cm_mode(int mode) {
 
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void) { return g_cm_given_up.load(); }
 
+BZIP3_API int bz3_hip_set_lean_states(int on) {
+    g_lean.store(on ? 1 : 0);
+    return 0;
+}
+
+BZIP3_API void bz3_hip_release_cached_memory(void) {
+    const int n = device_count();
+    for (int d = 0; d < n; d++) {
+        DeviceCtx * c = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            c = g_ctx[(size_t)d];
+        }
+        if (!c) continue;
+        (void)hipSetDevice(d);
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->temp_trim();
+        if (c->ws) (void)hipFree(c->ws);
+        c->ws = nullptr;
+        c->ws_cap = 0;
+    }
+}
+
 BZIP3_API void bz3_hip_last_timings(struct bz3_state * st, float ms[BZ3_HIP_T_COUNT]) {
     for (int i = 0; i < BZ3_HIP_T_COUNT; i++) ms[i] = st->t[i];
 }
@@ -1296,7 +1509,7 @@ BZIP3_API int32_t bz3_hip_stage_unbwt(const uint8_t * in, uint8_t * out, int32_t
 // row-cache kernel gives up is coded again by the full-model kernel, as in run_cm_jobs.
 extern "C++" template <class Job, class Launch>
 void stage_cm_job(StageEnv & e, Job job, Launch && go) {
-    const int variant = cm_variant_for(e.ctx, 1);
+    const int variant = cm_variant_for(e.ctx, 1, std::is_same<Job, CmEncodeJob>::value);
     u32 * status = nullptr;
     if (variant != CM_VARIANT_FULL) {
         job.spill = dev_addr(e.dev(CM_SPILL_BYTES));
@@ -1322,10 +1535,31 @@ BZIP3_API int32_t bz3_hip_stage_cm_encode(const uint8_t * in, int32_t n, uint8_t
         u32 * w = (u32 *)e.dev(64);
         const char * dbg = getenv("BZ3_CM_DEBUG");  // profiling only: 1 = coder alone, 2 = model alone (output invalid)
         CmEncodeJob job{dev_addr(d), dev_addr(o), dev_addr(w), (u32)n, dbg ? (u32)atoi(dbg) : 0u};
+        // tests: BZ3_CM_TEST_GAP=<g> codes IN PLACE, the input g bytes above the output in one buffer (cm.hip CmSink), with a
+        // side buffer of BZ3_CM_TEST_SIDE bytes (default 64 KiB); returns -1 when the side buffer overflowed
+        const char * tg = getenv("BZ3_CM_TEST_GAP");
+        u8 * side = nullptr;
+        if (tg) {
+            const size_t g = (size_t)atol(tg);
+            const char * ts = getenv("BZ3_CM_TEST_SIDE");
+            const size_t side_cap = ts ? (size_t)atol(ts) : CM_SIDE_BYTES;
+            u8 * both = e.dev(g + (size_t)n + 64);
+            HIP_CHECK(hipMemcpy(both + g, d, (size_t)n, hipMemcpyDeviceToDevice));
+            side = e.dev(side_cap + 64);
+            o = both;
+            job.in = dev_addr(both + g);
+            job.out = dev_addr(both);
+            job.gap = (u32)g;
+            job.side = dev_addr(side);
+            job.side_cap = (u32)side_cap;
+        }
         stage_cm_job(e, job, [](const CmEncodeJob * j, u32 nj, hipStream_t st, int variant) { cm_encode_batch(j, nj, st, variant); });
-        const s32 size = (s32)e.word(w);
-        e.down(out, o, (size_t)size);
-        return size;
+        const u32 coded = e.word(w), sw = e.word(w + 1);
+        if (coded == 0xFFFFFFFFu) return -1;
+        const u32 head = (tg && sw < coded) ? sw : coded;
+        e.down(out, o, (size_t)head);
+        if (head < coded) e.down(out + head, side, (size_t)(coded - head));
+        return (s32)coded;
     });
 }
 

@@ -52,6 +52,13 @@ __device__ __forceinline__ u32 cm_uniform(u32 v) {
 #endif
 }
 
+// Issue priority of the calling wave among the waves of its SIMD (s_setprio 3 = highest user level).
+__device__ __forceinline__ void cm_raise_priority() {
+#ifndef BZ3_EMU
+    __builtin_amdgcn_s_setprio(3);
+#endif
+}
+
 template <class M>
 __device__ __forceinline__ void cm_model_init(M & m) {  // begin(): :350-358
     for (int i = threadIdx.x; i < M::ROWS * 256; i += blockDim.x) m.c1[i] = 32768;
@@ -337,9 +344,34 @@ __device__ __forceinline__ bool cm_code_bits(const uint4 (&ev)[8], u32 & r, u32 
     }
     return (l ^ (l + r)) < (1u << 24) || rmin == 0u;
 }
+// Where the coded bytes go.  Normally `out`, a buffer of its own.  In-place coding (gap != CM_NO_GAP): `out` lies
+// `gap` bytes BELOW the input inside the same buffer, so a byte may only be stored below the input bytes that every
+// model wave has already loaded: while byte i is being coded these are the chunks up to and including the one that
+// holds i.  Compressed output trails its input by construction; should it ever catch up (the prefix coded so far
+// expands by more than the buffer's slack, the n/50 + 32 bytes bz3_bound adds) the sink switches, for the rest of
+// the block, to the side buffer, and the host appends that part once the input is dead.
+struct CmSink {
+    u8 * __restrict__ out;
+    u8 * __restrict__ side;
+    u32 gap, side_cap, n;
+    u32 op = 0;                // bytes coded so far
+    u32 sw = 0xFFFFFFFFu;      // first byte that went to the side buffer
+    u32 failed = 0;            // side buffer exhausted
+    __device__ __forceinline__ void put(u32 byte, u32 i) {
+        if (sw == 0xFFFFFFFFu && gap != CM_NO_GAP) {
+            const u32 loaded = (i | (CM_CHUNK - 1u)) + 1u;  // input bytes below this index are in registers
+            if ((u64)op >= (u64)gap + (loaded < n ? loaded : n)) sw = op;
+        }
+        if (sw == 0xFFFFFFFFu) out[op] = (u8)byte;
+        else if (op - sw < side_cap) side[op - sw] = (u8)byte;
+        else failed = 1;
+        op++;
+    }
+};
+
 // The same steps with the reference's test after every bit (:390-394).
 template <int K0, int CNT>
-__device__ __forceinline__ void cm_code_bits_checked(const uint4 (&ev)[8], u32 & range, u32 & low, u8 * __restrict__ out, u32 & op) {
+__device__ __forceinline__ void cm_code_bits_checked(const uint4 (&ev)[8], u32 & range, u32 & low, CmSink & sink, u32 i) {
 #pragma unroll
     for (int kk = K0; kk < K0 + CNT; kk++) {
         const uint4 e = ev[kk];
@@ -349,7 +381,7 @@ __device__ __forceinline__ void cm_code_bits_checked(const uint4 (&ev)[8], u32 &
         range = r2;
         if (__builtin_expect(__ballot(range < (1u << 24)) != 0ull, 0)) {  // necessary for (low ^ high) < 2^24; the exact test follows
             while (__ballot((low ^ (low + range)) < (1u << 24)) != 0ull) {  // :390-394
-                out[op++] = (u8)(low >> 24);
+                sink.put(low >> 24, i);
                 low <<= 8;
                 range = (range << 8) | 0xFFu;
             }
@@ -396,7 +428,8 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     const u32 n = jobs[blockIdx.x].n;
     u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
     u32 * __restrict__ out_size = global_ptr<u32>(jobs[blockIdx.x].out_size);
-    const u32 debug = jobs[blockIdx.x].debug;
+    const u32 debug = jobs[blockIdx.x].debug & 15u;
+    const u32 tune = jobs[blockIdx.x].debug >> 4;  // experiments: bit 0 = raise the coder wave's issue priority
     __shared__ CmLdsT<R> m;
     __shared__ uint4 ring[CM_RING * 8];
     __shared__ CmEvent ev_a[6 * CM_CHUNK], ev_b[CM_CHUNK], ev_c[CM_CHUNK];
@@ -429,6 +462,10 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
         CmRowState rs;
         u16 * __restrict__ spill = global_ptr<u16>(jobs[blockIdx.x].spill);
         const u32 miss_base = jobs[blockIdx.x].miss_base, miss_shift = jobs[blockIdx.x].miss_shift;
+        // In-place coding: giving a block up is only possible while the coded bytes cannot have reached the input
+        // yet (the full-model kernel will read that input again): output <= bz3_bound(position) < gap.
+        const u32 gap = jobs[blockIdx.x].gap;
+        const u32 abort_limit = gap == CM_NO_GAP ? 0xFFFFFFFFu : (gap > 4096u ? (u32)(((u64)(gap - 2048u) * 32u) / 33u) : 0u);
         u32 hrow1 = 0, hrow2 = 0;  // slots of bytes -1 and -2 (byte value 0 before the block starts: slot 0)
         if (R) cm_rows_init<R>(rc);
         for (u32 base = 0; base < n; base += CM_CHUNK) {
@@ -443,7 +480,7 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
             if (R) {
                 rowv = role == 3 ? cm_rows_chunk<R, 2>(m, rc, rs, spill, mine, cnt, hrow1, hrow2, L.node)
                                  : cm_rows_chunk<R, 1>(m, rc, rs, spill, mine, cnt, hrow1, hrow2, L.node);
-                if (__builtin_expect(rs.misses > miss_base + (base >> miss_shift), 0)) {
+                if (__builtin_expect(rs.misses > miss_base + (base >> miss_shift) && base < abort_limit, 0)) {
                     // the working set does not fit: give the block up (every model wave gets here at the same chunk)
                     if (role == 1 && lane == 0) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
                     LDS_POKE(s_prod[role - 1], CM_ABORT_MARK);
@@ -492,13 +529,15 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     }
     // ---- coder wave: ONE active lane (an LDS read then returns 16 bytes, not 64 x 16) ------------------------
     if (debug == 2 || lane != 0) return;
+    if (tune & 1u) cm_raise_priority();
     u32 vzero;
 #ifdef BZ3_EMU
     vzero = 0;
 #else
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));  // opaque zero: keeps the recurrence on the vector ALU
 #endif
-    u32 range = 0xFFFFFFFFu ^ vzero, low = vzero, op = 0, prod_seen = debug == 1 ? 0xFFFFFFFFu : 0u;
+    u32 range = 0xFFFFFFFFu ^ vzero, low = vzero, prod_seen = debug == 1 ? 0xFFFFFFFFu : 0u;
+    CmSink sink{out, global_ptr<u8>(jobs[blockIdx.x].side), jobs[blockIdx.x].gap, jobs[blockIdx.x].side_cap, n};
     for (u32 i = 0; i < n; i++) {
         while (prod_seen <= i) {
             const u32 a = LDS_PEEK(s_prod[0]), b = LDS_PEEK(s_prod[1]), c = LDS_PEEK(s_prod[2]);
@@ -529,28 +568,29 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
                     range = r;
                     low = l;
                 } else {
-                    cm_code_bits_checked<0, 4>(ev, range, low, out, op);
+                    cm_code_bits_checked<0, 4>(ev, range, low, sink, i);
                 }
                 r = range, l = low;
                 if (__ballot(cm_code_bits<4, 4>(ev, r, l)) == 0ull) {
                     range = r;
                     low = l;
                 } else {
-                    cm_code_bits_checked<4, 4>(ev, range, low, out, op);
+                    cm_code_bits_checked<4, 4>(ev, range, low, sink, i);
                 }
             }
         }
         if ((i & 15u) == 15u) LDS_POKE(s_cons, i + 1);
     }
     for (int j = 0; j < 4; j++) {  // flush (:425-432)
-        out[op + j] = (u8)(low >> 24);
+        sink.put(low >> 24, n - 1u);
         low <<= 8;
     }
-    *out_size = op + 4;
+    out_size[0] = sink.failed ? 0xFFFFFFFFu : sink.op;
+    out_size[1] = sink.sw;
 }
 
 constexpr int CM_ROWS_ENC = 96;   // 48 KiB of C1 rows: 79.5 KB of LDS per workgroup, two workgroups per CU
-constexpr int CM_ROWS_DEC = 112;  // 56 KiB of C1 rows: 80.6 KB of LDS per workgroup
+constexpr int CM_ROWS_DEC = 96;   // 48 KiB of C1 rows: 72.1 KB of LDS per workgroup (112 rows = 80.6 KB: measured, two of those do NOT share a CU)
 constexpr int CM_ROWS3_ENC = 44;  // 22 KiB of C1 rows: 52.9 KB of LDS per workgroup, three workgroups per CU (a chunk pins up to 34 rows)
 constexpr int CM_ROWS3_DEC = 56;  // 28 KiB of C1 rows: 50.8 KB of LDS per workgroup
 #ifdef BZ3_EMU
@@ -662,7 +702,8 @@ __device__ __forceinline__ void cm_decode_block(const CmDecodeJob * __restrict__
     const u32 in_size = jobs[blockIdx.x].in_size;
     u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
     const u32 n = jobs[blockIdx.x].n;
-    const u32 debug = jobs[blockIdx.x].debug;  // 3: cycle counters instead of the first output bytes (profiling only)
+    const u32 debug = jobs[blockIdx.x].debug & 15u;  // 3: cycle counters instead of the first output bytes (profiling only)
+    const u32 tune = jobs[blockIdx.x].debug >> 4;    // experiments: bit 0 = raise the walker's issue priority, bit 1 = model waves sleep while they poll
     __shared__ CmLdsT<R> m;
     __shared__ u32 ptab[2][256];  // (18-bit probability of node) << 14
     __shared__ __attribute__((aligned(16))) u32 s_ready[4];  // per model wave: 2i+1 = speculative table of byte i is there, 2i+2 = corrected one
@@ -723,6 +764,7 @@ __device__ __forceinline__ void cm_decode_block(const CmDecodeJob * __restrict__
             for (;;) {
                 word = cm_uniform(LDS_PEEK(s_done));
                 if ((word >> 8) == tag) break;
+                if (tune & 2u) BZ3_SPIN_PAUSE();
                 BZ3_SPIN_TIGHT();
             }
             const u32 c = word & 0xFFu;
@@ -790,6 +832,7 @@ __device__ __forceinline__ void cm_decode_block(const CmDecodeJob * __restrict__
         return;
     }
     // ---- walker ---------------------------------------------------------------------------------------------
+    if (tune & 1u) cm_raise_priority();
     // lane l assumes bits b0..b5 = l; nbK = all-ones where the assumed bit of level K is 0
     const u32 ul = (u32)lane;
     const bool as0 = (ul >> 5) & 1u, as1 = (ul >> 4) & 1u, as2 = (ul >> 3) & 1u, as3 = (ul >> 2) & 1u, as4 = (ul >> 1) & 1u, as5 = ul & 1u;

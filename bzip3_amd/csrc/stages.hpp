@@ -92,16 +92,22 @@ size_t unbwt_workspace_bytes(u64 n);
 // One workgroup (= one CU: the 145.5 KiB model fills its LDS) per block; a batch is ONE launch with
 // grid = number of blocks, so the blocks of bz3_encode_blocks / bz3_decode_blocks run side by side without
 // depending on how HIP maps streams to hardware queues.  Asynchronous.  Job arrays live in device memory.
+constexpr u32 CM_NO_GAP = 0xFFFFFFFFu;
 struct CmEncodeJob {  // device addresses as integers: see prims.hpp global_ptr()
     u64 in;
     u64 out;       // receives the coded bytes
-    u64 out_size;  // u32 *: receives the coded byte count
+    u64 out_size;  // u32[2] *: [0] receives the coded byte count
     u32 n;
     u32 debug;     // 0 = normal; profiling only (output invalid): 1 = coder wave alone, 2 = model waves alone
     // row-cache variants only (CM_VARIANT_ROWS*):
-    u64 spill;     // u16[256][256] scratch of this block: the order-1 rows that are not resident in LDS
-    u64 status;    // u32 *, zeroed by the caller: set to 1 when the kernel gave the block up (code it again with CM_VARIANT_FULL)
-    u32 miss_base, miss_shift;  // give up once row misses > miss_base + (position >> miss_shift)
+    u64 spill = 0;   // u16[256][256] scratch of this block: the order-1 rows that are not resident in LDS
+    u64 status = 0;  // u32 *, zeroed by the caller: set to 1 when the kernel gave the block up (code it again with CM_VARIANT_FULL)
+    u32 miss_base = 0, miss_shift = 0;  // give up once row misses > miss_base + (position >> miss_shift)
+    // in-place coding (cm.hip CmSink): `out` lies `gap` bytes below `in` in the same buffer; CM_NO_GAP = separate buffers.
+    // out_size[1] receives the index of the first coded byte that went to `side` instead (0xFFFFFFFF: none);
+    // out_size[0] = 0xFFFFFFFF when `side` overflowed.
+    u32 gap = CM_NO_GAP, side_cap = 0;
+    u64 side = 0;
 };
 struct CmDecodeJob {
     u64 in;        // coded bytes; reads past in_size yield 0xFF.. like read_in (:345)

@@ -31,14 +31,26 @@ BZIP3_API int bz3_hip_bind_device(int device);
 BZIP3_API int bz3_hip_state_device(struct bz3_state * state);
 
 /* CM kernel variant (process-wide).  0 = the whole 145.5 KiB model in LDS, one block per CU; 1 / 2 = row-cache
- * kernels (the order-1 rows a block uses are cached in LDS -- 96/112 or 44/56 of them --, the others spill to HBM:
+ * kernels (the order-1 rows a block uses are cached in LDS -- 96 or 44/56 of them --, the others spill to HBM:
  * two / three blocks per CU; a block whose working set does not fit is handed back to variant 0 automatically);
- * -1 = automatic (default): variant 1 only when a batch holds more blocks than the GPU has CUs, variant 2 beyond
- * twice that.  Environment BZ3_HIP_CM_MODE=auto|full|rows|rows3 has the same effect.  Output bytes do not depend on
- * the variant.  Returns 0, or -1 for an invalid mode. */
+ * -1 = automatic (default): the row-cache encoder when a batch holds more blocks than the GPU has CUs, the
+ * row-cache decoder beyond twice that (measured: two decoder blocks per CU gain nothing).  Environment
+ * BZ3_HIP_CM_MODE=auto|full|rows|rows3 has the same effect.  Output bytes do not depend on the variant.
+ * Returns 0, or -1 for an invalid mode. */
 BZIP3_API int bz3_hip_set_cm_mode(int mode);
 /* Number of blocks the row-cache kernels have handed back to the full-model kernels so far (statistics). */
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void);
+
+/* Lean states (process-wide switch, read by bz3_new; environment BZ3_HIP_LEAN=1 has the same effect).  A state
+ * normally owns its swap buffer (the reference's swap_buffer, bz3_bound(block_size) bytes of HBM) for life, so a
+ * batch of N blocks holds 2 N block-sized buffers.  A lean state owns none: it borrows one from a per-GPU pool only
+ * while its block is in the whole-GPU stages, the CM encoder works in place in the caller's buffer (input at the end
+ * of the bz3_bound(size) bytes the API guarantees, coded bytes growing from the start), and the CM decoder reads a
+ * staged copy of the coded payload -- about 1.2 block-sized buffers per block in flight, which is what lets 3 x 256
+ * blocks of 256 MiB share one MI355X.  Output bytes, return values and error codes are the same.  Returns 0. */
+BZIP3_API int bz3_hip_set_lean_states(int on);
+/* Frees the per-GPU workspace and the idle pooled swap buffers (they are otherwise kept for the next call). */
+BZIP3_API void bz3_hip_release_cached_memory(void);
 
 /* Device-resident variants: `buffer` / `buffers[i]` are device addresses on the state's GPU with the
  * same capacities the host API requires (bz3_bound(size) for encode; buffer_size for decode). */

@@ -250,3 +250,94 @@ def test_batch_api_through_row_cache_kernels(emu, oracle, cm_mode):
         assert emu.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: len(d)]) == d
     for s in states:
         emu.bz3_free(s)
+
+
+# ---- lean states (bz3_hip_set_lean_states): no per-state swap buffer, in-place CM encode, staged CM decode -----------
+@pytest.fixture()
+def lean(emu):
+    emu.bz3_hip_set_lean_states(1)
+    yield
+    emu.bz3_hip_set_lean_states(0)
+    emu.bz3_hip_set_cm_mode(-1)
+
+
+@pytest.mark.parametrize("name", ["empty", "63", "65", "runs", "f2", "nearmiss", "rand9k", "repeats"])
+def test_lean_block_parity(emu, oracle, lean, name):
+    d = CASES[name]
+    bs = 65 * 1024
+    for mode in (-1, 9):  # full-model kernels; row-cache kernels (in-place coding restricts when a block may be given up)
+        assert emu.bz3_hip_set_cm_mode(mode) == 0
+        with bzip3_amd.State(bs, emu) as st:
+            a = st.encode_block(d)
+            assert a == oracle.encode_block(d, bs)
+            r = st.decode_block(a[2], len(d))
+            assert (r[:2] == (len(d), 0) or len(d) == 0) and r[2] == d
+
+
+def test_lean_decoder_error_codes_and_small_buffers(emu, oracle, lean):
+    bs = 65 * 1024
+    t = datagen.shakespeare()
+    plain = (t[:3000] * 4) + t[5000:9000]  # LZP applies (model & 2): the lean LZP decoder writes into the caller's buffer
+    blk = oracle.encode_block(plain, bs)[2]
+    assert blk[8] & 2
+    n = len(plain)
+    muts = [blk[: len(blk) // 2], blk[:4] + b"\0\0\0\0" + blk[8:], blk[:8] + b"\x7f" + blk[9:], blk[:30] + bytes([blk[30] ^ 1]) + blk[31:],
+            blk[:9] + (5).to_bytes(4, "little") + blk[13:], blk[:9] + (n + 40000).to_bytes(4, "little") + blk[13:]]
+    with bzip3_amd.State(bs, emu) as st:
+        assert st.decode_block(blk, n)[2] == plain
+        for m in muts:
+            assert st.decode_block(m, n)[:2] == oracle.decode_block(m, n, bs)[:2]
+        # buffers smaller than the reference's swap buffer: same verdicts (DATA_SIZE_TOO_SMALL vs CRC)
+        for bsz, cs, osz in [(n, len(blk), n), (n + 1, len(blk), n), (len(blk), len(blk), n), (n - 1, len(blk), n), (n, len(blk), n - 1),
+                             (n // 2, len(blk), n // 2), (70000, len(blk), n), (5, len(blk), n)]:
+            assert st.decode_block(blk, osz, buffer_size=bsz, comp_size=cs)[:2] == oracle.decode_block(blk, osz, bs, buffer_size=bsz, comp_size=cs)[:2], (bsz, cs, osz)
+        n2, err, _ = st.encode_block(b"x" * (bs + 1))
+        assert (n2, err) == (-1, bzip3_amd.BZ3_ERR_DATA_TOO_BIG)
+
+
+def test_lean_batch_and_frame(emu, oracle, lean):
+    assert emu.bz3_hip_set_cm_mode(9) == 0
+    bs = 65 * 1024
+    t = datagen.shakespeare()
+    blocks = [t[:3000], datagen.random_bytes(2500), b"tiny", t[5000:8000] * 3, b"", datagen.low_entropy(3000)]
+    n = len(blocks)
+    states = (C.c_void_p * n)(*[emu.bz3_new(bs) for _ in range(n)])
+    cap = emu.bz3_bound(bs) + 64
+    bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+    for b, d in zip(bufs, blocks):
+        C.memmove(b, d, len(d))
+    ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+    emu.bz3_encode_blocks(states, ptrs, sizes, n)
+    for i, d in enumerate(blocks):
+        assert bytes(bufs[i][: sizes[i]]) == oracle.encode_block(d, bs)[2], i
+    bsz = (C.c_size_t * n)(*[cap] * n)
+    orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+    emu.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+    for i, d in enumerate(blocks):
+        assert bytes(bufs[i][: len(d)]) == d, i
+    for s in states:
+        emu.bz3_free(s)
+    emu.bz3_hip_release_cached_memory()
+    import frame_cases
+
+    rng = np.random.default_rng(4)
+    unit = bytes(rng.integers(0, 256, size=997, dtype=np.uint8))
+    frame_cases.check(emu, (unit * 400)[: 4 * 65 * 1024 + 1234], 65 * 1024, only=("cut9", "flip_chunk1", "orig_small", "n_blocks_2"))
+
+
+def test_cm_in_place_sink(emu, oracle):
+    """cm.hip CmSink through the stage hook: the coder's output starts `gap` bytes below its input in ONE buffer; when the
+    coded bytes would reach input that is not in registers yet they go to the side buffer instead (stitched by the caller);
+    an exhausted side buffer is an error, never a silent overwrite."""
+    d = datagen.random_bytes(2600)
+    c = oracle.cm_encode(d)
+    try:
+        for gap, side, ok in ((0, 65536, True), (7, 65536, True), (90, 65536, True), (2590, 65536, True), (10, 100, False)):
+            os.environ["BZ3_CM_TEST_GAP"], os.environ["BZ3_CM_TEST_SIDE"] = str(gap), str(side)
+            out = (C.c_uint8 * (len(d) + 200))()
+            n = emu.bz3_hip_stage_cm_encode(bzip3_amd._cbuf(d, len(d)), len(d), out)
+            assert (n == len(c) and C.string_at(out, n) == c) if ok else n == -1, (gap, side, n)
+    finally:
+        os.environ.pop("BZ3_CM_TEST_GAP", None)
+        os.environ.pop("BZ3_CM_TEST_SIDE", None)

@@ -274,6 +274,68 @@ def test_cm_row_cache_kernels_on_gpu(gpu_lib, oracle, text):
         gpu_lib.bz3_hip_set_cm_mode(-1)
 
 
+def test_lean_states_on_gpu(gpu_lib, oracle, text):
+    """Lean states (bz3_hip_set_lean_states): no per-state swap buffer, the CM encoder works in place in the caller's
+    buffer, the CM decoder reads a staged copy of the payload, the tail runs in windows.  Same bytes, return values and
+    error codes: block parity on every case, a batch, the device-resident entry points, 300 mutated blocks, and small
+    caller buffers (the LZP decoder writes into the caller's buffer instead of a bz3_bound-sized swap buffer)."""
+    import mutants
+
+    try:
+        assert gpu_lib.bz3_hip_set_lean_states(1) == 0
+        for mode in (-1, 1):
+            assert gpu_lib.bz3_hip_set_cm_mode(mode) == 0
+            for name in sorted(CASES):
+                d = CASES[name]
+                bs = max(65 * 1024, len(d))
+                with bzip3_amd.State(bs, gpu_lib) as st:
+                    a = st.encode_block(d)
+                    assert a == oracle.encode_block(d, bs), (mode, name)
+                    r = st.decode_block(a[2], len(d))
+                    assert (r[:2] == (len(d), 0) or len(d) == 0) and r[2] == d, (mode, name)
+        assert gpu_lib.bz3_hip_set_cm_mode(-1) == 0
+        # batch through the host-buffer API
+        bs = 1 << 20
+        blocks = [text[i * 700000 : i * 700000 + 700000 - i * 1000] for i in range(5)] + [b"tiny", datagen.random_bytes(300000, seed=9), b""]
+        n = len(blocks)
+        states = (C.c_void_p * n)(*[gpu_lib.bz3_new(bs) for _ in range(n)])
+        assert all(states)
+        cap = gpu_lib.bz3_bound(bs) + 64
+        bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+        for b, d in zip(bufs, blocks):
+            C.memmove(b, d, len(d))
+        ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+        sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+        gpu_lib.bz3_encode_blocks(states, ptrs, sizes, n)
+        for i, d in enumerate(blocks):
+            assert bytes(bufs[i][: sizes[i]]) == oracle.encode_block(d, bs)[2], i
+        bsz = (C.c_size_t * n)(*[cap] * n)
+        orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+        gpu_lib.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+        for i, d in enumerate(blocks):
+            assert bytes(bufs[i][: len(d)]) == d, i
+        for s in states:
+            gpu_lib.bz3_free(s)
+        # hostile input
+        data = mutants.seeds()
+        enc = [oracle.encode_block(d, mutants.BS)[2] for d in data]
+        for m, osz in mutants.mutants(enc, [len(d) for d in data], 300, seed=77):
+            a, b = bzip3_amd.decode_block(m, osz, mutants.BS, gpu_lib), oracle.decode_block(m, osz, mutants.BS)
+            assert a[:2] == b[:2] and (a[0] < 0 or a[2] == b[2]), (len(m), osz, a[:2], b[:2])
+        # caller buffers smaller than bz3_bound(block_size)
+        plain = (text[:3000] * 4) + text[5000:9000]
+        blk = oracle.encode_block(plain, mutants.BS)[2]
+        k = len(plain)
+        with bzip3_amd.State(mutants.BS, gpu_lib) as st:
+            for bsz_, cs, osz in [(k, len(blk), k), (k + 1, len(blk), k), (len(blk), len(blk), k), (k - 1, len(blk), k), (k, len(blk), k - 1),
+                                  (k // 2, len(blk), k // 2), (70000, len(blk), k), (5, len(blk), k)]:
+                assert st.decode_block(blk, osz, buffer_size=bsz_, comp_size=cs)[:2] == oracle.decode_block(blk, osz, mutants.BS, buffer_size=bsz_, comp_size=cs)[:2]
+    finally:
+        gpu_lib.bz3_hip_set_lean_states(0)
+        gpu_lib.bz3_hip_set_cm_mode(-1)
+        gpu_lib.bz3_hip_release_cached_memory()
+
+
 def test_device_resident_api(gpu_lib, oracle, text):
     import torch
 

@@ -1,5 +1,5 @@
 """CM kernel variants side by side on the GPU box (no torch import):
-    python tools/cm_rows_probe.py [block MiB=16] [cfg ...]      cfg = <mode>:<blocks>, mode = full | rows | rows3 | auto
+    python tools/cm_rows_probe.py [block MiB=16] [cfg ...]      cfg = <mode>:<blocks>[:<tune>], mode = full | rows | rows3 | auto, tune = BZ3_CM_TUNE bits
 For every configuration: bz3_encode_blocks + bz3_decode_blocks on host buffers (text blocks, 64 KiB pieces of one
 Markov text in a block-specific order), round trip verified, CM launch times from the library's HIP events.
 Prints one JSON line per configuration."""
@@ -19,6 +19,14 @@ import datagen  # noqa: E402
 MODES = {"auto": -1, "full": 0, "rows": 1, "rows3": 2}
 
 
+T0 = time.time()
+
+
+def note(msg):
+    sys.stderr.write(f"[{time.time() - T0:7.1f}s] {msg}\n")
+    sys.stderr.flush()
+
+
 def main():
     mib = float(sys.argv[1]) if len(sys.argv) > 1 else 16
     cfgs = sys.argv[2:] or ["full:256", "rows:512"]
@@ -30,25 +38,33 @@ def main():
     npieces = n // piece
     cap = lib.bz3_bound(n) + 64
     for cfg in cfgs:
-        mode, nblk = cfg.split(":")
+        mode, nblk, *tune = cfg.split(":")
         nblk = int(nblk)
+        os.environ["BZ3_CM_TUNE"] = tune[0] if tune else "0"
         assert lib.bz3_hip_set_cm_mode(MODES[mode]) == 0
         rng = np.random.default_rng(17)
         bufs, plain = [], []
-        for k in range(nblk):
+        variants = []  # 8 distinct blocks, reused round robin (the CM time of a block does not depend on its neighbours)
+        for k in range(min(8, nblk)):
             d = base if k == 0 else np.concatenate([base[: npieces * piece].reshape(npieces, piece)[rng.permutation(npieces)].reshape(-1), base[npieces * piece:]])
+            variants.append((np.ascontiguousarray(d), int(d.sum(dtype=np.uint64))))
+        for k in range(nblk):
+            d, sm = variants[k % len(variants)]
             b = (C.c_uint8 * cap)()
             C.memmove(b, d.ctypes.data, n)
             bufs.append(b)
-            plain.append(int(d.astype(np.uint64).sum()))
+            plain.append(sm)
+        note(f"{cfg}: buffers ready")
         states = (C.c_void_p * nblk)(*[lib.bz3_new(n) for _ in range(nblk)])
         assert all(states)
+        note(f"{cfg}: states created")
         ptrs = (C.c_void_p * nblk)(*[C.addressof(b) for b in bufs])
         sizes = (C.c_int32 * nblk)(*[n] * nblk)
         g0 = lib.bz3_hip_cm_blocks_given_up()
         t0 = time.time()
         lib.bz3_encode_blocks(states, ptrs, sizes, nblk)
         t1 = time.time()
+        note(f"{cfg}: encode_blocks returned after {t1 - t0:.1f}s")
         assert all(lib.bz3_last_error(states[i]) == 0 and sizes[i] > 0 for i in range(nblk))
         tm = (C.c_float * 8)()
         lib.bz3_hip_last_timings(states[0], tm)
@@ -59,11 +75,12 @@ def main():
         t2 = time.time()
         lib.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, nblk)
         t3 = time.time()
+        note(f"{cfg}: decode_blocks returned after {t3 - t2:.1f}s")
         lib.bz3_hip_last_timings(states[0], tm)
         cm_dec = tm[4]
         for i in range(nblk):
             assert lib.bz3_last_error(states[i]) == 0
-            assert int(np.frombuffer(bufs[i], dtype=np.uint8, count=n).astype(np.uint64).sum()) == plain[i], f"block {i}: round trip changed the data"
+            assert int(np.frombuffer(bufs[i], dtype=np.uint8, count=n).sum(dtype=np.uint64)) == plain[i], f"block {i}: round trip changed the data"
         for s in states:
             lib.bz3_free(s)
         tot = nblk * n / 2 ** 20
