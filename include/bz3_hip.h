@@ -33,10 +33,10 @@ BZIP3_API int bz3_hip_state_device(struct bz3_state * state);
 /* CM kernel variant (process-wide).  0 = the whole 145.5 KiB model in LDS, one block per CU; 1 / 2 = row-cache
  * kernels (the order-1 rows a block uses are cached in LDS -- 96 or 44/56 of them --, the others spill to HBM:
  * two / three blocks per CU; a block whose working set does not fit is handed back to variant 0 automatically);
- * -1 = automatic (default): the row-cache encoder when a batch holds more blocks than the GPU has CUs, the
- * row-cache decoder beyond twice that (measured: two decoder blocks per CU gain nothing).  Environment
- * BZ3_HIP_CM_MODE=auto|full|rows|rows3 has the same effect.  Output bytes do not depend on the variant.
- * Returns 0, or -1 for an invalid mode. */
+ * 100 = by batch size as measured (row-cache encoder beyond one block per CU, row-cache decoder beyond two);
+ * -1 = automatic (default): currently variant 0 -- the row-cache kernels are opt-in (bzip3_amd/csrc/api.hip).
+ * Environment BZ3_HIP_CM_MODE=auto|full|rows|rows3|measured has the same effect.  Output bytes do not depend on
+ * the variant.  Returns 0, or -1 for an invalid mode. */
 BZIP3_API int bz3_hip_set_cm_mode(int mode);
 /* Number of blocks the row-cache kernels have handed back to the full-model kernels so far (statistics). */
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void);

@@ -99,10 +99,22 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &
                     prepare(g_pool[t]);
                     g_pool[t].tid = dim3((unsigned)t, 0, 0);
                 }
+                // BZ3_EMU_SCHED=<seed>: stress mode for the inter-wave hand-off protocols.  In every sweep each wave is
+                // either given its turn or skipped (coin flip per wave), so the waves of a block advance at wildly
+                // different and changing speeds, as they do on a CU shared with other workgroups.
+                static const char * sched = getenv("BZ3_EMU_SCHED");
+                static uint64_t rng = sched ? (uint64_t)atoll(sched) * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull : 0;
                 while (b.alive > 0) {
+                    uint32_t skip = 0;
+                    if (sched) {
+                        rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+                        skip = (uint32_t)(rng >> 20) & ((1u << b.nwaves) - 1u);
+                        if ((rng >> 60) < 4) skip = 0;                                  // now and then everybody runs
+                        if (skip == ((1u << b.nwaves) - 1u)) skip &= ~(1u << ((rng >> 8) % (unsigned)b.nwaves));
+                    }
                     for (int t = 0; t < nthreads; t++) {
                         Fiber & f = g_pool[t];
-                        if (f.done) continue;
+                        if (f.done || ((skip >> (t / kWave)) & 1u)) continue;
                         g_cur = &f;
                         emu_swap(&g_sched_sp, f.sp);
                     }

@@ -16,7 +16,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import bzip3_amd  # noqa: E402
 import datagen  # noqa: E402
 
-MODES = {"auto": -1, "full": 0, "rows": 1, "rows3": 2}
+MODES = {"auto": -1, "full": 0, "rows": 1, "rows3": 2, "measured": 100}
 
 
 T0 = time.time()
@@ -87,7 +87,7 @@ def main():
         print(json.dumps({"cfg": cfg, "block_mib": mib, "blocks": nblk, "cm_enc_ms": round(cm_enc, 1), "cm_dec_ms": round(cm_dec, 1),
                           "cm_enc_MiBps": round(tot / (cm_enc * 1e-3), 1), "cm_dec_MiBps": round(tot / (cm_dec * 1e-3), 1),
                           "t_enc_s": round(t1 - t0, 2), "t_dec_s": round(t3 - t2, 2), "round_trip_MiBps": round(tot / (t1 - t0 + t3 - t2), 1),
-                          "ratio": round(nblk * n / comp, 3), "given_up": lib.bz3_hip_cm_blocks_given_up() - g0}), flush=True)
+                          "ratio": round(nblk * n / comp, 3), "lean": os.environ.get("BZ3_HIP_LEAN", "0"), "given_up": lib.bz3_hip_cm_blocks_given_up() - g0}), flush=True)
         del bufs
 
 
