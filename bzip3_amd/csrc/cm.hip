@@ -758,16 +758,29 @@ __device__ __forceinline__ void cm_decode_block(const CmDecodeJob * __restrict__
             lds_release();
             LDS_POKE(s_ready[role - 1], 2u * i + 1u);
             if (debug == 3) t1 = cm_clock();
-            // -- the walker's verdict on byte i-1
-            u32 word;
-            const u32 tag = i & 0xFFFFFFu;
+            // -- the walker's verdict on byte i-1.  s_done is a one-word mailbox and this wave announced the speculative table
+            // of byte i BEFORE reading it: if the guess was right the walker does not wait for anybody, decodes byte i from
+            // that table and overwrites the word with the verdict on byte i (tag i+1).  A model wave that was held up
+            // meanwhile (waves of other workgroups on the same CU, a context switch) then never sees tag i -- but tag i+1
+            // can only appear after a right guess (a wrong one makes the walker wait for this wave's corrected table), so it
+            // carries the missed verdict: byte i-1 was g.  The walker cannot get further ahead than that: byte i+1 needs a
+            // table this wave has not announced yet.
+            u32 word, seen_tag;
+            const u32 tag = i & 0xFFFFFFu, tag_next = (i + 1u) & 0xFFFFFFu;
+#ifdef BZ3_EMU_WATCH
+            unsigned long long spins_ = 0;
+#endif
             for (;;) {
                 word = cm_uniform(LDS_PEEK(s_done));
-                if ((word >> 8) == tag) break;
+                seen_tag = word >> 8;
+                if (seen_tag == tag || seen_tag == tag_next) break;
                 if (tune & 2u) BZ3_SPIN_PAUSE();
                 BZ3_SPIN_TIGHT();
+#ifdef BZ3_EMU_WATCH
+                if (++spins_ == 300000ull && lane == 0) fprintf(stderr, "[model wave %u] stuck at i=%u waiting tag %u: s_done=%08x s_ready=%u %u %u %u\n", role, i, tag, s_done, s_ready[0], s_ready[1], s_ready[2], s_ready[3]);
+#endif
             }
-            const u32 c = word & 0xFFu;
+            const u32 c = seen_tag == tag ? (word & 0xFFu) : g;
             if (debug == 3) t2 = cm_clock();
             if (c != g) {
                 // wrong guess: put the old counters back (the old values are still in `prev`), apply the real update
@@ -931,12 +944,20 @@ __device__ __forceinline__ void cm_decode_block(const CmDecodeJob * __restrict__
 #else
 #define CM_READY_MIN() cm_min4v(*(const volatile __attribute__((address_space(3))) cm_u32x4 *)(s_ready))  // LDS address space: ds_read_b128, not a flat load
 #endif
+#ifdef BZ3_EMU_WATCH
+#define CM_WATCH_DECL unsigned long long spins_ = 0;
+#define CM_WATCH_SPIN(need) if (++spins_ == 300000ull && lane == 0) fprintf(stderr, "[walker] stuck waiting for %u: s_ready=%u %u %u %u s_done=%08x\n", (u32)(need), s_ready[0], s_ready[1], s_ready[2], s_ready[3], s_done);
+#else
+#define CM_WATCH_DECL
+#define CM_WATCH_SPIN(need)
+#endif
 // Wait until every model wave has announced at least `need`, then fetch this lane's nine probabilities from table BUF.
 // `seen` is an earlier CM_READY_MIN() (announcements only grow): when it already suffices nothing is polled.
 #define CM_FETCH_TABLE(BUF, seen, need)                                                               \
     do {                                                                                              \
         if (cm_uniform(seen) < (need)) {                                                              \
-            while (cm_uniform(CM_READY_MIN()) < (need)) BZ3_SPIN_TIGHT();                             \
+            CM_WATCH_DECL                                                                             \
+            while (cm_uniform(CM_READY_MIN()) < (need)) { BZ3_SPIN_TIGHT(); CM_WATCH_SPIN(need) }     \
         }                                                                                             \
         lds_acquire();                                                                                \
         const u32 * __restrict__ pt_ = ptab[BUF];                                                     \

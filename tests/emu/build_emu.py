@@ -18,6 +18,7 @@ def build():
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(HERE, "hip_emu.hpp")]
     deps += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
     h = hashlib.sha256()
+    h.update(os.environ.get("BZ3_EMU_WATCH", "").encode())
     for p in sorted(deps):
         h.update(open(p, "rb").read())
     stamp = OUT + ".sha"
@@ -29,7 +30,7 @@ def build():
     for s in srcs:
         o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
         objs.append(o)
-        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DBZ3_EMU", "-I", HERE, "-I", CSRC, "-x", "c++", "-c", s, "-o", o,
+        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DBZ3_EMU", *(["-DBZ3_EMU_WATCH"] if os.environ.get("BZ3_EMU_WATCH") else []), "-I", HERE, "-I", CSRC, "-x", "c++", "-c", s, "-o", o,
                "-Wno-unknown-pragmas", "-Wno-attributes"]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for s, p in procs:

@@ -8,6 +8,7 @@ Block g_blk;
 Fiber * g_cur = nullptr;
 void * g_sched_sp = nullptr;
 std::vector<Fiber> g_pool;
+bool g_lockstep_release = getenv("BZ3_EMU_SCHED") != nullptr;
 
 asm(R"(
 .text
@@ -108,10 +109,27 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &
                     uint32_t skip = 0;
                     if (sched) {
                         rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
-                        skip = (uint32_t)(rng >> 20) & ((1u << b.nwaves) - 1u);
-                        if ((rng >> 60) < 4) skip = 0;                                  // now and then everybody runs
+                        if (sched[0] == '-') {  // negative seed: long stalls -- now and then a wave sleeps for up to 63 sweeps
+                            static int stall[32];
+                            for (int w = 0; w < b.nwaves; w++) {
+                                if (stall[w] > 0) stall[w]--;
+                                else if (((rng >> (3 * w)) & 7u) == 0) stall[w] = (int)((rng >> 40) & 63u);
+                                if (stall[w] > 0) skip |= 1u << w;
+                            }
+                        } else {
+                            skip = (uint32_t)(rng >> 20) & ((1u << b.nwaves) - 1u);
+                            if ((rng >> 60) < 4) skip = 0;                              // now and then everybody runs
+                        }
                         if (skip == ((1u << b.nwaves) - 1u)) skip &= ~(1u << ((rng >> 8) % (unsigned)b.nwaves));
                     }
+#ifdef BZ3_EMU_WATCH
+                    static unsigned long long sweeps = 0;
+                    if ((++sweeps % 2000000ull) == 0) {
+                        fprintf(stderr, "[emu] sweep %llu block %u alive %d skip %x waves alive:", sweeps, bx, b.alive, skip);
+                        for (int w = 0; w < b.nwaves; w++) fprintf(stderr, " %d", b.wave_alive[w]);
+                        fprintf(stderr, "\n");
+                    }
+#endif
                     for (int t = 0; t < nthreads; t++) {
                         Fiber & f = g_pool[t];
                         if (f.done || ((skip >> (t / kWave)) & 1u)) continue;

@@ -78,6 +78,10 @@ extern void * g_sched_sp;
 extern std::vector<Fiber> g_pool;
 
 extern "C" void emu_swap(void ** save_sp, void * load_sp);
+// Set under BZ3_EMU_SCHED (stress scheduling): the thread that completes a rendezvous yields once, so that all lanes of a
+// wave leave it in the same scheduler sweep -- whole waves are then stalled or run, never a wave minus one lane (which
+// no GPU can produce, and which would let one lane publish a flag on behalf of lanes that have not stored their data).
+extern bool g_lockstep_release;
 
 inline void yield() { emu_swap(&g_cur->sp, g_sched_sp); }
 
@@ -91,8 +95,14 @@ inline void syncthreads() {
     if (++b.bar_count == (unsigned)b.alive) {
         b.bar_count = 0;
         b.bar_gen++;
+        if (g_lockstep_release) yield();  // stress scheduling: the releasing thread resumes together with its wave
     } else {
+#ifdef BZ3_EMU_WATCH
+        unsigned long long w_ = 0;
+        while (b.bar_gen == gen) { yield(); if (++w_ == 2000000ull) fprintf(stderr, "[emu] thread %d stuck in __syncthreads (count %u alive %d)\n", cur_linear(), b.bar_count, b.alive); }
+#else
         while (b.bar_gen == gen) yield();
+#endif
     }
 }
 
@@ -103,8 +113,14 @@ inline void wave_barrier() {
     if (++b.wbar_count[w] == (unsigned)b.wave_alive[w]) {
         b.wbar_count[w] = 0;
         b.wbar_gen[w]++;
+        if (g_lockstep_release) yield();
     } else {
+#ifdef BZ3_EMU_WATCH
+        unsigned long long w_ = 0;
+        while (b.wbar_gen[w] == gen) { yield(); if (++w_ == 2000000ull) fprintf(stderr, "[emu] thread %d stuck in a wave rendezvous (wave %d count %u alive %d)\n", cur_linear(), w, b.wbar_count[w], b.wave_alive[w]); }
+#else
         while (b.wbar_gen[w] == gen) yield();
+#endif
     }
 }
 

@@ -339,3 +339,32 @@ def test_cm_in_place_sink(emu, oracle):
     finally:
         os.environ.pop("BZ3_CM_TEST_GAP", None)
         os.environ.pop("BZ3_CM_TEST_SIDE", None)
+
+
+def test_cm_protocols_survive_stalled_waves(emu):
+    """Liveness of the LDS hand-off protocols under hostile wave scheduling (BZ3_EMU_SCHED < 0: whole waves of the emulated
+    workgroup are put to sleep for dozens of scheduler sweeps at random).  Round 1 found this way that a model wave of the
+    CM decoder which is held up for longer than the walker needs for one byte missed the walker's verdict in the one-word
+    mailbox and waited for ever (on the GPU: two stalled runs with several workgroups per CU); the verdict is now recovered
+    from the following one.  Runs in a subprocess because the scheduler mode is fixed when the library is loaded."""
+    import subprocess
+
+    code = r'''
+import sys, ctypes as C
+sys.path[:0] = [%r, %r, %r]
+import bzip3_amd, datagen
+from build_emu import build
+from oracle_lib import Oracle
+lib = bzip3_amd._declare(C.CDLL(build()))
+o, g = Oracle(), bzip3_amd.StageApi(lib)
+d = o.bwt(datagen.shakespeare()[100000:101500])[1]
+c = o.cm_encode(d)
+for mode in (0, 9):
+    assert lib.bz3_hip_set_cm_mode(mode) == 0
+    assert g.cm_encode(d) == c and g.cm_decode(c, len(d)) == d
+    assert g.cm_decode(c[: len(c) // 2], len(d)) == o.cm_decode(c[: len(c) // 2], len(d))
+print("ok")
+''' % (os.path.dirname(HERE), HERE, os.path.join(HERE, "emu"))
+    for seed in ("-1", "-3"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BZ3_EMU_SCHED=seed), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (seed, r.stdout[-300:], r.stderr[-800:])
