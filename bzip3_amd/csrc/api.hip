@@ -183,6 +183,7 @@ int cm_mode() {
         if (e && !strcmp(e, "full")) m = CM_VARIANT_FULL;
         else if (e && !strcmp(e, "rows")) m = CM_VARIANT_ROWS;
         else if (e && !strcmp(e, "rows3")) m = CM_VARIANT_ROWS3;
+        else if (e && !strcmp(e, "lock3")) m = CM_VARIANT_LOCK3;
         else if (e && !strcmp(e, "measured")) m = CM_MODE_MEASURED;
 #ifdef BZ3_EMU
         else if (e && !strcmp(e, "rows-test")) m = CM_VARIANT_ROWS_TEST;
@@ -229,8 +230,8 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
         for (size_t i = 0; i < jobs.size(); i++) {
             jobs[i].spill = dev_addr(spill + i * CM_SPILL_BYTES);
             jobs[i].status = dev_addr(d_status + i);
-            jobs[i].miss_base = variant == CM_VARIANT_ROWS_TEST ? 64u : 256u;
-            jobs[i].miss_shift = variant == CM_VARIANT_ROWS_TEST ? 3u : 8u;  // give up beyond 0.4 % misses (test variant: 12.5 %)
+            jobs[i].miss_base = variant >= CM_VARIANT_ROWS_TEST ? 64u : 256u;
+            jobs[i].miss_shift = variant >= CM_VARIANT_ROWS_TEST ? 3u : 8u;  // give up beyond 0.4 % misses (test variants: 12.5 %)
         }
     }
     if (const char * t = getenv("BZ3_CM_TUNE"))  // kernel experiments (cm.hip `tune`); no effect on the output bytes
@@ -1307,9 +1308,9 @@ BZIP3_API int bz3_hip_bind_device(int device) {
 BZIP3_API int bz3_hip_state_device(struct bz3_state * st) { return st->device; }
 
 BZIP3_API int bz3_hip_set_cm_mode(int mode) {
-    bool ok = (mode >= -1 && mode <= CM_VARIANT_ROWS3) || mode == CM_MODE_MEASURED;
+    bool ok = (mode >= -1 && mode <= CM_VARIANT_LOCK3) || mode == CM_MODE_MEASURED;
 #ifdef BZ3_EMU
-    ok = ok || mode == CM_VARIANT_ROWS_TEST;
+    ok = ok || mode == CM_VARIANT_ROWS_TEST || mode == CM_VARIANT_LOCK_TEST;
 #endif
     if (!ok) return -1;
     g_cm_mode.store(mode);
@@ -1522,8 +1523,8 @@ void stage_cm_job(StageEnv & e, Job job, Launch && go) {
         status = (u32 *)e.dev(64);
         HIP_CHECK(hipMemset(status, 0, 64));
         job.status = dev_addr(status);
-        job.miss_base = variant == CM_VARIANT_ROWS_TEST ? 64u : 256u;
-        job.miss_shift = variant == CM_VARIANT_ROWS_TEST ? 3u : 8u;
+        job.miss_base = variant >= CM_VARIANT_ROWS_TEST ? 64u : 256u;
+        job.miss_shift = variant >= CM_VARIANT_ROWS_TEST ? 3u : 8u;
     }
     Job * d_job = (Job *)e.dev(sizeof job, &job, sizeof job);
     go(d_job, 1u, e.s, variant);

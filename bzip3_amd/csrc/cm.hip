@@ -1053,19 +1053,176 @@ __device__ __forceinline__ void cm_decode_block(const CmDecodeJob * __restrict__
         o[2] = prof_slow;
         o[3] = prof_miss;
     }
+#undef CM_FETCH_TABLE
+#undef CM_READY_MIN
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode, lock-step variant (row cache only): four waves, one tree node per lane, TWO barriers per byte.
+//
+// The guess-ahead decoder above buys single-block latency with VALU work: every model lane evaluates its node for
+// every byte, 45 % of the time twice, next to a fifth wave that walks -- about 2/3 of a CU's issue slots for ONE block,
+// so workgroups that share a CU slow each other down (profiles/r01_cm_rows_probe.txt: two per CU = 2.07x the time).
+// This variant does the minimum instead: evaluate all nodes once the previous byte is known, barrier, wave 0 walks the
+// byte (same lane-speculated walk, same checked slow path) while the other waves sleep in the barrier, barrier, the 8
+// lanes on the decoded path update.  More latency per byte for a block that is alone, but about a third of the issue
+// slots, no polling and no speculation to undo: made for three to five blocks per CU.  Opt-in (CM_VARIANT_LOCK3);
+// not measured on the GPU yet (written after the round-1 GPU budget was spent).
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ void cm_decode_block_lockstep(const CmDecodeJob * __restrict__ jobs) {
+    static_assert(R > 0, "row-cache kernel");
+    const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
+    const u32 in_size = jobs[blockIdx.x].in_size;
+    u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
+    const u32 n = jobs[blockIdx.x].n;
+    __shared__ CmLdsT<R> m;
+    __shared__ u32 ptab[256];  // (18-bit probability of node) << 14
+    __shared__ u32 s_byte;     // the byte wave 0 decoded
+    __shared__ CmRowCache<R> rcs[4];
+    cm_model_init(m);
+    if (n == 0) return;
+    const int lane = lane_id();
+    const u32 wave = cm_uniform((u32)wave_id());
+    const u32 node = threadIdx.x;
+    const u32 lvl = node ? (u32)(31 - __clz((int)node)) : 0u;
+    const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
+    u32 c0 = 32768u;  // the node's C0 counter lives in a register
+    CmRowCache<R> & rc = rcs[wave];
+    CmRowState rs;
+    u16 * __restrict__ spill = global_ptr<u16>(jobs[blockIdx.x].spill);
+    const u32 miss_base = jobs[blockIdx.x].miss_base, miss_shift = jobs[blockIdx.x].miss_shift;
+    cm_rows_init<R>(rc);
+    // walk side (wave 0 only): lane l assumes bits b0..b5 = l
+    const u32 ul = (u32)lane;
+    const bool as0 = (ul >> 5) & 1u, as1 = (ul >> 4) & 1u, as2 = (ul >> 3) & 1u, as3 = (ul >> 2) & 1u, as4 = (ul >> 1) & 1u, as5 = ul & 1u;
+    const u32 nb0 = (u32)as0 - 1u, nb1 = (u32)as1 - 1u, nb2 = (u32)as2 - 1u, nb3 = (u32)as3 - 1u, nb4 = (u32)as4 - 1u, nb5 = (u32)as5 - 1u;
+    const u32 ix0 = 1u, ix1 = 2u | (ul >> 5), ix2 = 4u | (ul >> 4), ix3 = 8u | (ul >> 3), ix4 = 16u | (ul >> 2), ix5 = 32u | (ul >> 1);
+    const u32 ix6 = 64u | ul, ix7 = 128u | (ul << 1);
+    u32 low_u = 0, range_u = 0xFFFFFFFFu, code = 0;
+    u32 ip = 0, ibase = 0, window = 0, staged = 0;
+    if (wave == 0) {
+        window = (ibase + lane < in_size) ? in[ibase + lane] : 0xFFFFFFFFu;
+        for (int j = 0; j < 4; j++) {  // :438-441; bytes past the end read as -1 (:345)
+            u32 b;
+            CM_NEXT_BYTE(b);
+            code = (code << 8) + b;
+        }
+    }
+    u32 c1 = 0, c2 = 0, run = 0;
+    u32 row1 = 0, row2 = 0;  // slots of the rows of c1 and c2 (byte value 0 before the block starts: slot 0)
+    for (u32 i = 0; i < n; i++) {
+        run = (c1 == c2) ? run + 1 : 0;  // :367-372
+        const u32 f = run > 2 ? 1u : 0u;
+        // ---- every lane: probability of its node (:377-388) ---------------------------------------------------
+        const u32 a1 = row1 * 256u + node;
+        const u32 p1 = m.c1[a1];
+        const u32 p2 = m.c1[row2 * 256u + node];
+        const int p = (int)(((c0 + p1) * 7u + 2u * p2) >> 4);
+        const u32 ci = (2u * node + f) * CM_C2_STRIDE + (u32)(p >> 12);
+        const u32 w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[ci]));  // x1 | x2 << 16
+        {
+            const int x1 = (int)(w & 0xFFFFu), x2 = (int)(w >> 16);
+            const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);
+            ptab[node] = (u32)(ssep * 3 + p) << 14;
+        }
+        __syncthreads();
+        // ---- wave 0: the byte ------------------------------------------------------------------------------------
+        if (wave == 0) {
+            const u32 P0 = ptab[ix0], P1 = ptab[ix1], P2 = ptab[ix2], P3 = ptab[ix3], P4 = ptab[ix4], P5 = ptab[ix5], P6 = ptab[ix6];
+            const u32 P7a = ptab[ix7], P7b = ptab[ix7 + 1u];
+            u32 c;
+            u32 range = range_u, low;
+            u32 d = code - low_u;
+            const bool inside = d <= range_u;  // low <= code <= high: always, unless a truncated stream fed -1 bytes (:345)
+            u32 acc = 0;
+            bool bit6, bit7;
+            CM_FAST_SPEC(P0, nb0, as0);  // :453-489
+            CM_FAST_SPEC(P1, nb1, as1);
+            CM_FAST_SPEC(P2, nb2, as2);
+            CM_FAST_SPEC(P3, nb3, as3);
+            CM_FAST_SPEC(P4, nb4, as4);
+            CM_FAST_SPEC(P5, nb5, as5);
+            const u64 ok = __ballot(acc == ul);  // exactly one lane decoded the six bits it had assumed
+            u32 cbits = acc;
+            CM_FAST_REAL(P6, bit6);
+            const u32 P7f = bit6 ? P7b : P7a;
+            CM_FAST_REAL(P7f, bit7);
+            const int wl = __ffsll((unsigned long long)ok) - 1;
+            const u32 low_f = code - cm_readlane(d, wl), range_f = cm_readlane(range, wl);
+            if (__builtin_expect(inside && (low_f ^ (low_f + range_f)) >= (1u << 24), 1)) {
+                low_u = low_f;
+                range_u = range_f;
+                c = cm_readlane(cbits, wl);
+            } else {  // a renormalisation was due on the true path: decode this byte again, checking every level
+                low = low_u;
+                range = range_u;
+                u64 valid = ~0ull;
+                CM_SPEC_LEVEL(P0, nb0, 0xFFFFFFFF00000000ull);
+                CM_SPEC_LEVEL(P1, nb1, 0xFFFF0000FFFF0000ull);
+                CM_SPEC_LEVEL(P2, nb2, 0xFF00FF00FF00FF00ull);
+                CM_SPEC_LEVEL(P3, nb3, 0xF0F0F0F0F0F0F0F0ull);
+                CM_SPEC_LEVEL(P4, nb4, 0xCCCCCCCCCCCCCCCCull);
+                CM_SPEC_LEVEL(P5, nb5, 0xAAAAAAAAAAAAAAAAull);
+                CM_REAL_LEVEL(P6, bit6);
+                const u32 P7 = bit6 ? P7b : P7a;
+                CM_REAL_LEVEL(P7, bit7);
+                const int w2 = __ffsll((unsigned long long)valid) - 1;  // exactly one lane survives
+                low_u = cm_readlane(low, w2);
+                range_u = cm_readlane(range, w2);
+                c = cm_readlane((ul << 2) | ((u32)bit6 << 1) | (u32)bit7, w2);
+            }
+            LDS_POKE(s_byte, c);
+            if ((u32)lane == (i & 63u)) staged = c;
+            if ((i & 63u) == 63u || i + 1 == n) {
+                const u32 first = i & ~63u;
+                if (first + lane <= i) out[first + lane] = (u8)staged;
+            }
+        }
+        __syncthreads();
+        const u32 c = cm_uniform(LDS_PEEK(s_byte));
+        // ---- the 8 lanes on the decoded path: counter updates (:396-399, :411-414; branch-free, see cm_upd) ---------
+        if ((hibit | (c >> shr)) == node) {
+            const u32 mk = 0u - ((c >> bitpos) & 1u);
+            c0 = cm_upd(c0, 2, mk & 16383u);
+            m.c1[a1] = (u16)cm_upd(p1, 4, mk & 4095u);
+            reinterpret_cast<PackedU32 *>(&m.c2[ci])->v = cm_upd_pair6(w, mk & 0x03FF03FFu);
+        }
+        // ---- contexts of the next byte; its order-1 row must be resident ---------------------------------------------
+        c2 = c1;
+        c1 = c;
+        row2 = row1;
+        if (c1 != c2) {
+            u32 row = cm_uniform((u32)rc.row_of[c]);
+            if (__builtin_expect(row >= CM_ROW_SPILLED, 0)) {
+                rs.tick++;
+                if (lane == 0) rc.stamp[row2] = rs.tick;  // the row of c2 is still needed
+                wave_sync();
+                row = cm_rows_fetch<R, 1>(m, rc, rs, spill, c, row, node);
+                if (__builtin_expect(rs.misses > miss_base + (i >> miss_shift), 0)) {
+                    // the working set does not fit: give the block up (all four waves count the same misses)
+                    if (threadIdx.x == 0) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
+                    return;
+                }
+            }
+            row1 = row;
+        }
+    }
+}
 #undef CM_NEXT_BYTE
 #undef CM_RENORM
 #undef CM_SPEC_LEVEL
 #undef CM_REAL_LEVEL
 #undef CM_FAST_SPEC
 #undef CM_FAST_REAL
-#undef CM_FETCH_TABLE
-#undef CM_READY_MIN
-}
 
 __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<0>(jobs); }
 __global__ void __launch_bounds__(320) k_cm_decode_rows(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<CM_ROWS_DEC>(jobs); }
 __global__ void __launch_bounds__(320) k_cm_decode_rows3(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<CM_ROWS3_DEC>(jobs); }
+__global__ void __launch_bounds__(256) k_cm_decode_lock3(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_lockstep<CM_ROWS3_DEC>(jobs); }
+#ifdef BZ3_EMU
+__global__ void __launch_bounds__(256) k_cm_decode_lock_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_lockstep<CM_ROWS_TEST>(jobs); }
+#endif
 #ifdef BZ3_EMU
 __global__ void __launch_bounds__(320) k_cm_decode_rows_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<CM_ROWS_TEST>(jobs); }
 #endif
@@ -1073,9 +1230,9 @@ __global__ void __launch_bounds__(320) k_cm_decode_rows_test(const CmDecodeJob *
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant) {
     if (!njobs) return;
 #ifdef BZ3_EMU
-    if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_encode_rows_test, dim3(njobs), dim3(256), 0, s, d_jobs);
+    if (variant == CM_VARIANT_ROWS_TEST || variant == CM_VARIANT_LOCK_TEST) return launch(k_cm_encode_rows_test, dim3(njobs), dim3(256), 0, s, d_jobs);
 #endif
-    if (variant == CM_VARIANT_ROWS3) launch(k_cm_encode_rows3, dim3(njobs), dim3(256), 0, s, d_jobs);
+    if (variant == CM_VARIANT_ROWS3 || variant == CM_VARIANT_LOCK3) launch(k_cm_encode_rows3, dim3(njobs), dim3(256), 0, s, d_jobs);
     else if (variant != CM_VARIANT_FULL) launch(k_cm_encode_rows, dim3(njobs), dim3(256), 0, s, d_jobs);
     else launch(k_cm_encode, dim3(njobs), dim3(256), 0, s, d_jobs);
 }
@@ -1084,8 +1241,10 @@ void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int v
     if (!njobs) return;
 #ifdef BZ3_EMU
     if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_decode_rows_test, dim3(njobs), dim3(320), 0, s, d_jobs);
+    if (variant == CM_VARIANT_LOCK_TEST) return launch(k_cm_decode_lock_test, dim3(njobs), dim3(256), 0, s, d_jobs);
 #endif
-    if (variant == CM_VARIANT_ROWS3) launch(k_cm_decode_rows3, dim3(njobs), dim3(320), 0, s, d_jobs);
+    if (variant == CM_VARIANT_LOCK3) launch(k_cm_decode_lock3, dim3(njobs), dim3(256), 0, s, d_jobs);
+    else if (variant == CM_VARIANT_ROWS3) launch(k_cm_decode_rows3, dim3(njobs), dim3(320), 0, s, d_jobs);
     else if (variant != CM_VARIANT_FULL) launch(k_cm_decode_rows, dim3(njobs), dim3(320), 0, s, d_jobs);
     else launch(k_cm_decode, dim3(njobs), dim3(320), 0, s, d_jobs);
 }

@@ -216,6 +216,14 @@ def test_cm_row_cache_kernels_match_oracle(emu, oracle, cm_mode):
     c = oracle.cm_encode(d)
     assert g.cm_encode(d) == c and g.cm_decode(c, len(d)) == d
     assert emu.bz3_hip_cm_blocks_given_up() == n0
+    # the lock-step row-cache decoder (CM_VARIANT_LOCK*: evaluate, barrier, wave 0 walks, barrier, update)
+    for mode in (10, 3):
+        assert cm_mode(mode) == 0
+        for name in ("text", "skew60", "flat200", "tiny", "one"):
+            d = cases[name][0]
+            c = oracle.cm_encode(d)
+            assert g.cm_encode(d) == c and g.cm_decode(c, len(d)) == d, (mode, name)
+            assert g.cm_decode(c[: len(c) // 2], len(d)) == oracle.cm_decode(c[: len(c) // 2], len(d)), (mode, name)
     junk = bytes(rng.integers(0, 256, size=900, dtype=np.uint8))  # arbitrary input: 256 live rows, handed back
     assert g.cm_decode(junk, 2000) == oracle.cm_decode(junk, 2000)
     assert emu.bz3_hip_set_cm_mode(7) == -1

@@ -1,5 +1,5 @@
 """CM kernel variants side by side on the GPU box (no torch import):
-    python tools/cm_rows_probe.py [block MiB=16] [cfg ...]      cfg = <mode>:<blocks>[:<tune>], mode = full | rows | rows3 | auto, tune = BZ3_CM_TUNE bits
+    python tools/cm_rows_probe.py [block MiB=16] [cfg ...]      cfg = <mode>:<blocks>[:<tune>], mode = full | rows | rows3 | lock3 | measured | auto, tune = BZ3_CM_TUNE bits
 For every configuration: bz3_encode_blocks + bz3_decode_blocks on host buffers (text blocks, 64 KiB pieces of one
 Markov text in a block-specific order), round trip verified, CM launch times from the library's HIP events.
 Prints one JSON line per configuration."""
@@ -16,7 +16,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import bzip3_amd  # noqa: E402
 import datagen  # noqa: E402
 
-MODES = {"auto": -1, "full": 0, "rows": 1, "rows3": 2, "measured": 100}
+MODES = {"auto": -1, "full": 0, "rows": 1, "rows3": 2, "lock3": 3, "measured": 100}
 
 
 T0 = time.time()
