@@ -135,6 +135,8 @@ DeviceCtx * get_ctx(int dev) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) c->cus = cus;
 #endif
+        if (const char * e = getenv("BZ3_HIP_CUS"))  // tests / experiments: pretend the GPU has this many CUs (batch-size policies)
+            if (atoi(e) > 0) c->cus = atoi(e);
         g_ctx[dev] = c;
     }
     return g_ctx[dev];

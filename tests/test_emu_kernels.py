@@ -376,3 +376,51 @@ print("ok")
     for seed in ("-1", "-3"):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BZ3_EMU_SCHED=seed), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (seed, r.stdout[-300:], r.stderr[-800:])
+
+
+def test_measured_cm_policy_by_batch_size(oracle):
+    """BZ3_HIP_CM_MODE=measured picks the CM kernels by batch size (api.hip cm_variant_for): with BZ3_HIP_CUS=2 a batch of
+    3 blocks takes the two-per-CU row-cache encoder and the full-model decoder, a batch of 5 the three-per-CU kernels both
+    ways; random blocks are handed back to the full-model kernel inside the same call.  Subprocess: the CU count is read
+    when the device context is created."""
+    import subprocess
+
+    code = r'''
+import sys, ctypes as C
+sys.path[:0] = [%r, %r, %r]
+import bzip3_amd, datagen
+from build_emu import build
+from oracle_lib import Oracle
+lib = bzip3_amd._declare(C.CDLL(build()))
+o = Oracle()
+assert lib.bz3_hip_set_cm_mode(100) == 0
+bs = 65 * 1024
+t = datagen.shakespeare()
+for n in (3, 5):
+    blocks = [t[i * 900 : i * 900 + 700 + i] for i in range(n - 1)] + [datagen.random_bytes(1200, seed=n)]
+    states = (C.c_void_p * n)(*[lib.bz3_new(bs) for _ in range(n)])
+    cap = lib.bz3_bound(bs) + 64
+    bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+    for b, d in zip(bufs, blocks):
+        C.memmove(b, d, len(d))
+    ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+    g0 = lib.bz3_hip_cm_blocks_given_up()
+    lib.bz3_encode_blocks(states, ptrs, sizes, n)
+    g1 = lib.bz3_hip_cm_blocks_given_up()
+    for i, d in enumerate(blocks):
+        assert bytes(bufs[i][: sizes[i]]) == o.encode_block(d, bs)[2], (n, i)
+    bsz = (C.c_size_t * n)(*[cap] * n)
+    orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+    lib.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+    g2 = lib.bz3_hip_cm_blocks_given_up()
+    for i, d in enumerate(blocks):
+        assert lib.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: len(d)]) == d, (n, i)
+    # the random block is given up by every row-cache launch: encode always (n > 2 CUs), decode only beyond 2 x 2 blocks
+    assert (g1 - g0, g2 - g1) == ((1, 0) if n == 3 else (1, 1)), (n, g1 - g0, g2 - g1)
+    for s in states:
+        lib.bz3_free(s)
+print("ok")
+''' % (os.path.dirname(HERE), HERE, os.path.join(HERE, "emu"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BZ3_HIP_CUS="2"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-300:], r.stderr[-1200:])
