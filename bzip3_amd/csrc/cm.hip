@@ -1,19 +1,22 @@
 // cm.hip -- bzip3's context-mixing model + 32-bit binary arithmetic coder, one workgroup per block.
 // Replaces begin / encode_bytes / decode_bytes (reference src/libbz3.c:333-494).
 //
-// The whole model -- C0 u16[256], C1 u16[256][256], C2 u16[512][17] = 148,992 B -- lives in the
-// 160 KiB LDS of ONE compute unit for the lifetime of the block, so the 5 table reads and 4 counter
-// updates per coded bit never leave the CU; HBM traffic is the algorithmic minimum (read n bytes,
-// write the coded bytes, or the reverse).  Blocks are independent, so a batch runs one block per CU.
+// The model -- C0 u16[256], C1 u16[256][256], C2 u16[512][17] = 148,992 B -- lives in the LDS of the compute unit that
+// codes the block, so the 5 table reads and 4 counter updates per coded bit never leave the CU; HBM traffic is the
+// algorithmic minimum (read n bytes, write the coded bytes, or the reverse).  Blocks are independent: a batch is ONE
+// launch with one workgroup per block.  Kernel variants (stages.hpp CM_VARIANT_*):
+//   full model   k_cm_encode / k_cm_decode            the whole C1 table in LDS: one block per CU
+//   row cache    k_cm_*_rows, k_cm_*_rows3            only the C1 rows a block uses are resident (96 or 44/56 rows, the
+//                                                     others spill to HBM): two / three blocks per CU
+//   lock step    k_cm_decode_lock3                    row-cache decoder that trades latency for VALU work
 //
 // Exact facts used:
-//  * encode: all 8 tree nodes of a byte are known up front (the encoder knows the byte), they touch
-//    disjoint counters, so 8 lanes evaluate and update them at once; the (low, high) recurrence of the
-//    coder is inherently serial and is kept wave-uniform (scalar registers).
-//  * decode: the bit is unknown until decoded, but the 255 nodes of the NEXT byte depend only on state
-//    that is fixed once the previous byte is known, so 256 lanes (one tree node each) pre-evaluate every
-//    node's 18-bit probability; the 8 serial decisions then only pick values out of registers
-//    (v_readlane), and the 8 lanes on the decoded path update their counters in parallel.
+//  * encode: all 8 tree nodes of a byte are known up front (the encoder knows the byte) and touch disjoint counters; the
+//    model factorises by tree node, so every node gets a lane of its own and whole chunks of bytes are modelled ahead of
+//    the coder; the (low, range) recurrence of the coder is inherently serial: one lane, fed through an LDS ring.
+//  * decode: the bit is unknown until decoded, but the 255 nodes of the NEXT byte depend only on state that is fixed
+//    once the previous byte is known, so 256 lanes (one tree node each) pre-evaluate every node's 18-bit probability
+//    (the guess-ahead decoder even before that byte is known); the 8 serial decisions are speculated across lanes.
 // All arithmetic is integer and matches the reference bit for bit, including the signed interpolation
 // `x1 + (((x2 - x1) * (p & 4095)) >> 12)` with an arithmetic shift of a possibly negative product.
 #include "prims.hpp"
@@ -68,47 +71,6 @@ __device__ __forceinline__ void cm_model_init(M & m) {  // begin(): :350-358
         m.c2[i] = (u16)((k << 12) - (k == 16));
     }
     __syncthreads();
-}
-
-struct CmProbe {
-    u32 p0, p1;   // C0[node], C1[c1][node]
-    u32 x1, x2;   // C2 row cells j, j+1
-    u32 c2off;    // index of cell j in c2[]
-    u32 p18;      // 18-bit probability of a 1 bit
-};
-
-__device__ __forceinline__ CmProbe cm_probe(const CmLds & m, u32 node, u32 c1, u32 c2, u32 f) {  // :377-388
-    CmProbe q;
-    q.p0 = m.c0[node];
-    q.p1 = m.c1[c1 * 256 + node];
-    const u32 p2 = m.c1[c2 * 256 + node];
-    const int p = (int)(((q.p0 + q.p1) * 7u + 2u * p2) >> 4);
-    const int j = p >> 12;
-    q.c2off = (2u * node + f) * CM_C2_STRIDE + (u32)j;
-    q.x1 = m.c2[q.c2off];
-    q.x2 = m.c2[q.c2off + 1];
-    const int ssep = (int)q.x1 + ((((int)q.x2 - (int)q.x1) * (p & 4095)) >> 12);
-    q.p18 = (u32)(ssep * 3 + p);
-    return q;
-}
-
-__device__ __forceinline__ void cm_learn(CmLds & m, const CmProbe & q, u32 node, u32 c1, u32 bit) {  // :347-348, :396-399, :411-414
-    u32 a = q.p0, b = q.p1, lo = q.x1, hi = q.x2;
-    if (bit) {
-        a += (a ^ 65535u) >> 2;
-        b += (b ^ 65535u) >> 4;
-        lo += (lo ^ 65535u) >> 6;
-        hi += (hi ^ 65535u) >> 6;
-    } else {
-        a -= a >> 2;
-        b -= b >> 4;
-        lo -= lo >> 6;
-        hi -= hi >> 6;
-    }
-    m.c0[node] = (u16)a;
-    m.c1[c1 * 256 + node] = (u16)b;
-    m.c2[q.c2off] = (u16)lo;
-    m.c2[q.c2off + 1] = (u16)hi;
 }
 
 // ------------------------------------------------------------------------------------------------
