@@ -1585,4 +1585,53 @@ BZIP3_API void bz3_hip_stage_cm_decode(const uint8_t * in, int32_t in_size, uint
     });
 }
 
+// Profiling: `copies` identical CM decode jobs in ONE launch (same coded input, one output buffer each), through the kernel
+// variant the current mode selects (no hand-back of given-up blocks: this measures the variant itself).  Returns the launch
+// time in ms (HIP events).  out receives the n decoded bytes of copy 0.  With BZ3_CM_DEBUG=3 the guess-ahead decoder leaves
+// cycle counters instead of the first output bytes (walker: wait, walk, slow-path bytes, wrong guesses at u64[0..3]; model
+// wave 1: speculate, wait, redo, wrong guesses at u64[8..11]); `counters`, if not NULL, receives u64[16] per copy.
+BZIP3_API float bz3_hip_stage_cm_decode_many(const uint8_t * in, int32_t in_size, uint8_t * out, int32_t n, int32_t copies, uint64_t * counters) {
+    return stage_guard([&]() -> float {
+        StageEnv e;
+        if (copies < 1 || n < 256) return -1.f;
+        u8 * d = e.dev((size_t)in_size + 64, in, (size_t)in_size);
+        const size_t stride = ((size_t)n + 64 + 255) & ~(size_t)255;
+        u8 * o = e.dev(stride * (size_t)copies);
+        const char * dbg = getenv("BZ3_CM_DEBUG");
+        const char * tune = getenv("BZ3_CM_TUNE");
+        const u32 debug = (dbg ? (u32)atoi(dbg) : 0u) | ((tune ? (u32)atoi(tune) : 0u) << 4);
+        const int variant = cm_variant_for(e.ctx, (size_t)copies, false);
+        u8 * spill = variant != CM_VARIANT_FULL ? e.dev(CM_SPILL_BYTES * (size_t)copies) : nullptr;
+        u32 * status = (u32 *)e.dev(4 * (size_t)copies + 64);
+        HIP_CHECK(hipMemset(status, 0, 4 * (size_t)copies));
+        std::vector<CmDecodeJob> jobs;
+        for (int32_t k = 0; k < copies; k++) {
+            CmDecodeJob j{dev_addr(d), dev_addr(o + stride * (size_t)k), (u32)in_size, (u32)n, debug, 0u};
+            if (spill) {
+                j.spill = dev_addr(spill + CM_SPILL_BYTES * (size_t)k);
+                j.status = dev_addr(status + k);
+                j.miss_base = 256u;
+                j.miss_shift = 8u;
+            }
+            jobs.push_back(j);
+        }
+        CmDecodeJob * d_jobs = (CmDecodeJob *)e.dev(sizeof(CmDecodeJob) * jobs.size(), jobs.data(), sizeof(CmDecodeJob) * jobs.size());
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, e.s));
+        cm_decode_batch(d_jobs, (u32)copies, e.s, variant);
+        HIP_CHECK(hipEventRecord(e1, e.s));
+        HIP_CHECK(hipStreamSynchronize(e.s));
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        e.down(out, o, (size_t)n);
+        if (counters)
+            for (int32_t k = 0; k < copies; k++) e.down(counters + 16 * (size_t)k, o + stride * (size_t)k, 128);
+        return ms;
+    });
+}
+
 }  // extern "C"

@@ -87,6 +87,11 @@ BZIP3_API int32_t bz3_hip_stage_unbwt(const uint8_t * in, uint8_t * out, int32_t
 BZIP3_API int32_t bz3_hip_stage_cm_encode(const uint8_t * in, int32_t n, uint8_t * out);            /* encode_bytes    */
 BZIP3_API void bz3_hip_stage_cm_decode(const uint8_t * in, int32_t in_size, uint8_t * out, int32_t n); /* decode_bytes  */
 
+/* Profiling: `copies` identical CM decode jobs in one launch through the current CM kernel variant; returns the launch
+ * time in milliseconds, `out` receives the n (>= 256) decoded bytes of copy 0; with BZ3_CM_DEBUG=3 `counters` (u64[16] per
+ * copy, may be NULL) receives the decoder's phase cycle counters instead of valid output (bzip3_amd/csrc/api.hip). */
+BZIP3_API float bz3_hip_stage_cm_decode_many(const uint8_t * in, int32_t in_size, uint8_t * out, int32_t n, int32_t copies, uint64_t * counters);
+
 #ifdef __cplusplus
 }
 #endif
