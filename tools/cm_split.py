@@ -3,11 +3,10 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import bzip3_amd, datagen
-from oracle_lib import Oracle
 n = int(float(sys.argv[1]) * (1 << 20)) if len(sys.argv) > 1 else 2 << 20
 d = datagen.text(n, seed=5, chains=4096)
-idx, u = Oracle().bwt(d)
 g = bzip3_amd.StageApi(bzip3_amd.load())
+idx, u = g.bwt(d)  # what the CM stage sees: BWT output
 for mode in ("0", "1", "2", "0"):
     os.environ["BZ3_CM_DEBUG"] = mode
     t = time.time(); out = g.cm_encode(u); dt = time.time() - t

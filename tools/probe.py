@@ -1,4 +1,4 @@
-"""Per-stage timing probe on the GPU box: python tools/probe.py <MiB> [kind] [--check]."""
+"""Per-stage timing probe on the GPU box: python tools/probe.py <MiB> [kind] [--once]."""
 import os
 import sys
 import time
@@ -34,13 +34,6 @@ def main():
             print("   enc ms:", {a: round(b, 2) for a, b in te.items()}, bw)
             print("   dec ms:", {a: round(b, 2) for a, b in td.items()})
             sys.stdout.flush()
-    if "--check" in sys.argv:
-        from oracle_lib import Bz3, RefLib
-        r = RefLib()
-        if r.available:
-            t0 = time.time()
-            ref = Bz3(r.lib).encode_block(d, bs)
-            print("   reference CPU encode %.2fs, identical=%s" % (time.time() - t0, ref[2] == blk))
 
 
 if __name__ == "__main__":
