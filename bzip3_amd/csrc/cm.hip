@@ -1045,12 +1045,15 @@ __device__ __forceinline__ void cm_decode_block_lockstep(const CmDecodeJob * __r
     cm_model_init(m);
     if (n == 0) return;
     const int lane = lane_id();
-    const u32 wave = cm_uniform((u32)wave_id());
+    // The walking wave is "wave 0" below.  Experiment (BZ3_CM_TUNE bit 2): rotate that role with the block index, so that
+    // the walkers of workgroups sharing a CU do not all sit on the SIMD that hosts hardware wave 0 of every workgroup.
+    const u32 hw_wave = cm_uniform((u32)wave_id());
+    const u32 wave = ((jobs[blockIdx.x].debug >> 4) & 4u) ? ((hw_wave + blockIdx.x) & 3u) : hw_wave;
     const u32 node = threadIdx.x;
     const u32 lvl = node ? (u32)(31 - __clz((int)node)) : 0u;
     const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
     u32 c0 = 32768u;  // the node's C0 counter lives in a register
-    CmRowCache<R> & rc = rcs[wave];
+    CmRowCache<R> & rc = rcs[hw_wave];
     CmRowState rs;
     u16 * __restrict__ spill = global_ptr<u16>(jobs[blockIdx.x].spill);
     const u32 miss_base = jobs[blockIdx.x].miss_base, miss_shift = jobs[blockIdx.x].miss_shift;
