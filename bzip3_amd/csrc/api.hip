@@ -1630,6 +1630,13 @@ BZIP3_API float bz3_hip_stage_cm_decode_many(const uint8_t * in, int32_t in_size
         e.down(out, o, (size_t)n);
         if (counters)
             for (int32_t k = 0; k < copies; k++) e.down(counters + 16 * (size_t)k, o + stride * (size_t)k, 128);
+        if (getenv("BZ3_CM_MANY_CHECK")) {  // every copy must have decoded the same bytes (-2 otherwise)
+            std::vector<u8> other((size_t)n);
+            for (int32_t k = 1; k < copies; k++) {
+                e.down(other.data(), o + stride * (size_t)k, (size_t)n);
+                if (memcmp(other.data(), out, (size_t)n) != 0) return -2.f;
+            }
+        }
         return ms;
     });
 }
