@@ -67,6 +67,8 @@ def _declare(L):
         "bz3_hip_stage_cm_encode": (i32, [vp, i32, vp]),
         "bz3_hip_stage_cm_decode": (None, [vp, i32, vp, i32]),
         "bz3_hip_stage_cm_decode_many": (C.c_float, [vp, i32, vp, i32, i32, vp]),
+        "bz3_hip_encode_stream": (C.c_int, [C.c_int, C.c_int, i32, i32]),
+        "bz3_hip_decode_stream": (C.c_int, [C.c_int, C.c_int, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = the library does not export what include/*.h declares

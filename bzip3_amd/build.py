@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libbzip3.so")
-SOURCES = ["sort.hip", "crc32c.hip", "mrle.hip", "lzp.hip", "bwt.hip", "unbwt.hip", "cm.hip", "api.hip"]
+SOURCES = ["sort.hip", "crc32c.hip", "mrle.hip", "lzp.hip", "bwt.hip", "unbwt.hip", "cm.hip", "api.hip", "stream.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unknown-pragmas", "-Wno-pass-failed"]

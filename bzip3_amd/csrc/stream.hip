@@ -1,0 +1,255 @@
+// stream.hip -- SURVEY.md 8f/N1: the driver loop of the reference CLI (src/main.c:351-407 -- read N blocks, fork-join,
+// write N blocks, repeat; no overlap of I/O and coding) as a three-stage pipeline on top of the C ABI of this library:
+// a reader thread fills batch k+1 from the input descriptor while the calling thread has batch k on the GPU
+// (bz3_encode_blocks / bz3_decode_blocks) and a writer thread drains batch k-1 in order.  Host code only; the file
+// bytes are those of `bzip3 -e -b <size>` / accepted by `bzip3 -d` (format: doc/bzip3_format.md:10-38, main.c:173-180,
+// :249-253): "BZ3v1", u32le block size, then per block u32le coded size, u32le original size, the block.  Like `-j 1`
+// (main.c:243-256) no chunk is written for a read of 0 bytes; the decoder accepts the empty chunk `-j N` appends when
+// the input is a multiple of the block size (main.c:352-362).
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include <errno.h>
+#include <unistd.h>
+
+#include "../../include/bz3_hip.h"
+#include "hipx.hpp"
+
+namespace {
+
+
+struct Batch {
+    s32 n = 0;                // blocks in use
+    std::vector<s32> size;    // encode: in = plain size, out = coded size; decode: coded size
+    std::vector<s32> orig;    // original size of every block
+    bool last = false;        // end of input reached after this batch
+    int error = 0;            // first error met while producing / processing it
+};
+
+// Hands batch slots from one stage to the next, in order.
+class Lane {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<int> q;
+
+public:
+    void put(int slot) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            q.push_back(slot);
+        }
+        cv.notify_one();
+    }
+    int take() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !q.empty(); });
+        const int s = q.front();
+        q.pop_front();
+        return s;
+    }
+};
+
+bool read_full(int fd, void * p, size_t n, size_t * got) {  // false on an I/O error; *got < n at end of file
+    size_t done = 0;
+    while (done < n) {
+        const ssize_t r = read(fd, (u8 *)p + done, n - done);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        if (r == 0) break;
+        done += (size_t)r;
+    }
+    *got = done;
+    return true;
+}
+
+bool write_full(int fd, const void * p, size_t n) {
+    size_t done = 0;
+    while (done < n) {
+        const ssize_t r = write(fd, (const u8 *)p + done, n - done);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        done += (size_t)r;
+    }
+    return true;
+}
+
+inline void put_le32(u8 * p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); p[3] = (u8)(v >> 24); }
+inline u32 get_le32(const u8 * p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
+
+constexpr int SLOTS = 3;
+
+struct Pipe {
+    s32 block_size = 0, per_batch = 0;
+    size_t cap = 0;
+    std::vector<bz3_state *> states;          // per_batch states, reused by every batch
+    std::vector<std::vector<u8 *>> bufs;      // [slot][block]: host buffers of bz3_bound(block_size) bytes
+    Batch batch[SLOTS];
+    Lane to_reader, to_coder, to_writer;
+
+    ~Pipe() {
+        for (bz3_state * s : states) bz3_free(s);
+        for (auto & v : bufs)
+            for (u8 * p : v) free(p);
+    }
+    bool init(s32 bs, s32 nb) {
+        block_size = bs;
+        per_batch = nb;
+        cap = bz3_bound((size_t)bs);
+        for (s32 i = 0; i < nb; i++) {
+            bz3_state * s = bz3_new(bs);
+            if (!s) return false;
+            states.push_back(s);
+        }
+        bufs.assign(SLOTS, std::vector<u8 *>());
+        for (int k = 0; k < SLOTS; k++) {
+            batch[k].size.assign((size_t)nb, 0);
+            batch[k].orig.assign((size_t)nb, 0);
+            for (s32 i = 0; i < nb; i++) {
+                u8 * p = (u8 *)malloc(cap);
+                if (!p) return false;
+                bufs[(size_t)k].push_back(p);
+            }
+            to_reader.put(k);
+        }
+        return true;
+    }
+};
+
+// Runs reader -> coder (this thread) -> writer until the batch flagged `last` (or the first error) has been written.
+template <class ReadBatch, class Code, class WriteBatch>
+int run_pipeline(Pipe & p, ReadBatch && read_batch, Code && code, WriteBatch && write_batch) {
+    std::thread reader([&] {
+        for (;;) {
+            const int k = p.to_reader.take();
+            if (k < 0) return;
+            Batch & b = p.batch[k];
+            b.n = 0;
+            b.last = false;
+            b.error = 0;
+            read_batch(b, p.bufs[(size_t)k]);
+            const bool stop = b.last || b.error;
+            p.to_coder.put(k);
+            if (stop) return;
+        }
+    });
+    int result = 0;
+    std::thread writer([&] {
+        for (;;) {
+            const int k = p.to_writer.take();
+            Batch & b = p.batch[k];
+            if (!result && b.n > 0) write_batch(b, p.bufs[(size_t)k]);  // blocks before the first failing one are committed
+            if (!result && b.error) result = b.error;
+            const bool stop = b.last || b.error;
+            p.to_reader.put(stop ? -1 : k);
+            if (stop) return;
+        }
+    });
+    for (;;) {
+        const int k = p.to_coder.take();
+        Batch & b = p.batch[k];
+        const bool stop = b.last || b.error;
+        if (b.n > 0) code(b, p.bufs[(size_t)k]);
+        p.to_writer.put(k);
+        if (stop || b.error) break;
+    }
+    writer.join();
+    p.to_reader.put(-1);  // in case the reader still waits for a slot
+    reader.join();
+    return result;
+}
+
+}  // namespace
+
+extern "C" {
+
+BZIP3_API int bz3_hip_encode_stream(int in_fd, int out_fd, int32_t block_size, int32_t blocks_per_batch) {
+    if (block_size < 65 * 1024 || block_size > 511 * 1024 * 1024 || blocks_per_batch < 1 || blocks_per_batch > 4096) return BZ3_ERR_INIT;
+    Pipe p;
+    if (!p.init(block_size, blocks_per_batch)) return BZ3_ERR_INIT;
+    u8 head[9] = {'B', 'Z', '3', 'v', '1'};
+    put_le32(head + 5, (u32)block_size);
+    if (!write_full(out_fd, head, 9)) return BZ3_HIP_ERR_IO;
+    return run_pipeline(
+        p,
+        [&](Batch & b, std::vector<u8 *> & bufs) {
+            for (s32 i = 0; i < p.per_batch; i++) {
+                size_t got = 0;
+                if (!read_full(in_fd, bufs[(size_t)i], (size_t)block_size, &got)) { b.error = BZ3_HIP_ERR_IO; return; }
+                if (got == 0) { b.last = true; return; }  // `if (read_count == 0) break;` (main.c:247)
+                b.size[(size_t)b.n] = b.orig[(size_t)b.n] = (s32)got;
+                b.n++;
+                if (got < (size_t)block_size) { b.last = true; return; }
+            }
+        },
+        [&](Batch & b, std::vector<u8 *> & bufs) {
+            bz3_encode_blocks(p.states.data(), bufs.data(), b.size.data(), b.n);
+            for (s32 i = 0; i < b.n; i++)
+                if (b.size[(size_t)i] < 0 || bz3_last_error(p.states[(size_t)i]) != BZ3_OK) {
+                    b.error = bz3_last_error(p.states[(size_t)i]) != BZ3_OK ? bz3_last_error(p.states[(size_t)i]) : BZ3_ERR_BWT;
+                    b.n = i;  // only the blocks before it are written
+                    return;
+                }
+        },
+        [&](Batch & b, std::vector<u8 *> & bufs) {
+            for (s32 i = 0; i < b.n; i++) {
+                u8 h[8];
+                put_le32(h, (u32)b.size[(size_t)i]);
+                put_le32(h + 4, (u32)b.orig[(size_t)i]);
+                if (!write_full(out_fd, h, 8) || !write_full(out_fd, bufs[(size_t)i], (size_t)b.size[(size_t)i])) { b.error = BZ3_HIP_ERR_IO; return; }
+            }
+        });
+}
+
+BZIP3_API int bz3_hip_decode_stream(int in_fd, int out_fd, int32_t blocks_per_batch) {
+    if (blocks_per_batch < 1 || blocks_per_batch > 4096) return BZ3_ERR_INIT;
+    u8 head[9];
+    size_t got = 0;
+    if (!read_full(in_fd, head, 9, &got)) return BZ3_HIP_ERR_IO;
+    if (got < 9 || memcmp(head, "BZ3v1", 5) != 0) return BZ3_ERR_MALFORMED_HEADER;  // "Invalid signature." (main.c:184-187)
+    const s32 block_size = (s32)get_le32(head + 5);
+    if (block_size < 65 * 1024 || block_size > 511 * 1024 * 1024) return BZ3_ERR_MALFORMED_HEADER;  // main.c:195-199
+    Pipe p;
+    if (!p.init(block_size, blocks_per_batch)) return BZ3_ERR_INIT;
+    std::vector<size_t> caps((size_t)blocks_per_batch, p.cap);
+    return run_pipeline(
+        p,
+        [&](Batch & b, std::vector<u8 *> & bufs) {
+            for (s32 i = 0; i < p.per_batch; i++) {
+                u8 h[8];
+                size_t g = 0;
+                if (!read_full(in_fd, h, 8, &g)) { b.error = BZ3_HIP_ERR_IO; return; }
+                if (g == 0) { b.last = true; return; }  // clean end of file between chunks
+                if (g < 8) { b.error = BZ3_ERR_TRUNCATED_DATA; return; }
+                const s32 comp = (s32)get_le32(h), orig = (s32)get_le32(h + 4);
+                // "Inconsistent headers." (main.c:265-268); negative sizes would make the reference read garbage: refused too
+                if (comp < 0 || orig < 0 || (size_t)comp > p.cap || (size_t)orig > p.cap) { b.error = BZ3_ERR_MALFORMED_HEADER; return; }
+                if (!read_full(in_fd, bufs[(size_t)b.n], (size_t)comp, &g)) { b.error = BZ3_HIP_ERR_IO; return; }
+                if (g < (size_t)comp) { b.error = BZ3_ERR_TRUNCATED_DATA; return; }
+                b.size[(size_t)b.n] = comp;
+                b.orig[(size_t)b.n] = orig;
+                b.n++;
+            }
+        },
+        [&](Batch & b, std::vector<u8 *> & bufs) {
+            bz3_decode_blocks(p.states.data(), bufs.data(), caps.data(), b.size.data(), b.orig.data(), b.n);
+            for (s32 i = 0; i < b.n; i++)
+                if (bz3_last_error(p.states[(size_t)i]) != BZ3_OK) {
+                    if (!b.error || i < b.n) b.error = bz3_last_error(p.states[(size_t)i]);
+                    b.n = i;
+                    return;
+                }
+        },
+        [&](Batch & b, std::vector<u8 *> & bufs) {
+            for (s32 i = 0; i < b.n; i++)
+                if (!write_full(out_fd, bufs[(size_t)i], (size_t)b.orig[(size_t)i])) { b.error = BZ3_HIP_ERR_IO; return; }
+        });
+}
+
+}  // extern "C"

@@ -87,6 +87,15 @@ BZIP3_API int32_t bz3_hip_stage_unbwt(const uint8_t * in, uint8_t * out, int32_t
 BZIP3_API int32_t bz3_hip_stage_cm_encode(const uint8_t * in, int32_t n, uint8_t * out);            /* encode_bytes    */
 BZIP3_API void bz3_hip_stage_cm_decode(const uint8_t * in, int32_t in_size, uint8_t * out, int32_t n); /* decode_bytes  */
 
+/* Streaming file codec (the reference CLI's driver loop, src/main.c:351-407, as a pipeline): reads blocks
+ * from in_fd, codes `blocks_per_batch` of them at a time on the GPU(s) while the next batch is being read and the previous
+ * one written, writes the reference's file format to out_fd ("BZ3v1", u32le block size, then per block u32le coded size,
+ * u32le original size, block bytes -- byte-identical to `bzip3 -e -b`, decodable by `bzip3 -d`, and vice versa).
+ * Returns 0, or a BZ3_ERR_* code (of the first failing block; the blocks before it have been written), or BZ3_HIP_ERR_IO. */
+#define BZ3_HIP_ERR_IO (-100)
+BZIP3_API int bz3_hip_encode_stream(int in_fd, int out_fd, int32_t block_size, int32_t blocks_per_batch);
+BZIP3_API int bz3_hip_decode_stream(int in_fd, int out_fd, int32_t blocks_per_batch);
+
 /* Profiling: `copies` identical CM decode jobs in one launch through the current CM kernel variant; returns the launch
  * time in milliseconds, `out` receives the n (>= 256) decoded bytes of copy 0; with BZ3_CM_DEBUG=3 `counters` (u64[16] per
  * copy, may be NULL) receives the decoder's phase cycle counters instead of valid output (bzip3_amd/csrc/api.hip). */

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "bzip3_amd", "csrc")
 OUT = os.path.join(HERE, "libbz3_emu_TESTONLY.so")
-SOURCES = ["sort.hip", "crc32c.hip", "mrle.hip", "lzp.hip", "bwt.hip", "unbwt.hip", "cm.hip", "api.hip"]
+SOURCES = ["sort.hip", "crc32c.hip", "mrle.hip", "lzp.hip", "bwt.hip", "unbwt.hip", "cm.hip", "api.hip", "stream.hip"]
 
 
 def build():

@@ -424,3 +424,58 @@ print("ok")
 ''' % (os.path.dirname(HERE), HERE, os.path.join(HERE, "emu"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BZ3_HIP_CUS="2"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-300:], r.stderr[-1200:])
+
+
+# ---- streaming file driver (stream.hip) ------------------------------------------------------------------
+def _bz3_file(oracle, data, bs):
+    """The reference CLI's file for `data` at block size bs (-j 1 layout: doc/bzip3_format.md, src/main.c:173-180, :243-256)."""
+    out = [b"BZ3v1", bs.to_bytes(4, "little")]
+    for off in range(0, len(data), bs):
+        chunk = data[off : off + bs]
+        n, err, blk = oracle.encode_block(chunk, bs)
+        assert err == 0
+        out += [n.to_bytes(4, "little"), len(chunk).to_bytes(4, "little"), blk]
+    return b"".join(out)
+
+
+def test_stream_driver_writes_and_reads_the_cli_format(emu, oracle, tmp_path):
+    bs = 65 * 1024
+    rng = np.random.default_rng(6)
+    unit = bytes(rng.integers(0, 256, size=911, dtype=np.uint8))
+    data = (unit * 300)[: 2 * bs + 7777]  # three blocks, the last one short; repetitive, so the emulated CM stage stays small
+
+    def run(fn, src_bytes, *args):
+        src, dst = tmp_path / "in.bin", tmp_path / "out.bin"
+        src.write_bytes(src_bytes)
+        fi, fo = os.open(src, os.O_RDONLY), os.open(dst, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+        try:
+            rc = fn(fi, fo, *args)
+        finally:
+            os.close(fi)
+            os.close(fo)
+        return rc, dst.read_bytes()
+
+    want = _bz3_file(oracle, data, bs)
+    for per_batch in (2, 5):
+        rc, enc = run(emu.bz3_hip_encode_stream, data, bs, per_batch)
+        assert rc == 0 and enc == want
+    assert run(emu.bz3_hip_decode_stream, want, 2) == (0, data)
+    # an input that is a multiple of the block size: no empty chunk (like -j 1); the decoder accepts the one -j N appends
+    exact = data[: 2 * bs]
+    rc, enc = run(emu.bz3_hip_encode_stream, exact, bs, 3)
+    assert rc == 0 and enc == _bz3_file(oracle, exact, bs)
+    empty_chunk = oracle.encode_block(b"", bs)[2]
+    quirk = enc + len(empty_chunk).to_bytes(4, "little") + (0).to_bytes(4, "little") + empty_chunk
+    assert run(emu.bz3_hip_decode_stream, quirk, 2) == (0, exact)
+    assert run(emu.bz3_hip_encode_stream, b"", bs, 2) == (0, b"BZ3v1" + bs.to_bytes(4, "little"))
+    assert run(emu.bz3_hip_decode_stream, b"BZ3v1" + bs.to_bytes(4, "little"), 2) == (0, b"")
+    # malformed files: what has been decoded before the failing block is committed, the code says why
+    second = 9 + 8 + int.from_bytes(want[9:13], "little")
+    rc, out = run(emu.bz3_hip_decode_stream, want[: second + 20], 2)
+    assert rc == bzip3_amd.BZ3_ERR_TRUNCATED_DATA and out == data[:bs]
+    flipped = want[: second + 40] + bytes([want[second + 40] ^ 0x10]) + want[second + 41 :]
+    rc, out = run(emu.bz3_hip_decode_stream, flipped, 1)
+    assert rc in (bzip3_amd.BZ3_ERR_CRC, bzip3_amd.BZ3_ERR_BWT, bzip3_amd.BZ3_ERR_MALFORMED_HEADER) and out == data[:bs]
+    assert run(emu.bz3_hip_decode_stream, b"BZ3v2" + want[5:], 2)[0] == bzip3_amd.BZ3_ERR_MALFORMED_HEADER
+    assert run(emu.bz3_hip_decode_stream, want[:9] + (2 ** 31 - 1).to_bytes(4, "little") + want[13:], 2)[0] == bzip3_amd.BZ3_ERR_MALFORMED_HEADER
+    assert emu.bz3_hip_encode_stream(0, 1, 1000, 2) == bzip3_amd.BZ3_ERR_INIT
