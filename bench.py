@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--blocks", type=int, default=int(os.environ.get("BZ3_BENCH_BLOCKS", "256")), help="256 MiB blocks per GPU")
     ap.add_argument("--block-mib", type=float, default=float(os.environ.get("BZ3_BENCH_BLOCK_MIB", "256")))
     ap.add_argument("--kind", default="text", choices=["text", "random"])
-    ap.add_argument("--cm-mode", default=os.environ.get("BZ3_BENCH_CM_MODE", "auto"), choices=["auto", "full", "rows", "rows3", "lock3", "measured"],
+    ap.add_argument("--cm-mode", default=os.environ.get("BZ3_BENCH_CM_MODE", "auto"), choices=["auto", "full", "rows", "rows3", "lock3", "lock2", "measured"],
                     help="CM kernel variant (bz3_hip_set_cm_mode): auto = full-model kernels; rows / rows3 = row-cache kernels, two / three blocks per CU; measured = by batch size")
     ap.add_argument("--lean", action="store_true", default=os.environ.get("BZ3_BENCH_LEAN", "0") == "1",
                     help="lean states (bz3_hip_set_lean_states): no per-state swap buffer, in-place CM encode -- room for ~3x256 blocks of 256 MiB")
@@ -169,7 +169,7 @@ def main():
     lib = bzip3_amd.load()
     assert lib.bz3_hip_device_count() > 0, "no HIP device"
     assert lib.bz3_hip_bind_device(local_rank) == 0
-    assert lib.bz3_hip_set_cm_mode({"auto": -1, "full": 0, "rows": 1, "rows3": 2, "lock3": 3, "measured": 100}[a.cm_mode]) == 0
+    assert lib.bz3_hip_set_cm_mode({"auto": -1, "full": 0, "rows": 1, "rows3": 2, "lock3": 3, "lock2": 4, "measured": 100}[a.cm_mode]) == 0
     assert lib.bz3_hip_set_lean_states(1 if a.lean else 0) == 0
 
     block_size = int(a.block_mib * (1 << 20))

@@ -186,6 +186,7 @@ int cm_mode() {
         else if (e && !strcmp(e, "rows")) m = CM_VARIANT_ROWS;
         else if (e && !strcmp(e, "rows3")) m = CM_VARIANT_ROWS3;
         else if (e && !strcmp(e, "lock3")) m = CM_VARIANT_LOCK3;
+        else if (e && !strcmp(e, "lock2")) m = CM_VARIANT_LOCK2;
         else if (e && !strcmp(e, "measured")) m = CM_MODE_MEASURED;
 #ifdef BZ3_EMU
         else if (e && !strcmp(e, "rows-test")) m = CM_VARIANT_ROWS_TEST;
@@ -1310,7 +1311,7 @@ BZIP3_API int bz3_hip_bind_device(int device) {
 BZIP3_API int bz3_hip_state_device(struct bz3_state * st) { return st->device; }
 
 BZIP3_API int bz3_hip_set_cm_mode(int mode) {
-    bool ok = (mode >= -1 && mode <= CM_VARIANT_LOCK3) || mode == CM_MODE_MEASURED;
+    bool ok = (mode >= -1 && mode <= CM_VARIANT_LOCK2) || mode == CM_MODE_MEASURED;
 #ifdef BZ3_EMU
     ok = ok || mode == CM_VARIANT_ROWS_TEST || mode == CM_VARIANT_LOCK_TEST;
 #endif

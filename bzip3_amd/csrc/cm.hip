@@ -1185,6 +1185,7 @@ __global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restric
 __global__ void __launch_bounds__(320) k_cm_decode_rows(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<CM_ROWS_DEC>(jobs); }
 __global__ void __launch_bounds__(320) k_cm_decode_rows3(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<CM_ROWS3_DEC>(jobs); }
 __global__ void __launch_bounds__(256) k_cm_decode_lock3(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_lockstep<CM_ROWS3_DEC>(jobs); }
+__global__ void __launch_bounds__(256) k_cm_decode_lock2(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_lockstep<CM_ROWS_DEC>(jobs); }
 #ifdef BZ3_EMU
 __global__ void __launch_bounds__(256) k_cm_decode_lock_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_lockstep<CM_ROWS_TEST>(jobs); }
 #endif
@@ -1209,6 +1210,7 @@ void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int v
     if (variant == CM_VARIANT_LOCK_TEST) return launch(k_cm_decode_lock_test, dim3(njobs), dim3(256), 0, s, d_jobs);
 #endif
     if (variant == CM_VARIANT_LOCK3) launch(k_cm_decode_lock3, dim3(njobs), dim3(256), 0, s, d_jobs);
+    else if (variant == CM_VARIANT_LOCK2) launch(k_cm_decode_lock2, dim3(njobs), dim3(256), 0, s, d_jobs);
     else if (variant == CM_VARIANT_ROWS3) launch(k_cm_decode_rows3, dim3(njobs), dim3(320), 0, s, d_jobs);
     else if (variant != CM_VARIANT_FULL) launch(k_cm_decode_rows, dim3(njobs), dim3(320), 0, s, d_jobs);
     else launch(k_cm_decode, dim3(njobs), dim3(320), 0, s, d_jobs);

@@ -122,7 +122,8 @@ struct CmDecodeJob {
 // Kernel variants: the whole 145.5 KiB model in LDS (one workgroup per CU), or the row-cache kernels (order-1 rows
 // cached in LDS: two or three workgroups per CU; they may give a block up, see status).
 // CM_VARIANT_LOCK3: row-cache encoder as ROWS3, but the lock-step decoder (cm.hip), three blocks per CU.
-enum { CM_VARIANT_FULL = 0, CM_VARIANT_ROWS = 1, CM_VARIANT_ROWS3 = 2, CM_VARIANT_LOCK3 = 3,
+// CM_VARIANT_LOCK2: the same pair with the 96-row caches, two blocks per CU.
+enum { CM_VARIANT_FULL = 0, CM_VARIANT_ROWS = 1, CM_VARIANT_ROWS3 = 2, CM_VARIANT_LOCK3 = 3, CM_VARIANT_LOCK2 = 4,
        CM_VARIANT_ROWS_TEST = 9, CM_VARIANT_LOCK_TEST = 10 /* emulator builds only: tiny cache */ };
 constexpr size_t CM_SPILL_BYTES = 256 * 256 * 2;
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL);

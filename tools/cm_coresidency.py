@@ -1,6 +1,6 @@
 """How do CM decoder variants behave when several blocks share a CU?  (GPU box, no torch import.)
     python tools/cm_coresidency.py [MiB=2] [copies ...=256 512 768] [--cycles]
-For every variant (full, rows, rows3, lock3) and every number of identical blocks: ONE launch of the CM decoder over
+For every variant (full, rows, rows3, lock2, lock3) and every number of identical blocks: ONE launch of the CM decoder over
 `copies` copies of the same coded block (bz3_hip_stage_cm_decode_many), launch time by HIP events, ns per byte and block,
 aggregate MiB/s.  --cycles additionally runs the guess-ahead variants with BZ3_CM_DEBUG=3 and prints the decoder's phase
 counters (cycles per byte: walker walk / wait, model wave speculate / wait / redo; shares of slow-path bytes and wrong
@@ -17,7 +17,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import bzip3_amd  # noqa: E402
 import datagen  # noqa: E402
 
-MODES = {"full": 0, "rows": 1, "rows3": 2, "lock3": 3}
+MODES = {"full": 0, "rows": 1, "rows3": 2, "lock2": 4, "lock3": 3}
 
 
 def main():
@@ -42,7 +42,7 @@ def main():
             ok = bytes(out) == plain and ms >= 0  # (BZ3_CM_MANY_CHECK=1: ms == -2 when the copies disagree)
             rec = {"variant": name, "copies": k, "block_mib": mib, "ms": round(ms, 1), "ns_per_byte_per_block": round(ms * 1e6 / n, 1),
                    "MiBps": round(k * mib / (ms * 1e-3), 1), "exact": ok}
-            if cycles and name != "lock3":
+            if cycles and not name.startswith("lock"):
                 os.environ["BZ3_CM_DEBUG"] = "3"
                 cnt = (C.c_uint64 * (16 * k))()
                 lib.bz3_hip_stage_cm_decode_many(inb, len(coded), out, n, k, cnt)
