@@ -665,7 +665,7 @@ __device__ __forceinline__ void cm_decode_block(const CmDecodeJob * __restrict__
     u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
     const u32 n = jobs[blockIdx.x].n;
     const u32 debug = jobs[blockIdx.x].debug & 15u;  // 3: cycle counters instead of the first output bytes (profiling only)
-    const u32 tune = jobs[blockIdx.x].debug >> 4;    // experiments: bit 0 = raise the walker's issue priority, bit 1 = model waves sleep while they poll
+    const u32 tune = jobs[blockIdx.x].debug >> 4;    // experiments: bit 0 = raise the walker's issue priority (measured: no effect)
     __shared__ CmLdsT<R> m;
     __shared__ u32 ptab[2][256];  // (18-bit probability of node) << 14
     __shared__ __attribute__((aligned(16))) u32 s_ready[4];  // per model wave: 2i+1 = speculative table of byte i is there, 2i+2 = corrected one
@@ -727,22 +727,21 @@ __device__ __forceinline__ void cm_decode_block(const CmDecodeJob * __restrict__
             // can only appear after a right guess (a wrong one makes the walker wait for this wave's corrected table), so it
             // carries the missed verdict: byte i-1 was g.  The walker cannot get further ahead than that: byte i+1 needs a
             // table this wave has not announced yet.
-            u32 word, seen_tag;
-            const u32 tag = i & 0xFFFFFFu, tag_next = (i + 1u) & 0xFFFFFFu;
+            u32 word, ahead;  // ahead = how far the mailbox is ahead of the verdict this wave waits for (tags are 24 bits wide)
+            const u32 tag = i & 0xFFFFFFu;
 #ifdef BZ3_EMU_WATCH
             unsigned long long spins_ = 0;
 #endif
             for (;;) {
                 word = cm_uniform(LDS_PEEK(s_done));
-                seen_tag = word >> 8;
-                if (seen_tag == tag || seen_tag == tag_next) break;
-                if (tune & 2u) BZ3_SPIN_PAUSE();
+                ahead = ((word >> 8) - tag) & 0xFFFFFFu;
+                if (ahead <= 1u) break;
                 BZ3_SPIN_TIGHT();
 #ifdef BZ3_EMU_WATCH
                 if (++spins_ == 300000ull && lane == 0) fprintf(stderr, "[model wave %u] stuck at i=%u waiting tag %u: s_done=%08x s_ready=%u %u %u %u\n", role, i, tag, s_done, s_ready[0], s_ready[1], s_ready[2], s_ready[3]);
 #endif
             }
-            const u32 c = seen_tag == tag ? (word & 0xFFu) : g;
+            const u32 c = ahead == 0u ? (word & 0xFFu) : g;
             if (debug == 3) t2 = cm_clock();
             if (c != g) {
                 // wrong guess: put the old counters back (the old values are still in `prev`), apply the real update
