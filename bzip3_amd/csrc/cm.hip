@@ -1026,9 +1026,9 @@ __device__ __forceinline__ void cm_decode_block(const CmDecodeJob * __restrict__
 // so workgroups that share a CU slow each other down (profiles/r01_cm_rows_probe.txt: two per CU = 2.07x the time).
 // This variant does the minimum instead: evaluate all nodes once the previous byte is known, barrier, wave 0 walks the
 // byte (same lane-speculated walk, same checked slow path) while the other waves sleep in the barrier, barrier, the 8
-// lanes on the decoded path update.  More latency per byte for a block that is alone, but about a third of the issue
-// slots, no polling and no speculation to undo: made for three to five blocks per CU.  Opt-in (CM_VARIANT_LOCK3);
-// not measured on the GPU yet (written after the round-1 GPU budget was spent).
+// lanes on the decoded path update.  More latency per byte for a block that is alone, but roughly half the issue slots
+// (~380 wave-instructions per byte by the ISA), no polling and no speculation to undo: made for several blocks per CU.
+// Opt-in (CM_VARIANT_LOCK2 / LOCK3); not measured on the GPU yet (written after the round-1 GPU budget was spent).
 // ------------------------------------------------------------------------------------------------
 template <int R>
 __device__ __forceinline__ void cm_decode_block_lockstep(const CmDecodeJob * __restrict__ jobs) {
