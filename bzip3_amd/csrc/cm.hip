@@ -385,6 +385,7 @@ __device__ __forceinline__ u32 cm_rows_chunk(M & m, CmRowCache<R> & rc, CmRowSta
 // One block.  R = 0: whole model in LDS; R > 0: row cache (see above).
 template <int R>
 __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__ jobs) {
+    static_assert(R == 0 || R >= (int)CM_CHUNK + 4, "a chunk pins up to CM_CHUNK + 2 rows: the cache must hold more than that");
     // one workgroup per block: blockIdx.x selects the job
     const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 n = jobs[blockIdx.x].n;
