@@ -116,8 +116,8 @@ struct CmDecodeJob {
     u32 n;
     u32 debug;     // 0 = normal; profiling only (output invalid): 1 = coder work only, 2 = model work only
     u32 pad;
-    u64 spill, status;          // as above
-    u32 miss_base, miss_shift;
+    u64 spill = 0, status = 0;  // as above
+    u32 miss_base = 0, miss_shift = 0;
 };
 // Kernel variants: the whole 145.5 KiB model in LDS (one workgroup per CU), or the row-cache kernels (order-1 rows
 // cached in LDS: two or three workgroups per CU; they may give a block up, see status).
