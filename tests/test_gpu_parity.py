@@ -222,6 +222,97 @@ def test_batch_api_host_buffers(gpu_lib, oracle, text):
         gpu_lib.bz3_free(s)
 
 
+def test_device_resident_api(gpu_lib, oracle, text):
+    import torch
+
+    bs = 2 << 20
+    d = text[: 2 << 20]
+    cap = gpu_lib.bz3_bound(bs) + 64
+    buf = torch.zeros(cap, dtype=torch.uint8, device="cuda:0")
+    buf[: len(d)] = torch.frombuffer(bytearray(d), dtype=torch.uint8).to("cuda:0")
+    torch.cuda.synchronize()
+    gpu_lib.bz3_hip_bind_device(0)
+    with bzip3_amd.State(bs, gpu_lib) as st:
+        n = gpu_lib.bz3_hip_encode_block_device(st.ptr, buf.data_ptr(), len(d))
+        assert st.last_error == 0
+        assert bytes(buf[:n].cpu().numpy()) == oracle.encode_block(d, bs)[2]
+        m = gpu_lib.bz3_hip_decode_block_device(st.ptr, buf.data_ptr(), cap, n, len(d))
+        assert (m, st.last_error) == (len(d), 0)
+        assert bytes(buf[:m].cpu().numpy()) == d
+    gpu_lib.bz3_hip_bind_device(-1)
+
+
+def test_frame_api_round_trip_and_reference_interop(gpu_lib, text):
+    from oracle_lib import RefLib
+
+    data = text[:3000000]
+    out = (C.c_uint8 * (gpu_lib.bz3_bound(len(data)) + 64))()
+    osz = C.c_size_t(len(out))
+    assert gpu_lib.bz3_compress(1 << 20, data, out, len(data), C.byref(osz)) == 0
+    ref = RefLib()
+    if ref.available:  # byte-identical frame, and the reference decodes ours
+        out2 = (C.c_uint8 * len(out))()
+        osz2 = C.c_size_t(len(out2))
+        assert ref.lib.bz3_compress(1 << 20, data, out2, len(data), C.byref(osz2)) == 0
+        assert osz.value == osz2.value and bytes(out[: osz.value]) == bytes(out2[: osz2.value])
+    back = (C.c_uint8 * (len(data) + 16))()
+    bsz = C.c_size_t(len(back))
+    assert gpu_lib.bz3_decompress(out, back, osz.value, C.byref(bsz)) == 0
+    assert bytes(back[: bsz.value]) == data
+
+
+def test_frame_api_multi_block_matches_reference(gpu_lib, text):
+    """bz3_compress / bz3_decompress (src/libbz3.c:876-997) batch the blocks of a frame; frames, return codes and the
+    bytes committed before an error must equal the reference's sequential loop (good + 15 malformed frames)."""
+    import frame_cases
+
+    frame_cases.check(gpu_lib, text[: 4 * 65 * 1024 + 1234], 65 * 1024)
+    frame_cases.check(gpu_lib, (text * 3)[: 4 * (1 << 20) + 777], 1 << 20)
+
+
+def test_large_block_round_trip_properties(gpu_lib, oracle):
+    # size-independent properties at a size the oracle's BWT would not finish quickly: decode(encode(x)) == x,
+    # the stored CRC is the oracle's CRC of x, header fields are self-consistent, and (when oracle/_ref
+    # travelled) the bytes equal the real reference's.
+    from oracle_lib import Bz3, RefLib
+
+    n = int(os.environ.get("BZ3_TEST_LARGE_MIB", "24")) << 20
+    d = datagen.text(n, seed=21, chains=4096)
+    with bzip3_amd.State(n, gpu_lib) as st:
+        m, err, blk = st.encode_block(d)
+        assert err == 0 and 0 < m < n // 3
+        assert struct.unpack("<I", blk[:4])[0] == oracle.crc32c(d)
+        ref = RefLib()
+        if ref.available:
+            assert Bz3(ref.lib).encode_block(d, n)[2] == blk
+        k, err, back = st.decode_block(blk, n)
+        assert (k, err) == (n, 0) and back == d
+        print("timings(decode, ms):", st.timings(), "bwt:", st.bwt_stats())
+
+
+@pytest.mark.skipif(os.environ.get("BZ3_TEST_FULL_SIZE") not in ("1", "2"), reason="256 MiB block: minutes of GPU time; set BZ3_TEST_FULL_SIZE=1 (encode) or 2 (+decode)")
+def test_full_size_256mib_block(gpu_lib, oracle):
+    """BASELINE.json's block size: the block the GPU produces is byte-identical to the reference's (REAL reference when
+    oracle/_ref is there).  The decode direction at this size is covered by bench.py's round-trip check of every block."""
+    from oracle_lib import Bz3, RefLib
+
+    n = 256 << 20
+    d = datagen.text(n, seed=31, chains=65536)
+    with bzip3_amd.State(n, gpu_lib) as st:
+        m, err, blk = st.encode_block(d)
+        assert err == 0 and struct.unpack("<I", blk[:4])[0] == oracle.crc32c(d)
+        print("timings(encode, ms):", st.timings(), "bwt:", st.bwt_stats())
+        ref = RefLib()
+        if ref.available:
+            rm, rerr, rblk = Bz3(ref.lib).encode_block(d, n)
+            assert (m, err) == (rm, rerr) and hashlib.md5(blk).hexdigest() == hashlib.md5(rblk).hexdigest() and blk == rblk
+            print("256 MiB block: %d bytes, md5 %s, identical to the reference" % (m, hashlib.md5(blk).hexdigest()))
+        if os.environ.get("BZ3_TEST_FULL_SIZE") == "2":
+            k, err, back = st.decode_block(blk, n)
+            assert (k, err) == (n, 0) and back == d
+
+
+# ---- opt-in machinery (row-cache kernels, lean states): after everything the default path needs ----------------------------------
 def test_cm_row_cache_kernels_on_gpu(gpu_lib, oracle, text):
     """The row-cache CM kernels (two workgroups per CU; bz3_hip_set_cm_mode(1)) must produce the bytes of the oracle:
     stage hooks on BWT output of text (fits the cache), on a 150-symbol source (slots are recycled through the spill
@@ -334,96 +425,6 @@ def test_lean_states_on_gpu(gpu_lib, oracle, text):
         gpu_lib.bz3_hip_set_lean_states(0)
         gpu_lib.bz3_hip_set_cm_mode(-1)
         gpu_lib.bz3_hip_release_cached_memory()
-
-
-def test_device_resident_api(gpu_lib, oracle, text):
-    import torch
-
-    bs = 2 << 20
-    d = text[: 2 << 20]
-    cap = gpu_lib.bz3_bound(bs) + 64
-    buf = torch.zeros(cap, dtype=torch.uint8, device="cuda:0")
-    buf[: len(d)] = torch.frombuffer(bytearray(d), dtype=torch.uint8).to("cuda:0")
-    torch.cuda.synchronize()
-    gpu_lib.bz3_hip_bind_device(0)
-    with bzip3_amd.State(bs, gpu_lib) as st:
-        n = gpu_lib.bz3_hip_encode_block_device(st.ptr, buf.data_ptr(), len(d))
-        assert st.last_error == 0
-        assert bytes(buf[:n].cpu().numpy()) == oracle.encode_block(d, bs)[2]
-        m = gpu_lib.bz3_hip_decode_block_device(st.ptr, buf.data_ptr(), cap, n, len(d))
-        assert (m, st.last_error) == (len(d), 0)
-        assert bytes(buf[:m].cpu().numpy()) == d
-    gpu_lib.bz3_hip_bind_device(-1)
-
-
-def test_frame_api_round_trip_and_reference_interop(gpu_lib, text):
-    from oracle_lib import RefLib
-
-    data = text[:3000000]
-    out = (C.c_uint8 * (gpu_lib.bz3_bound(len(data)) + 64))()
-    osz = C.c_size_t(len(out))
-    assert gpu_lib.bz3_compress(1 << 20, data, out, len(data), C.byref(osz)) == 0
-    ref = RefLib()
-    if ref.available:  # byte-identical frame, and the reference decodes ours
-        out2 = (C.c_uint8 * len(out))()
-        osz2 = C.c_size_t(len(out2))
-        assert ref.lib.bz3_compress(1 << 20, data, out2, len(data), C.byref(osz2)) == 0
-        assert osz.value == osz2.value and bytes(out[: osz.value]) == bytes(out2[: osz2.value])
-    back = (C.c_uint8 * (len(data) + 16))()
-    bsz = C.c_size_t(len(back))
-    assert gpu_lib.bz3_decompress(out, back, osz.value, C.byref(bsz)) == 0
-    assert bytes(back[: bsz.value]) == data
-
-
-def test_frame_api_multi_block_matches_reference(gpu_lib, text):
-    """bz3_compress / bz3_decompress (src/libbz3.c:876-997) batch the blocks of a frame; frames, return codes and the
-    bytes committed before an error must equal the reference's sequential loop (good + 15 malformed frames)."""
-    import frame_cases
-
-    frame_cases.check(gpu_lib, text[: 4 * 65 * 1024 + 1234], 65 * 1024)
-    frame_cases.check(gpu_lib, (text * 3)[: 4 * (1 << 20) + 777], 1 << 20)
-
-
-def test_large_block_round_trip_properties(gpu_lib, oracle):
-    # size-independent properties at a size the oracle's BWT would not finish quickly: decode(encode(x)) == x,
-    # the stored CRC is the oracle's CRC of x, header fields are self-consistent, and (when oracle/_ref
-    # travelled) the bytes equal the real reference's.
-    from oracle_lib import Bz3, RefLib
-
-    n = int(os.environ.get("BZ3_TEST_LARGE_MIB", "24")) << 20
-    d = datagen.text(n, seed=21, chains=4096)
-    with bzip3_amd.State(n, gpu_lib) as st:
-        m, err, blk = st.encode_block(d)
-        assert err == 0 and 0 < m < n // 3
-        assert struct.unpack("<I", blk[:4])[0] == oracle.crc32c(d)
-        ref = RefLib()
-        if ref.available:
-            assert Bz3(ref.lib).encode_block(d, n)[2] == blk
-        k, err, back = st.decode_block(blk, n)
-        assert (k, err) == (n, 0) and back == d
-        print("timings(decode, ms):", st.timings(), "bwt:", st.bwt_stats())
-
-
-@pytest.mark.skipif(os.environ.get("BZ3_TEST_FULL_SIZE") not in ("1", "2"), reason="256 MiB block: minutes of GPU time; set BZ3_TEST_FULL_SIZE=1 (encode) or 2 (+decode)")
-def test_full_size_256mib_block(gpu_lib, oracle):
-    """BASELINE.json's block size: the block the GPU produces is byte-identical to the reference's (REAL reference when
-    oracle/_ref is there).  The decode direction at this size is covered by bench.py's round-trip check of every block."""
-    from oracle_lib import Bz3, RefLib
-
-    n = 256 << 20
-    d = datagen.text(n, seed=31, chains=65536)
-    with bzip3_amd.State(n, gpu_lib) as st:
-        m, err, blk = st.encode_block(d)
-        assert err == 0 and struct.unpack("<I", blk[:4])[0] == oracle.crc32c(d)
-        print("timings(encode, ms):", st.timings(), "bwt:", st.bwt_stats())
-        ref = RefLib()
-        if ref.available:
-            rm, rerr, rblk = Bz3(ref.lib).encode_block(d, n)
-            assert (m, err) == (rm, rerr) and hashlib.md5(blk).hexdigest() == hashlib.md5(rblk).hexdigest() and blk == rblk
-            print("256 MiB block: %d bytes, md5 %s, identical to the reference" % (m, hashlib.md5(blk).hexdigest()))
-        if os.environ.get("BZ3_TEST_FULL_SIZE") == "2":
-            k, err, back = st.decode_block(blk, n)
-            assert (k, err) == (n, 0) and back == d
 
 
 def test_zz_three_blocks_per_cu_variants_on_gpu(gpu_lib, oracle, text):
