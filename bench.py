@@ -8,6 +8,21 @@ bz3_hip_decode_blocks_device (the inverse chain incl. the CRC check), i.e. the r
 bz3_encode_blocks / bz3_decode_blocks (src/libbz3.c:845-870) with device pointers.  value =
 input bytes of all ranks / 2^20 / (t_encode + t_decode).
 
+Wall budget.  One step over a GPU-filling batch of 256 MiB blocks takes minutes (the CM coder is a serial
+recurrence per block), so the requested --steps / --warmup are CLAMPED to what fits the wall budget
+(--budget-s, default 1300 s of the driver's 1800 s): at least one timed step always runs; a warmup step is
+only spent when a second step still fits.  The JSON line carries the steps / warmup actually run and the
+requested ones.  A watchdog thread prints the line with whatever has been measured so far if the hard
+deadline (--deadline-s) is reached while an optional extra leg is still running.
+
+Extra legs after the timed region (rank 0, N=1 only, each only while the budget lasts), all in "configs":
+  cfg3      BASELINE.json configs[2]: 1,000,000,000 B of text at -b 256 = 4 blocks on one GPU, with the
+            reference's -j 4 path timed on the host beside it;
+  random    incompressible blocks (LZP and RLE decline, the coder emits ~1 byte per byte).
+and "cpu_baseline": the REAL reference (oracle/_ref/libbz3ref.so) through its own bz3_encode_blocks /
+bz3_decode_blocks on min(cores, 64) host threads x 256 MiB blocks -- the same blocks the GPU coded, and the
+reference's coded bytes are compared with the GPU's (bit-exact parity at the metric's block size).
+
 Multi-GPU: blocks are independent, so each rank owns `--blocks` blocks on its own GPU (weak
 scaling), there is NO data-path collective; torch.distributed (RCCL) is used only for the barrier and the
 max-over-ranks timing the contract asks for.
@@ -15,14 +30,14 @@ max-over-ranks timing the contract asks for.
   python bench.py                       # N=1, default workload
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
          bench.py --gpus 8 --steps 1 --warmup 0
-Extra keys on the JSON line: "roofline" (dominant kernel), "cpu_baseline" (reference CPU path on this host),
-"stages" (per-stage ms of one block) and "bwt_roofline" (the HBM-bound radix-sort suffix array).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import signal
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -34,6 +49,14 @@ PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 ALG_BYTES_ROUND_TRIP = 32.4  # 17.2 B/B encode + 15.2 B/B decode
 ALG_BYTES_BWT = 11.0
+CFG3_BYTES = 1_000_000_000  # BASELINE.json configs[2]: "enwik9 (1 GB), -b 256, single MI355X"
+CM_MODES = {"auto": -1, "full": 0, "rows": 1, "rows3": 2, "lock3": 3, "lock2": 4, "measured": 100}
+
+T_START = time.perf_counter()
+RANK = int(os.environ.get("RANK", "0"))
+WORLD = int(os.environ.get("WORLD_SIZE", "1"))
+RESULT = {"line": None, "printed": False}  # the JSON line as far as it has been measured (rank 0)
+_PRINT_LOCK = threading.Lock()
 
 
 def parse():
@@ -41,28 +64,78 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--blocks", type=int, default=int(os.environ.get("BZ3_BENCH_BLOCKS", "256")), help="256 MiB blocks per GPU")
+    ap.add_argument("--blocks", type=int, default=int(os.environ.get("BZ3_BENCH_BLOCKS", "0")),
+                    help="blocks per GPU (0 = default for the CM mode: one block per CU, three with the row-cache kernels + lean states)")
     ap.add_argument("--block-mib", type=float, default=float(os.environ.get("BZ3_BENCH_BLOCK_MIB", "256")))
     ap.add_argument("--kind", default="text", choices=["text", "random"])
-    ap.add_argument("--cm-mode", default=os.environ.get("BZ3_BENCH_CM_MODE", "auto"), choices=["auto", "full", "rows", "rows3", "lock3", "lock2", "measured"],
-                    help="CM kernel variant (bz3_hip_set_cm_mode): auto = full-model kernels; rows / rows3 = row-cache kernels, two / three blocks per CU; measured = by batch size")
-    ap.add_argument("--lean", action="store_true", default=os.environ.get("BZ3_BENCH_LEAN", "0") == "1",
-                    help="lean states (bz3_hip_set_lean_states): no per-state swap buffer, in-place CM encode -- room for ~3x256 blocks of 256 MiB")
+    ap.add_argument("--cm-mode", default=os.environ.get("BZ3_BENCH_CM_MODE", "auto"), choices=sorted(CM_MODES),
+                    help="CM kernel variant (bz3_hip_set_cm_mode): auto = the library's policy; full = whole model in LDS, one block per CU; "
+                         "rows / rows3 / lock2 / lock3 = row-cache kernels, two / three blocks per CU")
+    ap.add_argument("--lean", type=int, default=int(os.environ.get("BZ3_BENCH_LEAN", "-1")),
+                    help="lean states (bz3_hip_set_lean_states): 1 = no per-state swap buffer, in-place CM encode (room for 3x256 blocks of 256 MiB); -1 = by block count")
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("BZ3_BENCH_BUDGET_S", "1300")),
+                    help="wall budget from process start: steps/warmup are clamped and the extra legs skipped so that the run ends before it")
+    ap.add_argument("--deadline-s", type=float, default=float(os.environ.get("BZ3_BENCH_DEADLINE_S", "1690")),
+                    help="hard deadline: the watchdog prints the JSON line as measured so far and exits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-mib", type=float, default=32.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the cfg3 / random legs")
     ap.add_argument("--cpu-threads", type=int, default=64)
+    ap.add_argument("--cpu-block-mib", type=float, default=0.0, help="CPU baseline block size (0 = the bench's block size)")
+    ap.add_argument("--cfg3-bytes", type=int, default=CFG3_BYTES, help="size of the cfg3 leg (only BASELINE's 1,000,000,000 B at 256 MiB blocks is reported as cfg3)")
+    ap.add_argument("--random-block-mib", type=float, default=32.0)
+    ap.add_argument("--random-blocks", type=int, default=64)
     return ap.parse_args()
 
 
-T_START = time.perf_counter()
+def elapsed():
+    return time.perf_counter() - T_START
 
 
 def progress(msg):
     """Milestones on stderr (stdout carries only the JSON line)."""
-    if int(os.environ.get("RANK", "0")) == 0:
-        print(f"[bench {time.perf_counter() - T_START:8.1f}s] {msg}", file=sys.stderr, flush=True)
+    if RANK == 0:
+        print(f"[bench {elapsed():8.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def emit_line(final):
+    """Print the JSON line once (rank 0)."""
+    with _PRINT_LOCK:
+        if RESULT["printed"] or RESULT["line"] is None:
+            return False
+        RESULT["line"]["complete"] = bool(final)
+        RESULT["line"]["wall_s"] = round(elapsed(), 1)
+        sys.stdout.write(json.dumps(RESULT["line"]) + "\n")
+        sys.stdout.flush()
+        RESULT["printed"] = True
+        return True
+
+
+def start_watchdog(deadline_s):
+    """The C calls of a step cannot be interrupted from Python (signal handlers only run between bytecodes), but ctypes
+    releases the GIL, so a thread can: at the hard deadline it prints what has been measured and ends the process."""
+
+    def run():
+        while elapsed() < deadline_s:
+            time.sleep(min(5.0, max(0.1, deadline_s - elapsed())))
+        if RANK == 0:
+            if emit_line(final=False):
+                progress("hard deadline: JSON line printed with the legs measured so far")
+            else:
+                progress("hard deadline: nothing measured yet" if RESULT["line"] is None else "hard deadline")
+        os._exit(0 if RESULT["printed"] or RANK != 0 else 3)
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+
+    def on_term(signum, frame):
+        if RANK == 0:
+            emit_line(final=False)
+        os._exit(0 if RESULT["printed"] or RANK != 0 else 3)
+
+    signal.signal(signal.SIGTERM, on_term)
+
+
+# ---- synthetic data ------------------------------------------------------------------------------------------------
 def gen_text_device(torch, nbytes, seed, device, piece=32 << 20):
     """`nbytes` of synthetic text, generated in pieces of at most 32 MiB (bounded temporaries), each piece its own seed."""
     parts = []
@@ -106,19 +179,63 @@ def gen_text_piece(torch, nbytes, seed, device):
     return out
 
 
-def cpu_baseline(sample_blocks, block_size):
-    """The REAL reference (oracle/_ref/libbz3ref.so, kind 'reference') -- or, if it did not travel, the plain-C
-    oracle (kind 'port', 1 core) -- timed on this host over a bounded sample of the same workload, through the
-    reference's own batch API (one pthread per block, src/libbz3.c:845-870)."""
+def fingerprint(torch, t):
+    """Position-sensitive 64-bit fingerprint of a uint8 tensor (a permuted or shifted block does not pass):
+    sum over 32-bit words of word * (1 + index mod 1000003), in chunks of 64 MiB."""
+    n4 = t.numel() // 4
+    acc = 0
+    step = 16 << 20  # words per chunk
+    w = t[: n4 * 4].view(torch.int32)
+    for o in range(0, n4, step):
+        m = min(step, n4 - o)
+        idx = torch.arange(o, o + m, device=t.device, dtype=torch.int64) % 1000003 + 1
+        acc = (acc + int((w[o : o + m].to(torch.int64) * idx).sum().item())) & 0xFFFFFFFFFFFFFFFF
+    tail = t[n4 * 4 :]
+    if tail.numel():
+        acc = (acc + int(tail.to(torch.int64).sum().item()) * 7919) & 0xFFFFFFFFFFFFFFFF
+    return acc
+
+
+# ---- the reference on the host (cpu_baseline) -----------------------------------------------------------------------
+def cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
+
+
+def host_mem_available():
+    try:
+        with open("/proc/meminfo") as fh:
+            for ln in fh:
+                if ln.startswith("MemAvailable"):
+                    return int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    return 8 << 30
+
+
+def reference_round_trip(sample_blocks, block_size, keep_encoded=False):
+    """The REAL reference (oracle/_ref/libbz3ref.so, kind 'reference') through its own batch API, one pthread per block
+    (src/libbz3.c:845-870), on this host.  Returns (record, encoded blocks or None).  Falls back to the plain-C oracle
+    (kind 'port', 1 core, 4 MiB) only if oracle/_ref did not travel."""
     from oracle_lib import Oracle, RefLib
 
     ref = RefLib()
     n = len(sample_blocks)
     total = sum(len(b) for b in sample_blocks)
+    model, ncpu = cpu_info()
     if ref.available:
         L = ref.lib
         cap = L.bz3_bound(block_size) + 64
         states = (C.c_void_p * n)(*[L.bz3_new(block_size) for _ in range(n)])
+        assert all(states), "reference bz3_new failed (host memory?)"
         bufs = [(C.c_uint8 * cap)() for _ in range(n)]
         for b, d in zip(bufs, sample_blocks):
             C.memmove(b, d, len(d))
@@ -127,37 +244,43 @@ def cpu_baseline(sample_blocks, block_size):
         t0 = time.perf_counter()
         L.bz3_encode_blocks(states, ptrs, sizes, n)
         t1 = time.perf_counter()
+        enc = [C.string_at(bufs[i], sizes[i]) for i in range(n)] if keep_encoded else None
         bsz = (C.c_size_t * n)(*[cap] * n)
         orig = (C.c_int32 * n)(*[len(d) for d in sample_blocks])
+        t1b = time.perf_counter()
         L.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
         t2 = time.perf_counter()
-        ok = all(L.bz3_last_error(states[i]) == 0 for i in range(n)) and all(bytes(bufs[i][: len(d)]) == d for i, d in enumerate(sample_blocks))
+        ok = all(L.bz3_last_error(states[i]) == 0 for i in range(n)) and all(
+            C.string_at(bufs[i], len(d)) == bytes(d) for i, d in enumerate(sample_blocks))
         for s in states:
             L.bz3_free(s)
         assert ok, "reference round trip failed"
-        return {"value": round(total / 2 ** 20 / (t2 - t0), 3), "unit": "MiB/s", "cores": n, "kind": "reference",
-                "sample": f"{n} x {len(sample_blocks[0]) / 2 ** 20:.0f} MiB text blocks, bz3_encode_blocks+bz3_decode_blocks of gcc -O2 reference, "
-                          f"enc {t1 - t0:.2f}s dec {t2 - t1:.2f}s"}
+        t_enc, t_dec = t1 - t0, t2 - t1b
+        rec = {"value": round(total / 2 ** 20 / (t_enc + t_dec), 3), "unit": "MiB/s", "cores": n, "kind": "reference",
+               "sample": f"{n} x {len(sample_blocks[0]) / 2 ** 20:.0f} MiB blocks (the GPU's blocks 0..{n - 1}), one pass of bz3_encode_blocks + "
+                         f"bz3_decode_blocks of the gcc -O2 reference, one thread per block",
+               "t_enc_s": round(t_enc, 2), "t_dec_s": round(t_dec, 2), "host_cpu": model, "host_cores": ncpu}
+        return rec, enc
     o = Oracle()
-    d = sample_blocks[0][: 4 << 20]
+    d = bytes(sample_blocks[0][: 4 << 20])
     t0 = time.perf_counter()
     n_enc, err, blk = o.encode_block(d, max(len(d), 65 * 1024))
     k, err2, back = o.decode_block(blk, len(d), max(len(d), 65 * 1024))
     t1 = time.perf_counter()
     assert err == 0 and err2 == 0 and back == d
     return {"value": round(len(d) / 2 ** 20 / (t1 - t0), 3), "unit": "MiB/s", "cores": 1, "kind": "port",
-            "sample": "one 4 MiB text block through oracle/bz3_oracle.c (oracle/_ref absent)"}
+            "sample": "one 4 MiB text block through oracle/bz3_oracle.c (oracle/_ref absent)", "host_cpu": model, "host_cores": ncpu}, None
 
 
 def main():
     a = parse()
+    start_watchdog(a.deadline_s)
     import torch  # first: the HIP runtime of the process must be torch's (see bzip3_amd._share_hip_runtime_with_torch)
     import torch.distributed as dist
 
     import bzip3_amd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    world, rank = WORLD, RANK
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     torch.cuda.set_device(local_rank)
@@ -169,11 +292,14 @@ def main():
     lib = bzip3_amd.load()
     assert lib.bz3_hip_device_count() > 0, "no HIP device"
     assert lib.bz3_hip_bind_device(local_rank) == 0
-    assert lib.bz3_hip_set_cm_mode({"auto": -1, "full": 0, "rows": 1, "rows3": 2, "lock3": 3, "lock2": 4, "measured": 100}[a.cm_mode]) == 0
-    assert lib.bz3_hip_set_lean_states(1 if a.lean else 0) == 0
+    assert lib.bz3_hip_set_cm_mode(CM_MODES[a.cm_mode]) == 0
+    per_cu = {"rows": 2, "lock2": 2, "rows3": 3, "lock3": 3, "measured": 3}.get(a.cm_mode, 1)
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    nblk = a.blocks if a.blocks > 0 else cus * per_cu
+    lean = a.lean == 1 or (a.lean < 0 and nblk > cus)
+    assert lib.bz3_hip_set_lean_states(1 if lean else 0) == 0
 
     block_size = int(a.block_mib * (1 << 20))
-    nblk = a.blocks
     cap = lib.bz3_bound(block_size) + 4096
 
     # ---- synthetic input, resident in HBM ----------------------------------------------------------------
@@ -184,7 +310,7 @@ def main():
         g = torch.Generator(device=device)
         g.manual_seed(2 + rank)
         base = torch.randint(0, 256, (block_size,), dtype=torch.uint8, generator=g, device=device)
-    bufs, sums = [], []
+    bufs, prints = [], []
     chunk = 1 << 16
     nchunks = block_size // chunk
     for k in range(nblk):
@@ -198,8 +324,10 @@ def main():
             buf[: nchunks * chunk] = base[: nchunks * chunk].view(nchunks, chunk)[perm].reshape(-1)
             buf[nchunks * chunk : block_size] = base[nchunks * chunk :]
         bufs.append(buf)
-        sums.append(int(buf[:block_size].to(torch.int64).sum().item()))
-    probe = bufs[0][: 1 << 16].clone()
+        prints.append(fingerprint(torch, buf[:block_size]))
+    # full copies of a few blocks, kept out of the codec's reach, for a byte-for-byte comparison after the round trip
+    n_keep = min(4, nblk) if not lean else min(2, nblk)
+    kept = [bufs[k][:block_size].clone() for k in range(n_keep)]
     del base
     torch.cuda.synchronize()
     torch.cuda.empty_cache()  # hand the generator's temporaries back: the codec workspace is hipMalloc'ed outside torch
@@ -219,8 +347,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    comp_total = [0]
+    def agree(x):
+        """Rank 0's value of a number, on every rank (all ranks must take the same budget decisions)."""
+        if world == 1:
+            return x
+        t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+        dist.broadcast(t, src=0)
+        return float(t.item())
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    comp_sizes = [0] * nblk
     stage = {}
+    # CPU parity / baseline sample: coded bytes of the first blocks, copied aside (device to device) before the in-place decode
+    want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline
+    cpu_block = int((a.cpu_block_mib or a.block_mib) * (1 << 20))
+    cpu_n = 0
+    if want_cpu:
+        per_thread = 6.5 * cpu_block + (64 << 20)  # reference state (~5.1 x block) + buffer + our copies
+        cpu_n = int(max(1, min(os.cpu_count() or 1, a.cpu_threads, nblk, host_mem_available() * 0.8 // per_thread)))
+    coded_kept = []
 
     def one_step(record=False):
         sizes = (C.c_int32 * nblk)(*[block_size] * nblk)
@@ -231,13 +382,16 @@ def main():
         for i in range(nblk):
             assert sizes[i] > 0 and lib.bz3_last_error(states[i]) == 0, f"encode failed on block {i}"
         if record:
-            comp_total[0] = sum(sizes)
+            comp_sizes[:] = list(sizes)
             tm = (C.c_float * 8)()
             lib.bz3_hip_last_timings(states[0], tm)
             stage["enc"] = {bzip3_amd.T_NAMES[j]: round(tm[j], 3) for j in range(6)}
             r, p, e = C.c_int32(), C.c_int32(), C.c_uint64()
             lib.bz3_hip_last_bwt_stats(states[0], C.byref(r), C.byref(p), C.byref(e))
             stage["bwt"] = {"rounds": r.value, "radix_passes": p.value, "sorted_elements": e.value}
+            if cpu_block == block_size and not coded_kept:  # a few ms of device-to-device copies inside the timed region, first recorded step only
+                for i in range(cpu_n):
+                    coded_kept.append(bufs[i][: sizes[i]].clone())
         t2 = time.perf_counter()
         lib.bz3_hip_decode_blocks_device(states, ptrs, bsz, sizes, orig, nblk)
         t3 = time.perf_counter()
@@ -251,39 +405,75 @@ def main():
             stage["t_enc_s"] = round(t1 - t0, 3)
             stage["t_dec_s"] = round(t3 - t2, 3)
 
-    for _ in range(a.warmup):
-        one_step()
+    # ---- steps under the wall budget ---------------------------------------------------------------------------------
+    extras_wanted = rank == 0 and world == 1 and not a.no_extras
+    reserve = (240.0 if want_cpu else 0.0) + (360.0 if extras_wanted else 0.0) + 30.0  # cpu_baseline, cfg3 + random, verification
     barrier()
     t0 = time.perf_counter()
-    for k in range(a.steps):
-        one_step(record=(k == a.steps - 1))
+    one_step(record=True)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    t_first = max_over_ranks(time.perf_counter() - t0)
+    left = agree(a.budget_s - elapsed()) - reserve
+    afford = int(max(0.0, left) // (t_first * 1.03))  # further steps that still fit
+    warmup_run, steps_run, timed = 0, 1, t_first
+    if afford >= 1 and (a.warmup > 0 or a.steps > 1):
+        if a.warmup > 0:  # the step just run becomes the warmup; more warmups only while timed steps are not displaced
+            warmup_run = 1 + max(0, min(a.warmup - 1, afford - a.steps))
+            for _ in range(warmup_run - 1):
+                one_step()
+            afford -= warmup_run - 1
+            steps_run, timed = 0, 0.0
+        more = max(1 - steps_run, min(a.steps - steps_run, afford))
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(more):
+            one_step(record=(k == more - 1))
+        barrier()
+        timed += max_over_ranks(time.perf_counter() - t0)
+        steps_run += more
+    progress(f"timed {steps_run} step(s) in {timed:.1f}s after {warmup_run} warmup step(s) (requested {a.steps} / {a.warmup}; budget {a.budget_s:.0f}s)")
 
     # ---- the round trip must be the identity (decode is in place: the buffers hold the plaintext again) ----
     for k in range(nblk):
-        assert int(bufs[k][:block_size].to(torch.int64).sum().item()) == sums[k], f"block {k}: round trip changed the data"
-    assert torch.equal(bufs[0][: 1 << 16], probe)
+        assert fingerprint(torch, bufs[k][:block_size]) == prints[k], f"block {k}: round trip changed the data"
+    for k in range(n_keep):
+        assert torch.equal(bufs[k][:block_size], kept[k]), f"block {k}: round trip changed the data"
+    # host copies for the reference legs: plaintext of blocks 0..cpu_n-1 (verified above) and the GPU's coded bytes of the same blocks
+    host_plain, host_coded = [], []
+    if want_cpu:
+        host_plain = [bufs[i][: min(cpu_block, block_size)].cpu().numpy() for i in range(cpu_n)] if cpu_block == block_size else \
+                     [bufs[0][:cpu_block].cpu().numpy()] * cpu_n
+        host_coded = [c.cpu().numpy().tobytes() for c in coded_kept]
+        coded_kept.clear()
 
     total_bytes = world * nblk * block_size
-    value = total_bytes * a.steps / 2 ** 20 / elapsed
-    out = None
+    value = total_bytes * steps_run / 2 ** 20 / timed
     if rank == 0:
+        comp_total = sum(comp_sizes)
         n_dec = block_size  # n' ~ n for text
-        cm_dec_ms = stage["dec"]["cm"]
-        cm_bytes = n_dec + comp_total[0] / nblk  # CM decode kernel: reads the coded bytes, writes n' bytes
+        cm_dec_ms, cm_enc_ms = stage["dec"]["cm"], stage["enc"]["cm"]
         bwt_ms = stage["enc"]["bwt"]
+        # Dominant kernel = the CM launch that takes longer.  Algorithmic bytes of a CM launch: every block's n' bytes on one
+        # side and its coded bytes on the other (CM 1R + cW / cR + 1W); launch time from HIP events on the
+        # launching stream (api.hip run_cm_jobs).
+        dec_dominant = cm_dec_ms >= cm_enc_ms
+        dom_ms = cm_dec_ms if dec_dominant else cm_enc_ms
+        mode = a.cm_mode
+        kern = {"full": "k_cm_decode", "auto": "k_cm_decode", "rows": "k_cm_decode_rows", "rows3": "k_cm_decode_rows3", "lock3": "k_cm_decode_lock3",
+                "lock2": "k_cm_decode_lock2", "measured": "k_cm_decode_rows3" if nblk > 2 * cus else "k_cm_decode"}[mode]
+        if not dec_dominant:
+            kern = kern.replace("decode", "encode").replace("lock3", "rows3").replace("lock2", "rows")
+        cm_bytes = n_dec * nblk + comp_total
         # HBM traffic of the dominant kernel from the PMC pass (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs,
-        # corrected as MI355X_MICROARCH.md prescribes), recorded per decoded byte and scaled to this launch.
+        # corrected as MI355X_MICROARCH.md prescribes), recorded per byte and scaled to this launch.
         traffic = None
         try:
             with open(PMC_TRAFFIC_FILE) as fh:
-                pm = json.load(fh)["k_cm_decode"]
-            traffic = int(pm["fetch_bytes_per_coded_byte"] * comp_total[0] + pm["write_bytes_per_decoded_byte"] * n_dec * nblk)
+                pm = json.load(fh).get(kern)
+            if pm and dec_dominant:
+                traffic = int(pm["fetch_bytes_per_coded_byte"] * comp_total + pm["write_bytes_per_decoded_byte"] * n_dec * nblk)
+            elif pm:
+                traffic = int(pm["fetch_bytes_per_input_byte"] * n_dec * nblk + pm["write_bytes_per_coded_byte"] * comp_total)
         except Exception:
             pass
         out = {
@@ -291,41 +481,44 @@ def main():
             "value": round(value, 3),
             "unit": "MiB/s",
             "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 1),
+            "steps": steps_run,
+            "warmup": warmup_run,
+            "ms_per_step": round(timed / steps_run * 1e3, 1),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
+            "requested": {"steps": a.steps, "warmup": a.warmup, "budget_s": a.budget_s,
+                          "note": "steps/warmup clamped to the wall budget: one step codes and decodes a GPU-filling batch of 256 MiB blocks"},
             "config": {
-                "workload": f"{nblk} x {a.block_mib:g} MiB synthetic enwik-style text blocks per GPU (word-bigram Markov over shakespeare.txt tokens; "
+                "workload": f"{nblk} x {a.block_mib:g} MiB synthetic enwik-style {a.kind} blocks per GPU (word-bigram Markov over shakespeare.txt tokens; "
                             f"blocks 2.. are 64 KiB-piece permutations of block 1), resident in HBM, "
                             f"bz3_hip_encode_blocks_device + bz3_hip_decode_blocks_device",
                 "block_bytes": block_size,
                 "blocks_per_gpu": nblk,
                 "parallelism": f"blocks sharded over {world} GPU(s), no collective",
-                "compressed_ratio": round(world * 0 + (nblk * block_size) / max(1, comp_total[0]), 3),
+                "compressed_ratio": round((nblk * block_size) / max(1, comp_total), 3),
                 "cm_mode": a.cm_mode,
-                "lean_states": bool(a.lean),
+                "lean_states": bool(lean),
                 "cm_blocks_given_up": int(lib.bz3_hip_cm_blocks_given_up()),
+                "round_trip_check": f"position-weighted 64-bit fingerprint of every block + byte-for-byte comparison of {n_keep} blocks",
             },
-            # dominant kernel by time: the CM decoder (one workgroup per block; a serial integer recurrence,
+            # dominant kernel by time: a CM launch (one workgroup per block; a serial integer recurrence,
             # latency-bound by construction -- SURVEY.md 7/H1), priced against the HBM roofline as the contract asks
             "roofline": {
-                "kernel": "k_cm_decode",
+                "kernel": kern,
                 "bound": "hbm",
-                "achieved": round(cm_bytes * nblk / (cm_dec_ms * 1e-3) / 1e9, 6),
+                "achieved": round(cm_bytes / (dom_ms * 1e-3) / 1e9, 6),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
-                "frac": round(cm_bytes * nblk / (cm_dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 9),
+                "frac": round(cm_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 9),
                 "traffic": traffic,
-                "launch_ms": cm_dec_ms,
-                "algorithmic_bytes_per_launch": int(cm_bytes * nblk),
+                "launch_ms": dom_ms,
+                "algorithmic_bytes_per_launch": int(cm_bytes),
             },
             "path_roofline": {
-                "achieved": round(ALG_BYTES_ROUND_TRIP * total_bytes * a.steps / elapsed / 1e9, 4),
+                "achieved": round(ALG_BYTES_ROUND_TRIP * total_bytes * steps_run / timed / 1e9, 4),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "bytes_per_input_byte": ALG_BYTES_ROUND_TRIP,
             },
             "bwt_roofline": {
@@ -337,24 +530,130 @@ def main():
             },
             "stages": stage,
             "gen_s": round(t_gen, 1),
+            "configs": {},
+            "cpu_baseline": {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": "not run (budget or --no-cpu-baseline)"},
         }
-        if not a.no_cpu_baseline:
-            try:
-                ncores = max(1, min(os.cpu_count() or 1, a.cpu_threads))
-                smp = int(a.cpu_sample_mib * (1 << 20))
-                smp = min(smp, block_size)
-                host = bufs[0][:block_size].cpu().numpy().tobytes()
-                sample = [host[(i * smp) % max(1, block_size - smp + 1):][:smp] for i in range(ncores)]
-                out["cpu_baseline"] = cpu_baseline(sample, max(smp, 65 * 1024))
-            except Exception as e:  # the baseline is reported, never required
-                out["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
+        RESULT["line"] = out
+
+    # ---- extra legs (rank 0 at N=1; the watchdog prints the line without them if they overrun) ----------------------------
+    def left_s():
+        return a.budget_s - elapsed()
+
+    def round_trip(sel, sizes_in):
+        """encode + decode of blocks `sel` of the batch (device pointers); returns (t_enc, t_dec, coded sizes)."""
+        n = len(sel)
+        S = (C.c_void_p * n)(*[states[k] for k in sel])
+        P = (C.c_void_p * n)(*[bufs[k].data_ptr() for k in sel])
+        sz = (C.c_int32 * n)(*sizes_in)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lib.bz3_hip_encode_blocks_device(S, P, sz, n)
+        t1 = time.perf_counter()
+        assert all(sz[i] > 0 and lib.bz3_last_error(S[i]) == 0 for i in range(n)), "encode failed"
+        coded = list(sz)
+        B = (C.c_size_t * n)(*[cap] * n)
+        O = (C.c_int32 * n)(*sizes_in)
+        lib.bz3_hip_decode_blocks_device(S, P, B, sz, O, n)
+        t2 = time.perf_counter()
+        assert all(lib.bz3_last_error(S[i]) == 0 for i in range(n)), "decode failed"
+        return t1 - t0, t2 - t1, coded
+
+    cpu_need = 2.6 * cpu_block / (4.5 * (1 << 20)) if want_cpu else 0.0  # ~4.5 MiB/s per thread and direction at 256 MiB blocks (BASELINE.md), with margin
+
+    n3 = (a.cfg3_bytes + block_size - 1) // block_size  # blocks of the cfg3 leg: full blocks + one partial
+    if extras_wanted and a.kind == "text" and nblk >= n3:
+        # cfg3 (BASELINE.json configs[2]): 1,000,000,000 B at -b 256 = 3 full blocks + 194,693,632 B, on one GPU
+        cm_s = (stage["enc"]["cm"] + stage["dec"]["cm"]) * 1e-3
+        est = cm_s * (1.0 if per_cu == 1 else 0.7) + 15.0
+        if left_s() - cpu_need > est:
+            progress(f"cfg3: {n3} blocks (estimated {est:.0f}s)")
+            sizes3 = [block_size] * (n3 - 1) + [a.cfg3_bytes - (n3 - 1) * block_size]
+            sel3 = list(range(n3))
+            fp3 = [fingerprint(torch, bufs[k][: sizes3[k]]) for k in sel3]
+            host_j4 = {}
+            th = None
+            if want_cpu and cpu_n >= n3 and cpu_block == block_size:
+                blocks3 = [host_plain[k][: sizes3[k]] for k in sel3]
+
+                def ref_j4():  # the reference's -j N on the same blocks, on the host, while the GPU codes them
+                    try:
+                        host_j4["rec"], _ = reference_round_trip(blocks3, block_size)
+                    except Exception as e:
+                        host_j4["err"] = str(e)
+
+                th = threading.Thread(target=ref_j4)
+                th.start()
+            te, td, coded = round_trip(sel3, sizes3)
+            assert all(fingerprint(torch, bufs[k][: sizes3[k]]) == fp3[k] for k in sel3), "cfg3: round trip changed the data"
+            is_cfg3 = a.cfg3_bytes == CFG3_BYTES and block_size == 256 << 20
+            rec = {"workload": ("BASELINE.json configs[2] stand-in: " if is_cfg3 else "(not BASELINE's size) ") +
+                               f"{a.cfg3_bytes} B of synthetic text, -b {a.block_mib:g} -> {n3} blocks ({n3 - 1} x {block_size} + {sizes3[-1]}) on one GPU",
+                   "value": round(a.cfg3_bytes / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
+                   "compressed_ratio": round(a.cfg3_bytes / sum(coded), 3)}
+            RESULT["line"]["configs"]["cfg3"] = rec
+            progress(f"cfg3: {rec['value']} MiB/s (enc {te:.1f}s dec {td:.1f}s)")
+            if th is not None:
+                th.join()
+                if "rec" in host_j4:
+                    r = host_j4["rec"]
+                    r["sample"] = f"reference -j {n3}: bz3_encode_blocks + bz3_decode_blocks on the same {n3} blocks, {n3} host threads, timed while the GPU coded them"
+                    rec["cpu_j4"] = r
+                    rec["vs_cpu_j4"] = round(rec["value"] / r["value"], 3)
+                    progress(f"cfg3: reference -j {n3} on the host: {r['value']} MiB/s")
+                else:
+                    rec["cpu_j4"] = {"value": None, "sample": "failed: " + host_j4.get("err", "?")}
+        else:
+            RESULT["line"]["configs"]["cfg3"] = {"skipped": f"needs ~{est:.0f}s, {left_s():.0f}s of the budget left"}
+
+    if want_cpu:
+        try:
+            if a.deadline_s - 20.0 - elapsed() < cpu_need:
+                raise RuntimeError(f"needs ~{cpu_need:.0f}s, {a.deadline_s - elapsed():.0f}s to the deadline")
+            progress(f"cpu_baseline: {cpu_n} threads x {cpu_block >> 20} MiB blocks (estimated {cpu_need:.0f}s)")
+            rec, enc = reference_round_trip(host_plain, max(cpu_block, 65 * 1024), keep_encoded=bool(host_coded))
+            if enc is not None and host_coded:
+                same = sum(1 for x, y in zip(enc, host_coded) if x == y)
+                rec["parity"] = f"{same} of {len(enc)} blocks of {cpu_block >> 20} MiB: the GPU's coded bytes are identical to the reference's"
+                assert same == len(enc), "GPU output differs from the reference: " + rec["parity"]
+            rec["gpu_over_cpu"] = round(RESULT["line"]["value"] / rec["value"], 3) if rec.get("value") else None
+            RESULT["line"]["cpu_baseline"] = rec
+            progress(f"cpu_baseline: {rec['value']} MiB/s on {rec['cores']} threads; {rec.get('parity', '')}")
+        except AssertionError:
+            raise
+        except Exception as e:  # the baseline is reported, never required
+            RESULT["line"]["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": f"not run: {e}"}
+        host_plain, host_coded = [], []
+
+    if extras_wanted and a.kind == "text":
+        # incompressible blocks: LZP and RLE decline (model 0), the coder emits ~1.004 bytes per byte
+        rb = int(a.random_block_mib * (1 << 20))
+        nr = max(1, min(a.random_blocks, nblk, cus))
+        if rb <= block_size and left_s() > 90.0:
+            progress(f"random: {nr} x {a.random_block_mib:g} MiB")
+            g = torch.Generator(device=device)
+            g.manual_seed(2)
+            fpr = []
+            rsel = list(range(nblk - nr, nblk))  # the last blocks of the batch (their text is not needed any more)
+            for k in rsel:
+                bufs[k][:rb] = torch.randint(0, 256, (rb,), dtype=torch.uint8, generator=g, device=device)
+                fpr.append(fingerprint(torch, bufs[k][:rb]))
+            te, td, coded = round_trip(rsel, [rb] * nr)
+            assert all(fingerprint(torch, bufs[k][:rb]) == f for k, f in zip(rsel, fpr)), "random: round trip changed the data"
+            RESULT["line"]["configs"]["random"] = {
+                "workload": f"{nr} x {a.random_block_mib:g} MiB uniformly random blocks on one GPU (states of {a.block_mib:g} MiB)",
+                "value": round(nr * rb / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
+                "compressed_ratio": round(nr * rb / sum(coded), 4)}
+            progress(f"random: {RESULT['line']['configs']['random']['value']} MiB/s")
+        else:
+            RESULT["line"]["configs"]["random"] = {"skipped": f"{left_s():.0f}s of the budget left"}
+
+    if rank == 0:
+        emit_line(final=True)
     for s in states:
         lib.bz3_free(s)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out))
 
 
 if __name__ == "__main__":

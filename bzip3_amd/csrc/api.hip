@@ -15,6 +15,7 @@
 #include <chrono>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -326,6 +327,7 @@ struct bz3_state {
     const u8 * cm_in = nullptr;
     u32 cm_in_size = 0;
     u8 * side = nullptr;  // lean encode: this block's slice of the in-place coder's side buffer
+    bool skip = false;    // host-buffer API: staging this block failed (on_failure has set the error); the group leaves it alone
     // decode
     size_t buffer_size = 0;
     u32 crc = 0;
@@ -391,6 +393,7 @@ void encode_front_a(bz3_state * st, u8 * buf, s32 data_size, Arena & arena, LzpE
     st->pending = bz3_state::FAILED;
     st->result = -1;
     c.active = false;
+    if (st->skip) return;  // last_error as on_failure left it
     if (data_size > st->block_size || data_size < 0) {  // :588-591 (a negative size would walk off the buffer)
         st->last_error = BZ3_ERR_DATA_TOO_BIG;
         return;
@@ -612,6 +615,7 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
 void decode_front(bz3_state * st, u8 * buf, size_t buffer_size, s32 compressed_size, s32 orig_size, const u8 * hdr) {
     st->pending = bz3_state::FAILED;
     st->result = -1;
+    if (st->skip) return;  // last_error as on_failure left it
     if (buffer_size < 9 || buffer_size < (size_t)compressed_size) {  // :658-661 (s32 -> size_t as in the reference)
         st->last_error = BZ3_ERR_DATA_SIZE_TOO_SMALL;
         return;
@@ -911,15 +915,25 @@ void on_failure(bz3_state * st) {
     }
 }
 
-// Splits a batch by device (states may live on different GPUs) and runs each group.
+// Splits a batch by device (states may live on different GPUs) and runs the groups CONCURRENTLY, one host thread per
+// GPU (the reference forks a thread per block, src/libbz3.c:845-856): every group has its own device context, stream,
+// arena and mutex, and hipSetDevice is per host thread, so the GPUs of a node work on their blocks at the same time.
+std::atomic<int> g_groups_running{0}, g_groups_peak{0};  // statistics (bz3_hip_debug_peak_concurrent_groups)
+
 template <typename F>
 void for_each_device_group(bz3_state ** states, s32 n, F && f) {
+    std::vector<std::vector<s32>> groups;
     std::vector<char> done((size_t)n, 0);
     for (s32 i = 0; i < n; i++) {
         if (done[(size_t)i]) continue;
-        std::vector<s32> idx;
+        groups.emplace_back();
         for (s32 j = i; j < n; j++)
-            if (!done[(size_t)j] && states[j]->device == states[i]->device) { idx.push_back(j); done[(size_t)j] = 1; }
+            if (!done[(size_t)j] && states[j]->device == states[i]->device) { groups.back().push_back(j); done[(size_t)j] = 1; }
+    }
+    auto run = [&](const std::vector<s32> & idx) {
+        const int now = g_groups_running.fetch_add(1) + 1;
+        int peak = g_groups_peak.load();
+        while (now > peak && !g_groups_peak.compare_exchange_weak(peak, now)) {}
         try {
             f(idx);
         } catch (const HipError & e) {
@@ -928,33 +942,107 @@ void for_each_device_group(bz3_state ** states, s32 n, F && f) {
         } catch (const std::bad_alloc &) {
             for (s32 j : idx) on_failure(states[j]);
         }
+        g_groups_running.fetch_sub(1);
+    };
+    std::vector<std::thread> workers;
+    size_t spawned = 1;  // groups [1, spawned) run on a worker thread each, group 0 and the rest on this thread
+    for (size_t g = 1; g < groups.size(); g++) {
+        try {
+            workers.emplace_back(run, std::cref(groups[g]));
+        } catch (const std::system_error &) {  // no thread to be had
+            break;
+        }
+        spawned = g + 1;
+    }
+    if (!groups.empty()) run(groups[0]);
+    for (size_t g = spawned; g < groups.size(); g++) run(groups[g]);
+    for (std::thread & t : workers) t.join();
+}
+
+// Host-buffer API: the blocks of a group are staged through the states' d_io buffers inside the group's own thread, all
+// copies of a direction enqueued back to back on the group's stream with ONE synchronisation, so the GPUs of a batch copy
+// and code at the same time.  A block whose staging fails is marked (skip) and left alone by the group; the others go on.
+void stage_in(bz3_state * st, const void * host, size_t bytes, hipStream_t s) {
+    try {
+        ensure_io(st);
+        if (bytes) HIP_CHECK(hipMemcpyAsync(st->d_io, host, bytes, hipMemcpyHostToDevice, s));
+    } catch (const HipError &) {
+        on_failure(st);
+        st->skip = true;
     }
 }
 
-void run_encode(bz3_state ** states, void ** buffers, s32 * sizes, s32 n) {
+void run_encode(bz3_state ** states, void ** buffers, s32 * sizes, s32 n, bool host) {
     for_each_device_group(states, n, [&](const std::vector<s32> & idx) {
         std::vector<bz3_state *> sts;
         std::vector<u8 *> bufs;
         std::vector<s32> szs;
-        for (s32 j : idx) { sts.push_back(states[j]); bufs.push_back((u8 *)buffers[j]); szs.push_back(sizes[j]); }
+        DeviceGuard g(states[idx[0]]->device);
+        hipStream_t s = states[idx[0]]->stream;
+        const double t0 = now_ms();
+        for (s32 j : idx) {
+            bz3_state * st = states[j];
+            st->skip = false;
+            if (host) stage_in(st, buffers[j], (sizes[j] >= 0 && sizes[j] <= st->block_size) ? (size_t)sizes[j] : 0, s);
+            sts.push_back(st);
+            bufs.push_back(host ? st->d_io : (u8 *)buffers[j]);
+            szs.push_back(sizes[j]);
+        }
+        if (host) HIP_CHECK(hipStreamSynchronize(s));
+        const float in_ms = (float)(now_ms() - t0);
         encode_group(sts.data(), bufs.data(), szs.data(), (s32)idx.size());
+        if (!host) return;
+        const double t1 = now_ms();
+        for (s32 j : idx) {
+            bz3_state * st = states[j];
+            if (st->result > 0 && !st->skip) HIP_CHECK(hipMemcpyAsync(buffers[j], st->d_io, (size_t)st->result, hipMemcpyDeviceToHost, s));
+        }
+        HIP_CHECK(hipStreamSynchronize(s));
+        const float out_ms = (float)(now_ms() - t1);
+        for (s32 j : idx) states[j]->t[BZ3_HIP_T_COPY] += (in_ms + out_ms) / (float)idx.size();
     });
-    for (s32 i = 0; i < n; i++) sizes[i] = states[i]->result;
+    for (s32 i = 0; i < n; i++) {
+        sizes[i] = states[i]->result;
+        states[i]->skip = false;
+    }
 }
 
-void run_decode(bz3_state ** states, void ** buffers, const size_t * buffer_sizes, const s32 * sizes, const s32 * orig_sizes, const u8 * hdrs, s32 n) {
+void run_decode(bz3_state ** states, void ** buffers, const size_t * buffer_sizes, const s32 * sizes, const s32 * orig_sizes, const u8 * hdrs, s32 n, bool host) {
     for_each_device_group(states, n, [&](const std::vector<s32> & idx) {
         std::vector<bz3_state *> sts;
         std::vector<u8 *> bufs;
         std::vector<size_t> bsz;
         std::vector<s32> csz, osz;
         std::vector<u8> hd;
+        DeviceGuard g(states[idx[0]]->device);
+        hipStream_t s = states[idx[0]]->stream;
+        const double t0 = now_ms();
         for (s32 j : idx) {
-            sts.push_back(states[j]); bufs.push_back((u8 *)buffers[j]); bsz.push_back(buffer_sizes[j]); csz.push_back(sizes[j]); osz.push_back(orig_sizes[j]);
+            bz3_state * st = states[j];
+            st->skip = false;
+            if (host) {
+                // the two checks that protect the H2D copy are the reference's first two (:658, :667); decode_front repeats them
+                const bool copy_ok = buffer_sizes[j] >= 9 && buffer_sizes[j] >= (size_t)sizes[j] && sizes[j] >= 0 &&
+                                     (size_t)sizes[j] <= bz3_bound((size_t)st->block_size);
+                stage_in(st, buffers[j], copy_ok ? (size_t)sizes[j] : 0, s);
+            }
+            sts.push_back(st); bufs.push_back(host ? st->d_io : (u8 *)buffers[j]); bsz.push_back(buffer_sizes[j]); csz.push_back(sizes[j]); osz.push_back(orig_sizes[j]);
             hd.insert(hd.end(), hdrs + 17 * (size_t)j, hdrs + 17 * (size_t)j + 17);
         }
+        if (host) HIP_CHECK(hipStreamSynchronize(s));
+        const float in_ms = (float)(now_ms() - t0);
         decode_group(sts.data(), bufs.data(), bsz.data(), csz.data(), osz.data(), hd.data(), (s32)idx.size());
+        if (!host) return;
+        const double t1 = now_ms();
+        for (s32 j : idx) {
+            bz3_state * st = states[j];
+            if (st->result > 0 && !st->skip) HIP_CHECK(hipMemcpyAsync(buffers[j], st->d_io, (size_t)st->result, hipMemcpyDeviceToHost, s));
+        }
+        HIP_CHECK(hipStreamSynchronize(s));
+        const float out_ms = (float)(now_ms() - t1);
+        for (s32 j : idx) states[j]->t[BZ3_HIP_T_COPY] += (in_ms + out_ms) / (float)idx.size();
     });
+    for (s32 i = 0; i < n; i++) states[i]->skip = false;
 }
 
 // Host copies of the first 17 bytes of n device-resident blocks.
@@ -1046,19 +1134,19 @@ BZIP3_API size_t bz3_min_memory_needed(int32_t block_size) {
 
 // ---- device-resident entry points (bz3_hip.h) -----------------------------------------------------
 BZIP3_API void bz3_hip_encode_blocks_device(struct bz3_state * states[], void * buffers[], int32_t sizes[], int32_t n) {
-    run_encode(states, buffers, sizes, n);
+    run_encode(states, buffers, sizes, n, false);
 }
 
 BZIP3_API void bz3_hip_decode_blocks_device(struct bz3_state * states[], void * buffers[], size_t buffer_sizes[], int32_t sizes[],
                                             int32_t orig_sizes[], int32_t n) {
     std::vector<u8> hdrs;
     fetch_headers(states, buffers, buffer_sizes, n, hdrs);
-    run_decode(states, buffers, buffer_sizes, sizes, orig_sizes, hdrs.data(), n);
+    run_decode(states, buffers, buffer_sizes, sizes, orig_sizes, hdrs.data(), n, false);
 }
 
 BZIP3_API int32_t bz3_hip_encode_block_device(struct bz3_state * st, void * buffer, int32_t size) {
     s32 sz = size;
-    run_encode(&st, &buffer, &sz, 1);
+    run_encode(&st, &buffer, &sz, 1, false);
     return sz;
 }
 
@@ -1068,76 +1156,16 @@ BZIP3_API int32_t bz3_hip_decode_block_device(struct bz3_state * st, void * buff
     return st->result;
 }
 
-// ---- host-buffer entry points (libbz3.h): stage through the state's d_io, then run the device path ------
+// ---- host-buffer entry points (libbz3.h): staged through the states' d_io buffers by the device groups (run_encode / run_decode) ------
 BZIP3_API void bz3_encode_blocks(struct bz3_state * states[], uint8_t * buffers[], int32_t sizes[], int32_t n) {
-    std::vector<void *> dev((size_t)n, nullptr);
-    std::vector<s32> in_sizes(sizes, sizes + n);
-    for (s32 i = 0; i < n; i++) {
-        bz3_state * st = states[i];
-        try {
-            HIP_CHECK(hipSetDevice(st->device));
-            ensure_io(st);
-            dev[(size_t)i] = st->d_io;
-            if (sizes[i] >= 0 && sizes[i] <= st->block_size) {
-                const double t0 = now_ms();
-                HIP_CHECK(hipMemcpyAsync(st->d_io, buffers[i], (size_t)sizes[i], hipMemcpyHostToDevice, st->stream));
-                HIP_CHECK(hipStreamSynchronize(st->stream));
-                st->t[BZ3_HIP_T_COPY] = (float)(now_ms() - t0);
-            }
-        } catch (const HipError &) {
-            on_failure(st);
-            in_sizes[(size_t)i] = -1;
-        }
-    }
-    run_encode(states, dev.data(), sizes, n);
-    for (s32 i = 0; i < n; i++) {
-        bz3_state * st = states[i];
-        if (sizes[i] <= 0) continue;
-        try {
-            HIP_CHECK(hipSetDevice(st->device));
-            HIP_CHECK(hipMemcpyAsync(buffers[i], st->d_io, (size_t)sizes[i], hipMemcpyDeviceToHost, st->stream));
-            HIP_CHECK(hipStreamSynchronize(st->stream));
-        } catch (const HipError &) {
-            on_failure(st);
-            sizes[i] = -1;
-        }
-    }
+    run_encode(states, (void **)buffers, sizes, n, true);
 }
 
 BZIP3_API void bz3_decode_blocks(struct bz3_state * states[], uint8_t * buffers[], size_t buffer_sizes[], int32_t sizes[], int32_t orig_sizes[],
                                  int32_t n) {
-    std::vector<void *> dev((size_t)n, nullptr);
     std::vector<u8> hdrs(17 * (size_t)n, 0);
-    for (s32 i = 0; i < n; i++) {
-        bz3_state * st = states[i];
-        // the two checks that protect the H2D copy are the reference's first two (:658, :667); decode_front repeats them
-        const bool copy_ok = buffer_sizes[i] >= 9 && buffer_sizes[i] >= (size_t)sizes[i] && sizes[i] >= 0 &&
-                             (size_t)sizes[i] <= bz3_bound((size_t)st->block_size);
-        memcpy(hdrs.data() + 17 * (size_t)i, buffers[i], buffer_sizes[i] < 17 ? buffer_sizes[i] : 17);
-        try {
-            HIP_CHECK(hipSetDevice(st->device));
-            ensure_io(st);
-            dev[(size_t)i] = st->d_io;
-            if (copy_ok) {
-                HIP_CHECK(hipMemcpyAsync(st->d_io, buffers[i], (size_t)sizes[i], hipMemcpyHostToDevice, st->stream));
-                HIP_CHECK(hipStreamSynchronize(st->stream));
-            }
-        } catch (const HipError &) {
-            on_failure(st);
-        }
-    }
-    run_decode(states, dev.data(), buffer_sizes, sizes, orig_sizes, hdrs.data(), n);
-    for (s32 i = 0; i < n; i++) {
-        bz3_state * st = states[i];
-        if (st->result <= 0) continue;
-        try {
-            HIP_CHECK(hipSetDevice(st->device));
-            HIP_CHECK(hipMemcpyAsync(buffers[i], st->d_io, (size_t)st->result, hipMemcpyDeviceToHost, st->stream));
-            HIP_CHECK(hipStreamSynchronize(st->stream));
-        } catch (const HipError &) {
-            on_failure(st);
-        }
-    }
+    for (s32 i = 0; i < n; i++) memcpy(hdrs.data() + 17 * (size_t)i, buffers[i], buffer_sizes[i] < 17 ? buffer_sizes[i] : 17);
+    run_decode(states, (void **)buffers, buffer_sizes, sizes, orig_sizes, hdrs.data(), n, true);
 }
 
 BZIP3_API int32_t bz3_encode_block(struct bz3_state * st, uint8_t * buffer, int32_t size) {
@@ -1241,9 +1269,17 @@ BZIP3_API int bz3_decompress(const uint8_t * in, uint8_t * out, size_t in_size, 
     in += 13;
     FrameWindow w;
     {
-        // never more states than chunks that can possibly be present (8 header bytes each)
-        const size_t possible = in_size / 8 + 1;
-        if (!w.init(block_size, n_blocks < possible ? n_blocks : possible)) return BZ3_ERR_INIT;  // :953-960
+        // The header fields are untrusted: size the window from the chunks that are actually PRESENT -- walk the chunk
+        // headers with the checks of the loop below and count the chunks that lie inside the input -- never from
+        // n_blocks alone (a few hundred bytes claiming thousands of 511 MiB blocks must not allocate a window of states).
+        size_t present = 0, off = 0;
+        while (present < n_blocks && in_size - off >= 8) {
+            const s32 size = (s32)rd_le32(in + off);
+            if (size < 0 || (u32)size > block_size || in_size - off < (size_t)size + 8) break;
+            off += (size_t)size + 8;
+            present++;
+        }
+        if (!w.init(block_size, present ? present : 1)) return BZ3_ERR_INIT;  // :953-960
     }
     const size_t buf_max = *out_size;
     *out_size = 0;
@@ -1321,6 +1357,12 @@ BZIP3_API int bz3_hip_set_cm_mode(int mode) {
 }
 
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void) { return g_cm_given_up.load(); }
+
+BZIP3_API int bz3_hip_debug_peak_concurrent_groups(int reset) {
+    const int v = g_groups_peak.load();
+    if (reset) g_groups_peak.store(0);
+    return v;
+}
 
 BZIP3_API int bz3_hip_set_lean_states(int on) {
     g_lean.store(on ? 1 : 0);
@@ -1524,7 +1566,7 @@ void stage_cm_job(StageEnv & e, Job job, Launch && go) {
     if (variant != CM_VARIANT_FULL) {
         job.spill = dev_addr(e.dev(CM_SPILL_BYTES));
         status = (u32 *)e.dev(64);
-        HIP_CHECK(hipMemset(status, 0, 64));
+        HIP_CHECK(hipMemsetAsync(status, 0, 64, e.s));  // on the launching stream: a non-blocking stream does not order with the null stream
         job.status = dev_addr(status);
         job.miss_base = variant >= CM_VARIANT_ROWS_TEST ? 64u : 256u;
         job.miss_shift = variant >= CM_VARIANT_ROWS_TEST ? 3u : 8u;
@@ -1604,7 +1646,7 @@ BZIP3_API float bz3_hip_stage_cm_decode_many(const uint8_t * in, int32_t in_size
         const int variant = cm_variant_for(e.ctx, (size_t)copies, false);
         u8 * spill = variant != CM_VARIANT_FULL ? e.dev(CM_SPILL_BYTES * (size_t)copies) : nullptr;
         u32 * status = (u32 *)e.dev(4 * (size_t)copies + 64);
-        HIP_CHECK(hipMemset(status, 0, 4 * (size_t)copies));
+        HIP_CHECK(hipMemsetAsync(status, 0, 4 * (size_t)copies, e.s));
         std::vector<CmDecodeJob> jobs;
         for (int32_t k = 0; k < copies; k++) {
             CmDecodeJob j{dev_addr(d), dev_addr(o + stride * (size_t)k), (u32)in_size, (u32)n, debug, 0u};

@@ -6,6 +6,7 @@
 // :249-253): "BZ3v1", u32le block size, then per block u32le coded size, u32le original size, the block.  Like `-j 1`
 // (main.c:243-256) no chunk is written for a read of 0 bytes; the decoder accepts the empty chunk `-j N` appends when
 // the input is a multiple of the block size (main.c:352-362).
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -123,12 +124,21 @@ struct Pipe {
 };
 
 // Runs reader -> coder (this thread) -> writer until the batch flagged `last` (or the first error) has been written.
+//
+// Shutdown protocol.  Batch slots travel reader -> coder -> writer -> reader; the end of the stream is a sentinel (-1)
+// that FOLLOWS the last batch down the same lanes: the reader puts it behind its last batch, the coder forwards it,
+// the writer returns when it arrives.  A failure met by the writer (write error, or a batch that carries an error) sets
+// `failed`: from then on nothing is committed any more, the writer keeps handing slots back (so the reader can never
+// wait for a slot for ever), the reader stops at its next slot and sends the sentinel, the coder skips the GPU work of
+// the batches still queued.  Batch fields are only touched by the stage that holds the slot (the lanes' mutexes order
+// the hand-overs); the writer reports through its return value, not through the batch.
 template <class ReadBatch, class Code, class WriteBatch>
 int run_pipeline(Pipe & p, ReadBatch && read_batch, Code && code, WriteBatch && write_batch) {
+    std::atomic<bool> failed{false};
     std::thread reader([&] {
         for (;;) {
             const int k = p.to_reader.take();
-            if (k < 0) return;
+            if (failed.load()) break;
             Batch & b = p.batch[k];
             b.n = 0;
             b.last = false;
@@ -136,32 +146,34 @@ int run_pipeline(Pipe & p, ReadBatch && read_batch, Code && code, WriteBatch && 
             read_batch(b, p.bufs[(size_t)k]);
             const bool stop = b.last || b.error;
             p.to_coder.put(k);
-            if (stop) return;
+            if (stop) break;
         }
+        p.to_coder.put(-1);
     });
     int result = 0;
     std::thread writer([&] {
         for (;;) {
             const int k = p.to_writer.take();
+            if (k < 0) return;
             Batch & b = p.batch[k];
-            if (!result && b.n > 0) write_batch(b, p.bufs[(size_t)k]);  // blocks before the first failing one are committed
-            if (!result && b.error) result = b.error;
-            const bool stop = b.last || b.error;
-            p.to_reader.put(stop ? -1 : k);
-            if (stop) return;
+            if (!result) {
+                if (b.n > 0) result = write_batch(b, p.bufs[(size_t)k]);  // blocks before the first failing one are committed
+                if (!result && b.error) result = b.error;
+                if (result) failed.store(true);
+            }
+            p.to_reader.put(k);
         }
     });
     for (;;) {
         const int k = p.to_coder.take();
+        if (k < 0) break;
         Batch & b = p.batch[k];
-        const bool stop = b.last || b.error;
-        if (b.n > 0) code(b, p.bufs[(size_t)k]);
+        if (b.n > 0 && !failed.load()) code(b, p.bufs[(size_t)k]);
         p.to_writer.put(k);
-        if (stop || b.error) break;
     }
-    writer.join();
-    p.to_reader.put(-1);  // in case the reader still waits for a slot
+    p.to_writer.put(-1);
     reader.join();
+    writer.join();
     return result;
 }
 
@@ -197,13 +209,14 @@ BZIP3_API int bz3_hip_encode_stream(int in_fd, int out_fd, int32_t block_size, i
                     return;
                 }
         },
-        [&](Batch & b, std::vector<u8 *> & bufs) {
+        [&](Batch & b, std::vector<u8 *> & bufs) -> int {
             for (s32 i = 0; i < b.n; i++) {
                 u8 h[8];
                 put_le32(h, (u32)b.size[(size_t)i]);
                 put_le32(h + 4, (u32)b.orig[(size_t)i]);
-                if (!write_full(out_fd, h, 8) || !write_full(out_fd, bufs[(size_t)i], (size_t)b.size[(size_t)i])) { b.error = BZ3_HIP_ERR_IO; return; }
+                if (!write_full(out_fd, h, 8) || !write_full(out_fd, bufs[(size_t)i], (size_t)b.size[(size_t)i])) return BZ3_HIP_ERR_IO;
             }
+            return 0;
         });
 }
 
@@ -246,9 +259,10 @@ BZIP3_API int bz3_hip_decode_stream(int in_fd, int out_fd, int32_t blocks_per_ba
                     return;
                 }
         },
-        [&](Batch & b, std::vector<u8 *> & bufs) {
+        [&](Batch & b, std::vector<u8 *> & bufs) -> int {
             for (s32 i = 0; i < b.n; i++)
-                if (!write_full(out_fd, bufs[(size_t)i], (size_t)b.orig[(size_t)i])) { b.error = BZ3_HIP_ERR_IO; return; }
+                if (!write_full(out_fd, bufs[(size_t)i], (size_t)b.orig[(size_t)i])) return BZ3_HIP_ERR_IO;
+            return 0;
         });
 }
 

@@ -42,6 +42,10 @@ BZIP3_API int bz3_hip_set_cm_mode(int mode);
 /* Number of blocks the row-cache kernels have handed back to the full-model kernels so far (statistics). */
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void);
 
+/* Test hook: the largest number of per-GPU groups of one batch call that have been running at the same time since the
+ * last reset (a batch whose states live on G GPUs runs G groups concurrently, one host thread per GPU). */
+BZIP3_API int bz3_hip_debug_peak_concurrent_groups(int reset);
+
 /* Lean states (process-wide switch, read by bz3_new; environment BZ3_HIP_LEAN=1 has the same effect).  A state
  * normally owns its swap buffer (the reference's swap_buffer, bz3_bound(block_size) bytes of HBM) for life, so a
  * batch of N blocks holds 2 N block-sized buffers.  A lean state owns none: it borrows one from a per-GPU pool only

@@ -1,6 +1,7 @@
 // tests/emu/hip_emu.cpp -- TEST INFRASTRUCTURE ONLY (see hip_emu.hpp).
 // Fiber scheduler that runs the threads of one emulated HIP block at a time.
 #include "hip_emu.hpp"
+#include <mutex>
 
 namespace emu {
 
@@ -71,7 +72,10 @@ static void prepare(Fiber & f) {
     f.done = false;
 }
 
+static std::mutex g_launch_mu;  // one emulated GPU: launches from several host threads (one per "device") take turns
+
 void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()> & body) {
+    std::lock_guard<std::mutex> launch_lock(g_launch_mu);
     if (g_cur != nullptr) { fprintf(stderr, "emu: nested launch\n"); abort(); }
     int nthreads = (int)(block.x * block.y * block.z);
     if (block.y != 1 || block.z != 1 || nthreads > 32 * kWave) { fprintf(stderr, "emu: unsupported block shape\n"); abort(); }

@@ -217,7 +217,13 @@ inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int * n) { *n = 1; return hipSuccess; }
+// BZ3_EMU_DEVICES=<n>: pretend there are n devices (tests of the per-device host threads).  All "devices" share the one
+// emulated GPU: kernel launches of different host threads are serialised by a lock in run_grid.
+inline hipError_t hipGetDeviceCount(int * n) {
+    const char * e = getenv("BZ3_EMU_DEVICES");
+    *n = (e && atoi(e) > 0) ? atoi(e) : 1;
+    return hipSuccess;
+}
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int * d) { *d = 0; return hipSuccess; }
 inline const char * hipGetErrorString(hipError_t) { return "emu error"; }

@@ -479,3 +479,102 @@ def test_stream_driver_writes_and_reads_the_cli_format(emu, oracle, tmp_path):
     assert run(emu.bz3_hip_decode_stream, b"BZ3v2" + want[5:], 2)[0] == bzip3_amd.BZ3_ERR_MALFORMED_HEADER
     assert run(emu.bz3_hip_decode_stream, want[:9] + (2 ** 31 - 1).to_bytes(4, "little") + want[13:], 2)[0] == bzip3_amd.BZ3_ERR_MALFORMED_HEADER
     assert emu.bz3_hip_encode_stream(0, 1, 1000, 2) == bzip3_amd.BZ3_ERR_INIT
+
+
+def test_stream_driver_returns_on_a_write_error_mid_stream(emu, oracle, tmp_path):
+    """A write error in a later batch (the reader of a pipe goes away: EPIPE; ENOSPC / EFBIG behave the same) must end the
+    pipeline with BZ3_HIP_ERR_IO -- the coder used to wait for ever for a batch the reader no longer produced."""
+    import threading
+
+    bs = 65 * 1024
+    rng = np.random.default_rng(8)
+    unit = bytes(rng.integers(0, 256, size=733, dtype=np.uint8))
+    data = (unit * 1200)[: 9 * bs + 100]  # ten blocks, one block per batch: the failure hits batch 3 or later
+    want = _bz3_file(oracle, data, bs)
+    third = 9
+    for _ in range(3):
+        third += 8 + int.from_bytes(want[third : third + 4], "little")
+    for fn, src_bytes, args, keep in ((emu.bz3_hip_encode_stream, data, (bs, 1), third), (emu.bz3_hip_decode_stream, want, (1,), 3 * bs)):
+        src = tmp_path / "in.bin"
+        src.write_bytes(src_bytes)
+        rd, wr = os.pipe()
+        got = []
+
+        def drain():
+            n = 0
+            while n < keep:
+                b = os.read(rd, keep - n)
+                if not b:
+                    break
+                got.append(b)
+                n += len(b)
+            os.close(rd)  # every later write fails with EPIPE (Python ignores SIGPIPE)
+
+        t = threading.Thread(target=drain)
+        t.start()
+        fi = os.open(src, os.O_RDONLY)
+        res = {}
+        call = threading.Thread(target=lambda: res.setdefault("rc", fn(fi, wr, *args)))
+        call.start()
+        call.join(timeout=120)
+        assert not call.is_alive(), "stream driver hangs after a write error"
+        os.close(fi)
+        os.close(wr)
+        t.join()
+        assert res["rc"] == -100  # BZ3_HIP_ERR_IO
+        assert b"".join(got) == (want if fn is emu.bz3_hip_encode_stream else data)[:keep]  # what was committed before the failure is intact
+
+
+def test_device_groups_of_a_batch_run_concurrently(oracle):
+    """A batch whose states live on several GPUs (bz3_new round-robins over the visible devices) is split into one group per
+    GPU and the groups run at the same time, one host thread each (api.hip for_each_device_group; the reference forks a
+    thread per block, src/libbz3.c:845-856).  Two emulated devices (BZ3_EMU_DEVICES=2; their kernel launches take turns on the
+    one emulated GPU, the host sides overlap): same bytes as the oracle both ways, a failing block does not disturb the
+    others, and both groups were inside their group function at the same time."""
+    import subprocess
+
+    code = r'''
+import sys, ctypes as C
+sys.path[:0] = [%r, %r, %r]
+import bzip3_amd, datagen
+from build_emu import build
+from oracle_lib import Oracle
+lib = bzip3_amd._declare(C.CDLL(build()))
+o = Oracle()
+assert lib.bz3_hip_device_count() == 2
+bs = 65 * 1024
+t = datagen.shakespeare()
+n = 6
+blocks = [t[i * 3000 : i * 3000 + 2500 + 7 * i] for i in range(n - 1)] + [b"tiny"]
+states = (C.c_void_p * n)(*[lib.bz3_new(bs) for _ in range(n)])
+assert sorted(lib.bz3_hip_state_device(s) for s in states) == [0, 0, 0, 1, 1, 1]
+cap = lib.bz3_bound(bs) + 64
+bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+for b, d in zip(bufs, blocks):
+    C.memmove(b, d, len(d))
+ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+sizes[2] = bs + 1  # too much data for its state: that block fails (BZ3_ERR_DATA_TOO_BIG), the others are coded
+lib.bz3_hip_debug_peak_concurrent_groups(1)
+lib.bz3_encode_blocks(states, ptrs, sizes, n)
+assert lib.bz3_hip_debug_peak_concurrent_groups(1) == 2
+for i, d in enumerate(blocks):
+    if i == 2:
+        assert sizes[i] == -1 and lib.bz3_last_error(states[i]) == bzip3_amd.BZ3_ERR_DATA_TOO_BIG
+        continue
+    assert lib.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: sizes[i]]) == o.encode_block(d, bs)[2], i
+enc2 = o.encode_block(blocks[2], bs)[2]
+C.memmove(bufs[2], enc2, len(enc2))
+sizes[2] = len(enc2)
+bsz = (C.c_size_t * n)(*[cap] * n)
+orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+lib.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+assert lib.bz3_hip_debug_peak_concurrent_groups(1) == 2
+for i, d in enumerate(blocks):
+    assert lib.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: len(d)]) == d, i
+for s in states:
+    lib.bz3_free(s)
+print("ok")
+''' % (os.path.dirname(HERE), HERE, os.path.join(HERE, "emu"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BZ3_EMU_DEVICES="2"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-300:], r.stderr[-1200:])

@@ -290,26 +290,60 @@ def test_large_block_round_trip_properties(gpu_lib, oracle):
         print("timings(decode, ms):", st.timings(), "bwt:", st.bwt_stats())
 
 
-@pytest.mark.skipif(os.environ.get("BZ3_TEST_FULL_SIZE") not in ("1", "2"), reason="256 MiB block: minutes of GPU time; set BZ3_TEST_FULL_SIZE=1 (encode) or 2 (+decode)")
-def test_full_size_256mib_block(gpu_lib, oracle):
-    """BASELINE.json's block size: the block the GPU produces is byte-identical to the reference's (REAL reference when
-    oracle/_ref is there).  The decode direction at this size is covered by bench.py's round-trip check of every block."""
+def test_full_size_blocks_256mib_and_32mib(gpu_lib, oracle):
+    """BASELINE.json's block sizes in the default suite: one 256 MiB block (cfg3/cfg4) and one 32 MiB block (cfg2) go through
+    bz3_encode_blocks / bz3_decode_blocks as ONE batch (the serial CM launches of both overlap, so the test costs one
+    256 MiB block: ~4 minutes).  The coded bytes are compared BYTE FOR BYTE with the REAL reference's (oracle/_ref, encoded on
+    the host meanwhile), then decoded and compared with the plaintext.  BZ3_TEST_511=1 adds the 511 MiB maximum (cfg5's
+    block size: u32 index arithmetic of the suffix sorter at 48 n = 25.7 GB of workspace; ~9 more minutes)."""
+    import threading
+
     from oracle_lib import Bz3, RefLib
 
-    n = 256 << 20
-    d = datagen.text(n, seed=31, chains=65536)
-    with bzip3_amd.State(n, gpu_lib) as st:
-        m, err, blk = st.encode_block(d)
-        assert err == 0 and struct.unpack("<I", blk[:4])[0] == oracle.crc32c(d)
-        print("timings(encode, ms):", st.timings(), "bwt:", st.bwt_stats())
-        ref = RefLib()
-        if ref.available:
-            rm, rerr, rblk = Bz3(ref.lib).encode_block(d, n)
-            assert (m, err) == (rm, rerr) and hashlib.md5(blk).hexdigest() == hashlib.md5(rblk).hexdigest() and blk == rblk
-            print("256 MiB block: %d bytes, md5 %s, identical to the reference" % (m, hashlib.md5(blk).hexdigest()))
-        if os.environ.get("BZ3_TEST_FULL_SIZE") == "2":
-            k, err, back = st.decode_block(blk, n)
-            assert (k, err) == (n, 0) and back == d
+    sizes_mib = [256, 32] + ([511] if os.environ.get("BZ3_TEST_511") == "1" else [])
+    blocks = [datagen.text(m << 20, seed=31 + k, chains=65536) for k, m in enumerate(sizes_mib)]
+    ref = RefLib()
+    want = {}
+
+    def encode_on_host(k):
+        want[k] = Bz3(ref.lib).encode_block(blocks[k], len(blocks[k]))
+
+    threads = [threading.Thread(target=encode_on_host, args=(k,)) for k in range(len(blocks))] if ref.available else []
+    for t in threads:
+        t.start()
+    n = len(blocks)
+    states = (C.c_void_p * n)(*[gpu_lib.bz3_new(len(d)) for d in blocks])
+    assert all(states)
+    caps = [gpu_lib.bz3_bound(len(d)) + 64 for d in blocks]
+    bufs = [(C.c_uint8 * cap)() for cap in caps]
+    for b, d in zip(bufs, blocks):
+        C.memmove(b, d, len(d))
+    ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+    gpu_lib.bz3_encode_blocks(states, ptrs, sizes, n)
+    coded = []
+    for i, d in enumerate(blocks):
+        assert gpu_lib.bz3_last_error(states[i]) == 0 and 0 < sizes[i] < len(d) // 3, i
+        coded.append(C.string_at(bufs[i], sizes[i]))
+        assert struct.unpack("<I", coded[i][:4])[0] == oracle.crc32c(d)
+    for t in threads:
+        t.join()
+    for i in range(n if ref.available else 0):
+        m, err, blk = want[i]
+        assert (sizes[i], 0) == (m, err) and coded[i] == blk, "%d MiB block differs from the reference" % sizes_mib[i]
+        print("%d MiB block: %d bytes, md5 %s, byte-identical to the reference" % (sizes_mib[i], m, hashlib.md5(blk).hexdigest()))
+    bsz = (C.c_size_t * n)(*caps)
+    orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+    gpu_lib.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+    for i, d in enumerate(blocks):
+        assert gpu_lib.bz3_last_error(states[i]) == 0, i
+        assert C.string_at(bufs[i], len(d)) == d, "%d MiB block: decode differs from the plaintext" % sizes_mib[i]
+    tm = (C.c_float * 8)()
+    gpu_lib.bz3_hip_last_timings(states[0], tm)
+    print("timings(decode of the 256 MiB block, ms):", [round(x, 1) for x in tm[:6]])
+    for s in states:
+        gpu_lib.bz3_free(s)
+    gpu_lib.bz3_hip_release_cached_memory()
 
 
 # ---- opt-in machinery (row-cache kernels, lean states): after everything the default path needs ----------------------------------
@@ -437,7 +471,7 @@ def test_zz_three_blocks_per_cu_variants_on_gpu(gpu_lib, oracle, text):
     wide = bytes(rng.permutation(256)[:90].astype(np.uint8)[rng.choice(90, size=300000, p=p / p.sum())])
     inputs = {"text": oracle.bwt(text[3000000 : 3000000 + (1 << 20)])[1], "wide90": wide, "rand": datagen.random_bytes(150000, seed=4), "tiny": b"abracadabra"}
     try:
-        for mode in (2, 3):
+        for mode in (2, 3, 4):  # rows3, lock3, lock2
             assert gpu_lib.bz3_hip_set_cm_mode(mode) == 0
             for name, d in inputs.items():
                 c = oracle.cm_encode(d)
