@@ -48,6 +48,19 @@ struct DeviceCtx {
     char * ws = nullptr;
     size_t ws_cap = 0;
     int cus = 256;          // compute units: one full-model CM workgroup fits per CU
+    // second stream of the device: the serial LZP drivers of one window of blocks run there while the calling thread drives
+    // the whole-GPU stages of the neighbouring windows on the group's stream (encode_group)
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_d0[2] = {nullptr, nullptr}, ev_d1[2] = {nullptr, nullptr};
+    void ensure_aux() {  // caller holds mu
+        if (aux) return;
+        HIP_CHECK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreate(&ev_prep));
+        for (int k = 0; k < 2; k++) {
+            HIP_CHECK(hipEventCreate(&ev_d0[k]));
+            HIP_CHECK(hipEventCreate(&ev_d1[k]));
+        }
+    }
 
     // Swap buffers lent to "lean" states for the duration of a stage sequence (see bz3_hip_set_lean_states).
     std::mutex temp_mu;
@@ -170,11 +183,10 @@ size_t workspace_bytes_for(u64 n) {
 // data).  Measured on MI355X (profiles/r01_cm_rows_probe.txt; time of one launch relative to one block per CU):
 //   encode  two blocks per CU 1.30x, three 1.59x   (throughput x1.54 / x1.89)
 //   decode  two blocks per CU 2.07x, three 2.2x    (throughput x0.97 / x1.36)
-// Policy (BZ3_HIP_CM_MODE=auto|full|rows|rows3, bz3_hip_set_cm_mode): the row-cache kernels are OPT-IN for now.
-// Two of the nine round-1 probe runs that used them at 256-768 blocks stopped making progress (not reproduced when
-// repeated; parity tests and the other runs are clean), so `auto` stays with the full-model kernels until that is
-// understood; cm_variant_auto() below is the policy the measurements suggest and is what BZ3_HIP_CM_MODE=measured
-// selects.
+// Policy (BZ3_HIP_CM_MODE=auto|full|rows|rows3|lock2|lock3|measured, bz3_hip_set_cm_mode): `auto` picks by batch size, see
+// cm_variant_for().  (Round 1 kept the row-cache kernels opt-in because two probe runs had stalled; the cause -- a one-word
+// mailbox in the guess-ahead decoder that a delayed model wave could miss -- was found with the emulator's hostile
+// scheduler and fixed, and round 2 re-ran every variant at 256 / 512 / 768 blocks on the GPU.)
 constexpr int CM_MODE_MEASURED = 100;
 std::atomic<int> g_cm_mode{-2};  // -2 = not read from the environment yet, -1 = auto, else CM_VARIANT_*
 
@@ -209,12 +221,20 @@ bool lean_states() {
 
 int cm_variant_for(const DeviceCtx * ctx, size_t njobs, bool encode) {
     const int m = cm_mode();
-    if (m == CM_MODE_MEASURED) {  // row-cache encoder beyond one block per CU, row-cache decoder only where three share a CU
-        const size_t c = (size_t)ctx->cus;
+    const size_t c = (size_t)ctx->cus;
+    if (m == CM_MODE_MEASURED) {  // round-1 policy: row-cache encoder beyond one block per CU, guess-ahead row-cache decoder only where three share a CU
         if (njobs > 2 * c) return CM_VARIANT_ROWS3;
         return (encode && njobs > c) ? CM_VARIANT_ROWS : CM_VARIANT_FULL;
     }
-    return m >= 0 ? m : (int)CM_VARIANT_FULL;
+    if (m >= 0) return m;
+    // auto, by batch size (profiles/r02_cm_coresidency.txt, MI355X): up to one block per CU the full-model kernels have the
+    // lowest latency per block; beyond that the CM launch would need a second round of workgroups, and the row-cache kernels
+    // put two / three blocks on a CU instead -- the encoder's model waves interleave well (x1.5 / x2.0 throughput), and the
+    // lock-step decoder (barriers instead of polling) loses only 9 % / 16 % per block with one / two neighbours
+    // (x1.6 / x2.25 throughput; the guess-ahead decoder gains nothing at two per CU and x1.4 at three).
+    if (njobs > 2 * c) return CM_VARIANT_LOCK3;  // rows3 encoder + lock-step decoder, three blocks per CU
+    if (njobs > c) return CM_VARIANT_LOCK2;      // rows encoder + lock-step decoder, two blocks per CU
+    return CM_VARIANT_FULL;
 }
 
 size_t cm_scratch_bytes(size_t njobs) { return njobs * (CM_SPILL_BYTES + 256) + 4096; }
@@ -389,7 +409,7 @@ constexpr u32 CM_SIDE_BYTES = 64 * 1024;  // per block: where in-place CM output
 //   3. per block: header, copy back into the caller's buffer if the ping-pong ended there   (encode_finish)
 // ======================================================================================================
 // Phase 1a: CRC, mRLE, LZP preparation (hash links + static events).  c receives the LZP context.
-void encode_front_a(bz3_state * st, u8 * buf, s32 data_size, Arena & arena, LzpEncodeCtx & c) {
+void encode_front_a(bz3_state * st, u8 * buf, s32 data_size, Arena & arena, Arena & ctx_arena, LzpEncodeCtx & c) {
     st->pending = bz3_state::FAILED;
     st->result = -1;
     c.active = false;
@@ -437,7 +457,7 @@ void encode_front_a(bz3_state * st, u8 * buf, s32 data_size, Arena & arena, LzpE
     st->b2 = b2;
     st->n_cm = n;
     t0 = now_ms();
-    lzp_encode_prepare(b1, n, c, arena, s);  // :616 (first third)
+    lzp_encode_prepare(b1, n, c, ctx_arena, arena, s);  // :616 (first third)
     st->t[BZ3_HIP_T_LZP] = (float)(now_ms() - t0);
     st->pending = bz3_state::ENC_CODED;
 }
@@ -543,64 +563,89 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         const size_t w = workspace_bytes_for((u64)(sizes[i] > 0 ? sizes[i] : 0) + 64);
         if (w > need) need = w;
     }
-    // LZP drivers are serial single-workgroup kernels: blocks are prepared in windows and each window's
-    // drivers run as one launch (one workgroup per block).  The window contexts stay on the arena meanwhile.
+    // LZP drivers are serial single-workgroup kernels (~0.7 s for a 256 MiB text block, however many run side by side).
+    // The blocks go through the front end in WINDOWS, software-pipelined over two context slots: while the drivers of
+    // window k run on the device's second stream, this thread prepares window k+1 and finishes window k-1 (LZP emission,
+    // BWT, header) on the group's stream, so the drivers' latency hides behind whole-GPU work of other blocks.
     u64 n_max = 64;
     for (s32 i = 0; i < n; i++)
         if (sizes[i] > 0 && (u64)sizes[i] > n_max) n_max = (u64)sizes[i];
-    const size_t ctx_bytes = lzp_encode_ctx_bytes(n_max + 64);
-    // window = as many contexts as fit into half of the memory that is free right now (at most 64 blocks, 96 GB)
-    size_t budget = (size_t)40 << 30;
+    const size_t ctx_bytes = lzp_encode_ctx_bytes(n_max + 64) + 65536;
+    // window = what fits twice into a third of the memory that is free right now; 8 blocks per window are plenty to hide a driver
+    size_t budget = (size_t)16 << 30;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t have = lead->ctx->ws_cap;  // the arena already holds this much
-            budget = (free_b + have > need) ? (free_b + have - need) / 2 : 0;
-            if (budget > ((size_t)96 << 30)) budget = (size_t)96 << 30;
+            budget = (free_b + have > need) ? (free_b + have - need) / 3 : 0;
         }
     }
-    s32 window = (s32)(budget / (ctx_bytes + 65536));
-    if (window < 1) window = 1;
-    if (window > 64) window = 64;
+    s32 window = (s32)(budget / (2 * ctx_bytes));
+    if (window > 8) window = 8;
     if (window > n) window = n;
-    Arena arena = lead->ctx->arena_for(need + (size_t)window * (ctx_bytes + 65536) + (size_t)n * (sizeof(CmEncodeJob) + CM_SIDE_BYTES + 256) +
+    if (window < 1) window = 1;
+    lead->ctx->ensure_aux();
+    hipStream_t s = lead->stream, s2 = lead->ctx->aux;
+    Arena arena = lead->ctx->arena_for(need + 2 * (size_t)window * (ctx_bytes + sizeof(LzpDriverJob) + 256) + (size_t)n * (sizeof(CmEncodeJob) + CM_SIDE_BYTES + 256) +
                                        cm_scratch_bytes((size_t)n) + 65536);
     CmEncodeJob * d_jobs = arena.take<CmEncodeJob>((size_t)n);
     u8 * sides = arena.take<u8>((size_t)n * CM_SIDE_BYTES);  // lean states only
+    struct Window {
+        s32 w0 = 0, w1 = 0;
+        Arena slot;                        // the LZP contexts of the window's blocks
+        LzpDriverJob * d_lz = nullptr;
+        std::vector<LzpEncodeCtx> ctxs;
+        std::vector<LzpDriverJob> lz;      // host copy: stays alive until the window is finished
+    } win[2];
+    for (int k = 0; k < 2; k++) {
+        win[k].slot.base = arena.take<char>((size_t)window * ctx_bytes);
+        win[k].slot.cap = (size_t)window * ctx_bytes;
+        win[k].d_lz = arena.take<LzpDriverJob>((size_t)window);
+    }
     std::vector<CmEncodeJob> jobs;
-    for (s32 w0 = 0; w0 < n; w0 += window) {
-        const s32 w1 = (w0 + window < n) ? w0 + window : n;
-        const size_t mk = arena.mark();
-        std::vector<LzpEncodeCtx> ctxs((size_t)(w1 - w0));
-        std::vector<LzpDriverJob> lz;
-        for (s32 i = w0; i < w1; i++) {
-            encode_front_a(sts[i], bufs[i], sizes[i], arena, ctxs[(size_t)(i - w0)]);
-            if (sts[i]->pending == bz3_state::ENC_CODED && ctxs[(size_t)(i - w0)].active) lz.push_back(lzp_driver_job(ctxs[(size_t)(i - w0)]));
-        }
-        float driver_ms = 0.f;
-        if (!lz.empty()) {
-            HIP_CHECK(hipStreamSynchronize(lead->stream));  // the prepares above are in flight on the group's stream
-            const double t0 = now_ms();
-            LzpDriverJob * d_lz = arena.take<LzpDriverJob>(lz.size());
-            lzp_driver_batch(lz.data(), d_lz, (u32)lz.size(), lead->stream);
-            HIP_CHECK(hipStreamSynchronize(lead->stream));
-            driver_ms = (float)(now_ms() - t0);
-        }
-        for (s32 i = w0; i < w1; i++) {
-            encode_front_b(sts[i], arena, ctxs[(size_t)(i - w0)], driver_ms);
-            if (sts[i]->pending == bz3_state::ENC_CODED) {
-                CmEncodeJob j{dev_addr(sts[i]->b2), dev_addr(sts[i]->b1 + sts[i]->overhead * 4 + 1), dev_addr(sts[i]->d_words + 2), sts[i]->n_cm, 0u};  // :634-638
-                if (sts[i]->lean) {  // in place: input at the end of the caller's buffer, output behind the header
-                    sts[i]->side = sides + (size_t)i * CM_SIDE_BYTES;
-                    j.gap = (u32)(sts[i]->b2 - (sts[i]->b1 + sts[i]->overhead * 4 + 1));
-                    j.side = dev_addr(sts[i]->side);
-                    j.side_cap = CM_SIDE_BYTES;
-                }
-                jobs.push_back(j);
+    const s32 nwin = (n + window - 1) / window;
+    for (s32 k = 0; k <= nwin; k++) {
+        if (k < nwin) {  // prepare window k, then start its drivers on the second stream
+            Window & w = win[k & 1];
+            w.w0 = k * window;
+            w.w1 = (w.w0 + window < n) ? w.w0 + window : n;
+            w.slot.used = 0;  // its previous tenant (window k-2) was finished one iteration ago, on this stream
+            w.ctxs.assign((size_t)(w.w1 - w.w0), LzpEncodeCtx());
+            w.lz.clear();
+            for (s32 i = w.w0; i < w.w1; i++) {
+                encode_front_a(sts[i], bufs[i], sizes[i], arena, w.slot, w.ctxs[(size_t)(i - w.w0)]);
+                if (sts[i]->pending == bz3_state::ENC_CODED && w.ctxs[(size_t)(i - w.w0)].active) w.lz.push_back(lzp_driver_job(w.ctxs[(size_t)(i - w.w0)]));
             }
-            lean_return(sts[i]);  // blocks that left the pipeline early (stored, failed) still hold their swap buffer
+            if (!w.lz.empty()) {
+                HIP_CHECK(hipEventRecord(lead->ctx->ev_prep, s));  // the prepares above are in flight on the group's stream
+                HIP_CHECK(hipStreamWaitEvent(s2, lead->ctx->ev_prep, 0));
+                HIP_CHECK(hipEventRecord(lead->ctx->ev_d0[k & 1], s2));
+                lzp_driver_batch(w.lz.data(), w.d_lz, (u32)w.lz.size(), s2);
+                HIP_CHECK(hipEventRecord(lead->ctx->ev_d1[k & 1], s2));
+            }
         }
-        arena.release(mk);
+        if (k >= 1) {  // finish window k-1: its drivers have had the preparation of window k to themselves
+            Window & w = win[(k - 1) & 1];
+            float driver_ms = 0.f;
+            if (!w.lz.empty()) {
+                HIP_CHECK(hipEventSynchronize(lead->ctx->ev_d1[(k - 1) & 1]));
+                (void)hipEventElapsedTime(&driver_ms, lead->ctx->ev_d0[(k - 1) & 1], lead->ctx->ev_d1[(k - 1) & 1]);
+            }
+            for (s32 i = w.w0; i < w.w1; i++) {
+                encode_front_b(sts[i], arena, w.ctxs[(size_t)(i - w.w0)], driver_ms);
+                if (sts[i]->pending == bz3_state::ENC_CODED) {
+                    CmEncodeJob j{dev_addr(sts[i]->b2), dev_addr(sts[i]->b1 + sts[i]->overhead * 4 + 1), dev_addr(sts[i]->d_words + 2), sts[i]->n_cm, 0u};  // :634-638
+                    if (sts[i]->lean) {  // in place: input at the end of the caller's buffer, output behind the header
+                        sts[i]->side = sides + (size_t)i * CM_SIDE_BYTES;
+                        j.gap = (u32)(sts[i]->b2 - (sts[i]->b1 + sts[i]->overhead * 4 + 1));
+                        j.side = dev_addr(sts[i]->side);
+                        j.side_cap = CM_SIDE_BYTES;
+                    }
+                    jobs.push_back(j);
+                }
+                lean_return(sts[i]);  // blocks that left the pipeline early (stored, failed) still hold their swap buffer
+            }
+        }
     }
     const float cm_ms = run_cm_jobs(lead->ctx, arena, jobs, d_jobs, lead->stream, lead->ev0, lead->ev1,
                                     [](const CmEncodeJob * j, u32 nj, hipStream_t st, int variant) { cm_encode_batch(j, nj, st, variant); });
@@ -1357,6 +1402,11 @@ BZIP3_API int bz3_hip_set_cm_mode(int mode) {
 }
 
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void) { return g_cm_given_up.load(); }
+
+BZIP3_API int bz3_hip_cm_variant_for(int device, int blocks, int encode) {
+    DeviceCtx * c = get_ctx(device);
+    return (c && blocks > 0) ? cm_variant_for(c, (size_t)blocks, encode != 0) : -1;
+}
 
 BZIP3_API int bz3_hip_debug_peak_concurrent_groups(int reset) {
     const int v = g_groups_peak.load();

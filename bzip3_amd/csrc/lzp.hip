@@ -366,9 +366,12 @@ __global__ void __launch_bounds__(LZ_BLOCK) k_lzp_emit(const u8 * __restrict__ i
 
 size_t lzp_encode_ctx_bytes(u64 n) { return n * 8 + (n / 32 + 8) * 12 + (n / LZ_MIN + 8) * 8 + 4096; }
 
-// Phase A (asynchronous): hash links + static event bitmap.  Allocations stay on the arena until the caller
-// releases its mark, so several blocks can be prepared before their drivers run as one batch.
-void lzp_encode_prepare(const u8 * d_in, u32 n, LzpEncodeCtx & c, Arena & tmp, hipStream_t s) {
+// Phase A (asynchronous): hash links + static event bitmap.  The context (what the driver and the emission need) is
+// carved from `ctx` and stays there until the caller recycles it, so several blocks can be prepared before their drivers
+// run as one batch; the sort buffers are transient and come from `tmp` (the two may be the same arena).
+void lzp_encode_prepare(const u8 * d_in, u32 n, LzpEncodeCtx & c, Arena & tmp, hipStream_t s) { lzp_encode_prepare(d_in, n, c, tmp, tmp, s); }
+
+void lzp_encode_prepare(const u8 * d_in, u32 n, LzpEncodeCtx & c, Arena & ctx, Arena & tmp, hipStream_t s) {
     c.active = false;
     c.in = d_in;
     c.n = n;
@@ -376,14 +379,14 @@ void lzp_encode_prepare(const u8 * d_in, u32 n, LzpEncodeCtx & c, Arena & tmp, h
     c.active = true;
     const u32 m = n - 4;
     c.nwords = (n + 31) / 32 + 2;
-    c.prev = tmp.take<u32>(n);
-    c.next = tmp.take<u32>(n);
-    c.skip = tmp.take<u32>(c.nwords);
-    c.mstart = tmp.take<u32>(c.nwords);
-    c.cand_bits = tmp.take<u32>(c.nwords);
-    c.mpos = tmp.take<u32>(n / LZ_MIN + 2);
-    c.mlen = tmp.take<u32>(n / LZ_MIN + 2);
-    c.d_res = reinterpret_cast<LzDriverOut *>(tmp.take<u32>(8));
+    c.prev = ctx.take<u32>(n);
+    c.next = ctx.take<u32>(n);
+    c.skip = ctx.take<u32>(c.nwords);
+    c.mstart = ctx.take<u32>(c.nwords);
+    c.cand_bits = ctx.take<u32>(c.nwords);
+    c.mpos = ctx.take<u32>(n / LZ_MIN + 2);
+    c.mlen = ctx.take<u32>(n / LZ_MIN + 2);
+    c.d_res = reinterpret_cast<LzDriverOut *>(ctx.take<u32>(8));
     {
         const size_t mk2 = tmp.mark();
         u32 * k0 = tmp.take<u32>(m);

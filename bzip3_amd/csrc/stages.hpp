@@ -58,6 +58,7 @@ struct LzpDriverJob {  // device addresses as integers: see prims.hpp global_ptr
 };
 size_t lzp_encode_ctx_bytes(u64 n);
 void lzp_encode_prepare(const u8 * d_in, u32 n, LzpEncodeCtx & c, Arena & tmp, hipStream_t s);
+void lzp_encode_prepare(const u8 * d_in, u32 n, LzpEncodeCtx & c, Arena & ctx, Arena & tmp, hipStream_t s);  // context and transient scratch from different arenas
 LzpDriverJob lzp_driver_job(const LzpEncodeCtx & c);
 void lzp_driver_batch(const LzpDriverJob * h_jobs, LzpDriverJob * d_jobs, u32 njobs, hipStream_t s);
 s32 lzp_encode_finish(const LzpEncodeCtx & c, u8 * d_out, Arena & tmp, hipStream_t s);  // encoded size or -1

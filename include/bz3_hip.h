@@ -33,14 +33,19 @@ BZIP3_API int bz3_hip_state_device(struct bz3_state * state);
 /* CM kernel variant (process-wide).  0 = the whole 145.5 KiB model in LDS, one block per CU; 1 / 2 = row-cache
  * kernels (the order-1 rows a block uses are cached in LDS -- 96 or 44/56 of them --, the others spill to HBM:
  * two / three blocks per CU; a block whose working set does not fit is handed back to variant 0 automatically);
- * 3 / 4 = as 2 / 1 with the lock-step decoder (far less VALU work per byte, for CUs shared by several blocks; not measured yet);
+ * 3 / 4 = as 2 / 1 with the lock-step decoder (barriers instead of polling: loses little when several blocks share a CU);
  * 100 = by batch size as measured (row-cache encoder beyond one block per CU, row-cache decoder beyond two);
- * -1 = automatic (default): currently variant 0 -- the row-cache kernels are opt-in (bzip3_amd/csrc/api.hip).
+ * -1 = automatic (default), by batch size: up to one block per CU variant 0, up to two per CU variant 4, beyond that variant 3
+ *      (measured on MI355X: profiles/r02_cm_coresidency.txt).
  * Environment BZ3_HIP_CM_MODE=auto|full|rows|rows3|lock3|lock2|measured has the same effect.  Output bytes do not depend on
  * the variant.  Returns 0, or -1 for an invalid mode. */
 BZIP3_API int bz3_hip_set_cm_mode(int mode);
 /* Number of blocks the row-cache kernels have handed back to the full-model kernels so far (statistics). */
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void);
+
+/* The CM kernel variant (0..4 as above) a batch of `blocks` blocks on `device` is coded (encode != 0) or decoded with under the
+ * current mode; -1 for an invalid device. */
+BZIP3_API int bz3_hip_cm_variant_for(int device, int blocks, int encode);
 
 /* Test hook: the largest number of per-GPU groups of one batch call that have been running at the same time since the
  * last reset (a batch whose states live on G GPUs runs G groups concurrently, one host thread per GPU). */
