@@ -200,6 +200,9 @@ int cm_mode() {
         else if (e && !strcmp(e, "rows3")) m = CM_VARIANT_ROWS3;
         else if (e && !strcmp(e, "lock3")) m = CM_VARIANT_LOCK3;
         else if (e && !strcmp(e, "lock2")) m = CM_VARIANT_LOCK2;
+        else if (e && !strcmp(e, "sync")) m = CM_VARIANT_SYNC;
+        else if (e && !strcmp(e, "sync2")) m = CM_VARIANT_SYNC2;
+        else if (e && !strcmp(e, "sync3")) m = CM_VARIANT_SYNC3;
         else if (e && !strcmp(e, "measured")) m = CM_MODE_MEASURED;
 #ifdef BZ3_EMU
         else if (e && !strcmp(e, "rows-test")) m = CM_VARIANT_ROWS_TEST;
@@ -848,8 +851,10 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
         if (bytes > max_round) max_round = bytes;
         k = e;
     }
-    // tail windows: all blocks at once when every state owns its swap buffer, else as many as borrow one at a time
-    const s32 tail_window = any_lean ? 32 : n;
+    // tail windows of 32 blocks, software-pipelined like the encoder's front end: the serial LZP decoders of window k (one
+    // workgroup per block, ~0.8 s for a 256 MiB text block) run on the device's second stream while this thread drives the
+    // inverse BWTs of window k+1 on the group's stream; lean states hold a borrowed swap buffer for two windows at most
+    const s32 tail_window = n < 32 ? n : 32;
     size_t lzp_in_window = 0;
     for (s32 w0 = 0; w0 < n; w0 += tail_window) {
         size_t c = 0;
@@ -857,7 +862,7 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
             if (sts[i]->pending == bz3_state::DEC_CODED && (sts[i]->model & 2)) c++;
         if (c > lzp_in_window) lzp_in_window = c;
     }
-    Arena arena = lead->ctx->arena_for(need + lzp_in_window * (LZP_LUT_WORDS * 4 + 256) + (size_t)n * 256 + cm_scratch_bytes(coded.size()) + max_round + 65536);
+    Arena arena = lead->ctx->arena_for(need + 2 * lzp_in_window * (LZP_LUT_WORDS * 4 + sizeof(LzpDecodeJob) + 256) + (size_t)n * 256 + cm_scratch_bytes(coded.size()) + max_round + 65536);
     // ---- phase 2: the CM launches (one workgroup per block) ------------------------------------------------------
     float cm_ms = 0.f;
     for (size_t r = 0, k0 = 0; r < round_end.size(); k0 = round_end[r++]) {
@@ -879,74 +884,95 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
         arena.release(mk);
     }
     // ---- phases 3-5 per tail window: inverse BWT per block, ONE LZP-decode launch (one workgroup per block), mRLE + CRC ----
-    for (s32 w0 = 0; w0 < n; w0 += tail_window) {
-        const s32 w1 = (w0 + tail_window < n) ? w0 + tail_window : n;
-        const size_t mk = arena.mark();
-        size_t n_lzp = 0;
-        for (s32 i = w0; i < w1; i++)
-            if (sts[i]->pending == bz3_state::DEC_CODED && (sts[i]->model & 2)) n_lzp++;
-        std::vector<LzpDecodeJob> lz_jobs;
+    struct TailWindow {
+        s32 w0 = 0, w1 = 0;
+        std::vector<LzpDecodeJob> lz_jobs;  // host copies: alive until the window is finished
         std::vector<s32> lz_owner;
-        LzpDecodeJob * d_lz = n_lzp ? arena.take<LzpDecodeJob>(n_lzp) : nullptr;
-        u32 * luts = n_lzp ? arena.take<u32>(n_lzp * LZP_LUT_WORDS) : nullptr;
-        std::vector<char> alive((size_t)(w1 - w0), 0);
-        for (s32 i = w0; i < w1; i++) {
-            bz3_state * st = sts[i];
-            if (st->pending == bz3_state::DEC_STORED) {  // :686-691
-                HIP_CHECK(hipStreamSynchronize(st->xs));
-                if (read_word(st->xs, st->d_words + 1) != st->crc) st->last_error = BZ3_ERR_CRC;
-                else st->result = st->size;  // last_error untouched (:691)
-                continue;
-            }
-            if (st->pending != bz3_state::DEC_CODED) continue;
-            lean_borrow(st);
-            if (!decode_unbwt(st, arena, cm_ms)) continue;
-            alive[(size_t)(i - w0)] = 1;
-            if (st->model & 2) {
-                if (st->lzp_size < 4) {  // lzp_decompress: `if (n < 4) return -1` (:252) -> BZ3_ERR_CRC (:769-771)
-                    st->last_error = BZ3_ERR_CRC;
-                    alive[(size_t)(i - w0)] = 0;
+        std::vector<char> alive;
+        LzpDecodeJob * d_lz = nullptr;
+        u32 * luts = nullptr;
+    } tw[2];
+    for (int k = 0; k < 2; k++) {
+        tw[k].d_lz = lzp_in_window ? arena.take<LzpDecodeJob>(lzp_in_window) : nullptr;
+        tw[k].luts = lzp_in_window ? arena.take<u32>(lzp_in_window * LZP_LUT_WORDS) : nullptr;
+    }
+    lead->ctx->ensure_aux();
+    hipStream_t s2 = lead->ctx->aux;
+    const s32 nwin = (n + tail_window - 1) / tail_window;
+    for (s32 k = 0; k <= nwin; k++) {
+        if (k < nwin) {  // window k: inverse BWTs on the group's stream, then its LZP decoders on the second stream
+            TailWindow & w = tw[k & 1];
+            w.w0 = k * tail_window;
+            w.w1 = (w.w0 + tail_window < n) ? w.w0 + tail_window : n;
+            w.lz_jobs.clear();
+            w.lz_owner.clear();
+            w.alive.assign((size_t)(w.w1 - w.w0), 0);
+            for (s32 i = w.w0; i < w.w1; i++) {
+                bz3_state * st = sts[i];
+                if (st->pending == bz3_state::DEC_STORED) {  // :686-691
+                    HIP_CHECK(hipStreamSynchronize(st->xs));
+                    if (read_word(st->xs, st->d_words + 1) != st->crc) st->last_error = BZ3_ERR_CRC;
+                    else st->result = st->size;  // last_error untouched (:691)
                     continue;
                 }
-                // The reference decodes into its swap buffer (bz3_bound(block_size) bytes) and compares with buffer_size
-                // afterwards (:767-781).  A lean state decodes into the caller's buffer, so the cap is the smaller of the two;
-                // decode_finish tells the two failures apart.
-                const size_t bound = bz3_bound((size_t)st->block_size);
-                const size_t room = st->lean && st->buffer_size < bound ? st->buffer_size : bound;
-                lz_jobs.push_back(LzpDecodeJob{dev_addr(st->b1), dev_addr(st->b2), dev_addr(luts + lz_jobs.size() * LZP_LUT_WORDS), dev_addr(st->d_words + 5),
-                                               (u32)st->lzp_size, (u32)room});
-                lz_owner.push_back(i);
+                if (st->pending != bz3_state::DEC_CODED) continue;
+                lean_borrow(st);
+                if (!decode_unbwt(st, arena, cm_ms)) continue;
+                w.alive[(size_t)(i - w.w0)] = 1;
+                if (st->model & 2) {
+                    if (st->lzp_size < 4) {  // lzp_decompress: `if (n < 4) return -1` (:252) -> BZ3_ERR_CRC (:769-771)
+                        st->last_error = BZ3_ERR_CRC;
+                        w.alive[(size_t)(i - w.w0)] = 0;
+                        continue;
+                    }
+                    // The reference decodes into its swap buffer (bz3_bound(block_size) bytes) and compares with buffer_size
+                    // afterwards (:767-781).  A lean state decodes into the caller's buffer, so the cap is the smaller of the two;
+                    // decode_finish tells the two failures apart.
+                    const size_t bound = bz3_bound((size_t)st->block_size);
+                    const size_t room = st->lean && st->buffer_size < bound ? st->buffer_size : bound;
+                    w.lz_jobs.push_back(LzpDecodeJob{dev_addr(st->b1), dev_addr(st->b2), dev_addr(w.luts + w.lz_jobs.size() * LZP_LUT_WORDS), dev_addr(st->d_words + 5),
+                                                     (u32)st->lzp_size, (u32)room});
+                    w.lz_owner.push_back(i);
+                }
+            }
+            if (!w.lz_jobs.empty()) {
+                HIP_CHECK(hipEventRecord(lead->ctx->ev_prep, s));  // the inverse BWTs above are in flight on the group's stream
+                HIP_CHECK(hipStreamWaitEvent(s2, lead->ctx->ev_prep, 0));
+                HIP_CHECK(hipEventRecord(lead->ctx->ev_d0[k & 1], s2));
+                lzp_decode_batch(w.lz_jobs.data(), w.d_lz, (u32)w.lz_jobs.size(), s2);
+                HIP_CHECK(hipEventRecord(lead->ctx->ev_d1[k & 1], s2));
             }
         }
-        if (!lz_jobs.empty()) {
-            const double t0 = now_ms();
-            lzp_decode_batch(lz_jobs.data(), d_lz, (u32)lz_jobs.size(), s);
-            HIP_CHECK(hipStreamSynchronize(s));
-            const float ms = (float)(now_ms() - t0);
-            for (s32 i : lz_owner) sts[i]->t[BZ3_HIP_T_LZP] = ms;
-            // lean state whose buffer is smaller than the reference's swap buffer: the decoder stops at the cap (:211) and
-            // returns it, where the reference would have gone on to bz3_bound(block_size) and then either reported a larger
-            // size (-> BZ3_ERR_DATA_SIZE_TOO_SMALL, :776) or run into malformed input (-> BZ3_ERR_CRC): when the cap was
-            // reached, decode once more into a borrowed buffer of the reference's size and keep that verdict
-            for (size_t k = 0; k < lz_jobs.size(); k++) {
-                bz3_state * st = sts[lz_owner[k]];
-                const size_t bound = bz3_bound((size_t)st->block_size);
-                if (!st->lean || st->buffer_size >= bound || read_word(s, st->d_words + 5) != lz_jobs[k].max_out) continue;
-                u8 * big = st->ctx->temp_get(st->cap);
-                LzpDecodeJob again = lz_jobs[k];
-                again.out = dev_addr(big);
-                again.max_out = (u32)bound;
-                again.lut = dev_addr(luts);
-                lzp_decode_batch(&again, d_lz, 1u, s);
-                HIP_CHECK(hipStreamSynchronize(s));
-                st->ctx->temp_put(big);
+        if (k >= 1) {  // finish window k-1: its LZP decoders have had the inverse BWTs of window k to themselves
+            TailWindow & w = tw[(k - 1) & 1];
+            if (!w.lz_jobs.empty()) {
+                HIP_CHECK(hipEventSynchronize(lead->ctx->ev_d1[(k - 1) & 1]));
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, lead->ctx->ev_d0[(k - 1) & 1], lead->ctx->ev_d1[(k - 1) & 1]);
+                for (s32 i : w.lz_owner) sts[i]->t[BZ3_HIP_T_LZP] = ms;
+                // lean state whose buffer is smaller than the reference's swap buffer: the decoder stops at the cap (:211) and
+                // returns it, where the reference would have gone on to bz3_bound(block_size) and then either reported a larger
+                // size (-> BZ3_ERR_DATA_SIZE_TOO_SMALL, :776) or run into malformed input (-> BZ3_ERR_CRC): when the cap was
+                // reached, decode once more into a borrowed buffer of the reference's size and keep that verdict
+                for (size_t j = 0; j < w.lz_jobs.size(); j++) {
+                    bz3_state * st = sts[w.lz_owner[j]];
+                    const size_t bound = bz3_bound((size_t)st->block_size);
+                    if (!st->lean || st->buffer_size >= bound || read_word(s, st->d_words + 5) != w.lz_jobs[j].max_out) continue;
+                    u8 * big = st->ctx->temp_get(st->cap);
+                    LzpDecodeJob again = w.lz_jobs[j];
+                    again.out = dev_addr(big);
+                    again.max_out = (u32)bound;
+                    again.lut = dev_addr(w.luts);
+                    lzp_decode_batch(&again, w.d_lz, 1u, s);
+                    HIP_CHECK(hipStreamSynchronize(s));
+                    st->ctx->temp_put(big);
+                }
+            }
+            for (s32 i = w.w0; i < w.w1; i++) {
+                if (w.alive[(size_t)(i - w.w0)]) decode_finish(sts[i], arena);
+                lean_return(sts[i]);
             }
         }
-        for (s32 i = w0; i < w1; i++) {
-            if (alive[(size_t)(i - w0)]) decode_finish(sts[i], arena);
-            lean_return(sts[i]);
-        }
-        arena.release(mk);
     }
     for (s32 i = 0; i < n; i++) sts[i]->pending = bz3_state::NONE;
 }
@@ -1392,9 +1418,9 @@ BZIP3_API int bz3_hip_bind_device(int device) {
 BZIP3_API int bz3_hip_state_device(struct bz3_state * st) { return st->device; }
 
 BZIP3_API int bz3_hip_set_cm_mode(int mode) {
-    bool ok = (mode >= -1 && mode <= CM_VARIANT_LOCK2) || mode == CM_MODE_MEASURED;
+    bool ok = (mode >= -1 && mode <= CM_VARIANT_SYNC3) || mode == CM_MODE_MEASURED;
 #ifdef BZ3_EMU
-    ok = ok || mode == CM_VARIANT_ROWS_TEST || mode == CM_VARIANT_LOCK_TEST;
+    ok = ok || mode == CM_VARIANT_ROWS_TEST || mode == CM_VARIANT_LOCK_TEST || mode == CM_VARIANT_SYNC_TEST;
 #endif
     if (!ok) return -1;
     g_cm_mode.store(mode);

@@ -1174,6 +1174,229 @@ __device__ __forceinline__ void cm_decode_block_lockstep(const CmDecodeJob * __r
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// decode, barrier-synchronised guess-ahead ("sync"): five waves like cm_decode_block -- wave 0 walks, waves 1..4 hold one
+// tree node per lane and evaluate the table of byte i+1 on the guess "byte i repeats byte i-1" WHILE the walker decodes
+// byte i -- but the hand-offs are workgroup barriers instead of LDS mailboxes that both sides poll:
+//     walker : decode byte i from table i, store it in s_done            | models : (speculative) table i+1
+//                                         ---------------- barrier 1 ----------------
+//     right guess: walker fetches table i+1 and goes on                  | models go on with table i+2
+//     wrong guess: walker waits at barrier 2                             | models undo, apply the real update, evaluate
+//                                         ---------------- barrier 2 ----------------  table i+1 again
+// A wave that waits in s_barrier issues nothing, so workgroups that share a CU do not pay for each other's waiting (the
+// polling decoder loses a factor 2 with two neighbours on the CU, profiles/r02_cm_coresidency.txt), there is no mailbox
+// to miss (cf. the deadlock the polling protocol had), and every wave takes the same, data-determined number of barriers
+// per byte: after barrier 1 all of them know byte i and the guess.  Everything that crosses a barrier alternates between two
+// buffers, because the waves only meet AT the barriers: table i+2 is written into the buffer of table i, which the walker has
+// read into registers before barrier 1 of byte i; byte i+1 is stored in the other word than byte i, which a model wave may read
+// arbitrarily late after barrier 1 (found by the emulator's stalled-wave scheduling).
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restrict__ jobs) {
+    const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
+    const u32 in_size = jobs[blockIdx.x].in_size;
+    u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
+    const u32 n = jobs[blockIdx.x].n;
+    const u32 debug = jobs[blockIdx.x].debug & 15u;  // 3: cycle counters instead of the first output bytes (profiling only)
+    __shared__ CmLdsT<R> m;
+    __shared__ u32 ptab[2][256];  // (18-bit probability of node) << 14
+    __shared__ u32 s_done[2];     // [i & 1] = byte i, written by the walker before barrier 1 of byte i.  Two words: after a right guess the
+                                  // walker decodes byte i+1 and stores it while a model wave that was held up may not have read byte i yet
+    __shared__ u32 s_abort;       // R > 0: the model waves gave the block up
+    __shared__ CmRowCache<R> rcs[R ? 4 : 1];  // R > 0: one private directory per model wave
+    if (threadIdx.x < 2) s_done[threadIdx.x] = 0;
+    if (threadIdx.x == 5) s_abort = 0;
+    cm_model_init(m);
+    if (n == 0) return;
+    const int lane = lane_id();
+    const u32 role = cm_uniform((u32)wave_id());
+    if (role != 0) {
+        // ---- model waves ------------------------------------------------------------------------------------
+        const u32 node = threadIdx.x - 64u;
+        const u32 lvl = node ? (u32)(31 - __clz((int)node)) : 0u;
+        const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
+        u32 c0 = 32768u;  // the node's C0 counter lives in a register
+        // byte 0: nothing to guess (c1 = c2 = 0, run = 1, :367-372)
+        CmEval prev = cm_evaluate(m, ptab[0], node, c0, node, m.c1[node], m.c1[node], 0u);
+        u32 k1 = 0;        // newest confirmed byte (byte i-2 inside the loop; the initial c1 = 0 before the block starts)
+        u32 run_prev = 1;  // run counter the evaluation of byte i-1 was made with
+        CmRowCache<R> & rc = rcs[R ? role - 1 : 0];
+        CmRowState rs;
+        u16 * __restrict__ spill = global_ptr<u16>(jobs[blockIdx.x].spill);
+        const u32 miss_base = jobs[blockIdx.x].miss_base, miss_shift = jobs[blockIdx.x].miss_shift;
+        if (R) cm_rows_init<R>(rc);
+        __syncthreads();  // barrier 0: table 0 is there
+        for (u32 i = 1; i < n; i++) {
+            u32 * __restrict__ pt = ptab[i & 1u];
+            // -- speculate: byte i-1 == k1.  Update of byte i-1 (:396-399, :411-414; branch-free, see cm_upd) ...
+            const u32 g = k1;
+            const bool on_g = (hibit | (g >> shr)) == node;
+            const u32 c0_old = c0;
+            u32 cell = prev.p1;  // C1[k1][node]: byte i-1 was evaluated with c1 = k1, so this is the cell its update moves
+            if (on_g) {
+                const u32 mk = 0u - ((g >> bitpos) & 1u);
+                c0 = cm_upd(c0, 2, mk & 16383u);
+                cell = cm_upd(prev.p1, 4, mk & 4095u);
+                m.c1[prev.a1] = (u16)cell;
+                reinterpret_cast<PackedU32 *>(&m.c2[prev.ci])->v = cm_upd_pair6(prev.w, mk & 0x03FF03FFu);
+            }
+            // ... and the table of byte i with c1 = g, c2 = k1: both order-1 counters are `cell`, the run counter goes up
+            CmEval cur = cm_evaluate(m, pt, node, c0, prev.a1, cell, cell, run_prev + 1u > 2u ? 1u : 0u);
+            __syncthreads();  // barrier 1: the walker has decoded byte i-1
+            const u32 c = cm_uniform(LDS_PEEK(s_done[(i - 1u) & 1u])) & 0xFFu;
+            if (c != g) {
+                // wrong guess: put the old counters back (the old values are still in `prev`), apply the real update
+                // and evaluate again.  The new c1 row differs from the row being repaired, so its read goes first.
+                u32 row = c;
+                bool give_up = false;
+                if (R) {
+                    row = cm_uniform((u32)rc.row_of[c]);
+                    if (__builtin_expect(row >= CM_ROW_SPILLED, 0)) {
+                        // the only row still needed is the one of byte i-2 (prev.a1 points into it): pin it
+                        rs.tick++;
+                        if (lane == 0) rc.stamp[cm_uniform(prev.a1 >> 8)] = rs.tick;
+                        wave_sync();
+                        row = cm_rows_fetch<R, 1>(m, rc, rs, spill, c, row, node);
+                        give_up = rs.misses > miss_base + (i >> miss_shift);  // the working set does not fit (every model wave gets here at the same byte)
+                    }
+                }
+                if (__builtin_expect(give_up, 0)) {
+                    if (threadIdx.x == 64) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
+                    LDS_POKE(s_abort, 1u);
+                    __syncthreads();  // barrier 2: the walker reads s_abort behind it
+                    return;
+                }
+                const u32 a1 = row * 256u + node;
+                const u32 p1 = m.c1[a1];
+                u32 cell2 = prev.p1;
+                if (on_g) {
+                    c0 = c0_old;
+                    reinterpret_cast<PackedU32 *>(&m.c2[prev.ci])->v = prev.w;
+                }
+                if ((hibit | (c >> shr)) == node) {
+                    const u32 mk = 0u - ((c >> bitpos) & 1u);
+                    c0 = cm_upd(c0, 2, mk & 16383u);
+                    cell2 = cm_upd(prev.p1, 4, mk & 4095u);
+                    reinterpret_cast<PackedU32 *>(&m.c2[prev.ci])->v = cm_upd_pair6(prev.w, mk & 0x03FF03FFu);
+                }
+                if (on_g || cell2 != prev.p1) m.c1[prev.a1] = (u16)cell2;
+                cur = cm_evaluate(m, pt, node, c0, a1, p1, cell2, 0u);  // c != k1: the run counter restarts
+                __syncthreads();  // barrier 2: the corrected table of byte i is there
+                run_prev = 0;
+            } else {
+                run_prev++;
+            }
+            prev = cur;
+            k1 = c;
+        }
+        return;
+    }
+    // ---- walker ---------------------------------------------------------------------------------------------
+    const u32 ul = (u32)lane;
+    const bool as0 = (ul >> 5) & 1u, as1 = (ul >> 4) & 1u, as2 = (ul >> 3) & 1u, as3 = (ul >> 2) & 1u, as4 = (ul >> 1) & 1u, as5 = ul & 1u;
+    const u32 nb0 = (u32)as0 - 1u, nb1 = (u32)as1 - 1u, nb2 = (u32)as2 - 1u, nb3 = (u32)as3 - 1u, nb4 = (u32)as4 - 1u, nb5 = (u32)as5 - 1u;
+    const u32 ix0 = 1u, ix1 = 2u | (ul >> 5), ix2 = 4u | (ul >> 4), ix3 = 8u | (ul >> 3), ix4 = 16u | (ul >> 2), ix5 = 32u | (ul >> 1);
+    const u32 ix6 = 64u | ul, ix7 = 128u | (ul << 1);
+    u32 low_u = 0, range_u = 0xFFFFFFFFu, code = 0, c1 = 0;
+    u32 ip = 0, ibase = 0;
+    u32 window = (ibase + lane < in_size) ? in[ibase + lane] : 0xFFFFFFFFu;
+    for (int j = 0; j < 4; j++) {  // :438-441; bytes past the end read as -1 (:345)
+        u32 b;
+        CM_NEXT_BYTE(b);
+        code = (code << 8) + b;
+    }
+    u32 staged = 0;
+    u64 prof_wait = 0, prof_walk = 0, prof_slow = 0, prof_miss = 0;  // debug == 3
+    u32 P0, P1, P2, P3, P4, P5, P6, P7a, P7b;  // this lane's slice of the table of the byte being decoded
+#define CM_SYNC_FETCH(BUF)                                                                            \
+    do {                                                                                              \
+        const u32 * __restrict__ pt_ = ptab[BUF];                                                     \
+        P0 = pt_[ix0]; P1 = pt_[ix1]; P2 = pt_[ix2]; P3 = pt_[ix3]; P4 = pt_[ix4]; P5 = pt_[ix5];     \
+        P6 = pt_[ix6]; P7a = pt_[ix7]; P7b = pt_[ix7 + 1u];                                           \
+    } while (0)
+    __syncthreads();  // barrier 0
+    CM_SYNC_FETCH(0);
+    for (u32 i = 0; i < n; i++) {
+        u64 t0 = 0, t1 = 0;
+        if (debug == 3) t0 = cm_clock();
+        u32 c;
+        {
+            u32 range = range_u, low;  // per-lane copies of the wave-uniform coder state
+            u32 d = code - low_u;
+            const bool inside = d <= range_u;  // low <= code <= high: always, unless a truncated stream fed -1 bytes (:345)
+            u32 acc = 0;
+            bool bit6, bit7;
+            CM_FAST_SPEC(P0, nb0, as0);  // :453-489
+            CM_FAST_SPEC(P1, nb1, as1);
+            CM_FAST_SPEC(P2, nb2, as2);
+            CM_FAST_SPEC(P3, nb3, as3);
+            CM_FAST_SPEC(P4, nb4, as4);
+            CM_FAST_SPEC(P5, nb5, as5);
+            const u64 ok = __ballot(acc == ul);  // exactly one lane decoded the six bits it had assumed
+            u32 cbits = acc;
+            CM_FAST_REAL(P6, bit6);
+            const u32 P7f = bit6 ? P7b : P7a;
+            CM_FAST_REAL(P7f, bit7);
+            const int w = __ffsll((unsigned long long)ok) - 1;
+            const u32 low_f = code - cm_readlane(d, w), range_f = cm_readlane(range, w);
+            if (__builtin_expect(inside && (low_f ^ (low_f + range_f)) >= (1u << 24), 1)) {
+                low_u = low_f;
+                range_u = range_f;
+                c = cm_readlane(cbits, w);
+            } else {  // a renormalisation was due on the true path: decode this byte again, checking every level
+                prof_slow++;
+                low = low_u;
+                range = range_u;
+                u64 valid = ~0ull;
+                CM_SPEC_LEVEL(P0, nb0, 0xFFFFFFFF00000000ull);
+                CM_SPEC_LEVEL(P1, nb1, 0xFFFF0000FFFF0000ull);
+                CM_SPEC_LEVEL(P2, nb2, 0xFF00FF00FF00FF00ull);
+                CM_SPEC_LEVEL(P3, nb3, 0xF0F0F0F0F0F0F0F0ull);
+                CM_SPEC_LEVEL(P4, nb4, 0xCCCCCCCCCCCCCCCCull);
+                CM_SPEC_LEVEL(P5, nb5, 0xAAAAAAAAAAAAAAAAull);
+                CM_REAL_LEVEL(P6, bit6);
+                const u32 P7 = bit6 ? P7b : P7a;
+                CM_REAL_LEVEL(P7, bit7);
+                const int w2 = __ffsll((unsigned long long)valid) - 1;  // exactly one lane survives
+                low_u = cm_readlane(low, w2);
+                range_u = cm_readlane(range, w2);
+                c = cm_readlane((ul << 2) | ((u32)bit6 << 1) | (u32)bit7, w2);
+            }
+        }
+        LDS_POKE(s_done[i & 1u], c);  // every lane stores the same word: no EXEC juggling on the critical path
+        if (debug == 3) t1 = cm_clock();
+        const bool hit = c == c1;  // the models' guess for byte i was byte i-1 (0 before the block starts)
+        c1 = c;
+        if ((u32)lane == (i & 63u)) staged = c;
+        if ((i & 63u) == 63u || i + 1 == n) {
+            const u32 first = i & ~63u;
+            if (first + lane <= i) out[first + lane] = (u8)staged;
+        }
+        if (i + 1u < n) {
+            __syncthreads();  // barrier 1: the speculative table of byte i+1 is complete, the models read byte i
+            if (!hit) {
+                if (debug == 3) prof_miss++;
+                __syncthreads();  // barrier 2: the corrected table
+                if (R && LDS_PEEK(s_abort) != 0u) return;  // given up (R > 0)
+            }
+            CM_SYNC_FETCH((i + 1u) & 1u);
+        }
+        if (debug == 3) {
+            const u64 t2 = cm_clock();
+            prof_walk += t1 - t0;
+            prof_wait += t2 - t1;
+        }
+    }
+    if (debug == 3 && n >= 256 && lane == 0) {  // profiling only: output bytes 0..31 become counters
+        u64 * o = reinterpret_cast<u64 *>(out);
+        o[0] = prof_wait;
+        o[1] = prof_walk;
+        o[2] = prof_slow;
+        o[3] = prof_miss;
+    }
+#undef CM_SYNC_FETCH
+}
 #undef CM_NEXT_BYTE
 #undef CM_RENORM
 #undef CM_SPEC_LEVEL
@@ -1186,6 +1409,12 @@ __global__ void __launch_bounds__(320) k_cm_decode_rows(const CmDecodeJob * __re
 __global__ void __launch_bounds__(320) k_cm_decode_rows3(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<CM_ROWS3_DEC>(jobs); }
 __global__ void __launch_bounds__(256) k_cm_decode_lock3(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_lockstep<CM_ROWS3_DEC>(jobs); }
 __global__ void __launch_bounds__(256) k_cm_decode_lock2(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_lockstep<CM_ROWS_DEC>(jobs); }
+__global__ void __launch_bounds__(320) k_cm_decode_sync(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_sync<0>(jobs); }
+__global__ void __launch_bounds__(320) k_cm_decode_sync2(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_sync<CM_ROWS_DEC>(jobs); }
+__global__ void __launch_bounds__(320) k_cm_decode_sync3(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_sync<CM_ROWS3_DEC>(jobs); }
+#ifdef BZ3_EMU
+__global__ void __launch_bounds__(320) k_cm_decode_sync_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_sync<CM_ROWS_TEST>(jobs); }
+#endif
 #ifdef BZ3_EMU
 __global__ void __launch_bounds__(256) k_cm_decode_lock_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_lockstep<CM_ROWS_TEST>(jobs); }
 #endif
@@ -1196,10 +1425,12 @@ __global__ void __launch_bounds__(320) k_cm_decode_rows_test(const CmDecodeJob *
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant) {
     if (!njobs) return;
 #ifdef BZ3_EMU
-    if (variant == CM_VARIANT_ROWS_TEST || variant == CM_VARIANT_LOCK_TEST) return launch(k_cm_encode_rows_test, dim3(njobs), dim3(256), 0, s, d_jobs);
+    if (variant == CM_VARIANT_ROWS_TEST || variant == CM_VARIANT_LOCK_TEST || variant == CM_VARIANT_SYNC_TEST)
+        return launch(k_cm_encode_rows_test, dim3(njobs), dim3(256), 0, s, d_jobs);
 #endif
-    if (variant == CM_VARIANT_ROWS3 || variant == CM_VARIANT_LOCK3) launch(k_cm_encode_rows3, dim3(njobs), dim3(256), 0, s, d_jobs);
-    else if (variant != CM_VARIANT_FULL) launch(k_cm_encode_rows, dim3(njobs), dim3(256), 0, s, d_jobs);
+    // the encoder has three kernels; the decoder variants pair up with the one that puts as many blocks on a CU
+    if (variant == CM_VARIANT_ROWS3 || variant == CM_VARIANT_LOCK3 || variant == CM_VARIANT_SYNC3) launch(k_cm_encode_rows3, dim3(njobs), dim3(256), 0, s, d_jobs);
+    else if (variant == CM_VARIANT_ROWS || variant == CM_VARIANT_LOCK2 || variant == CM_VARIANT_SYNC2) launch(k_cm_encode_rows, dim3(njobs), dim3(256), 0, s, d_jobs);
     else launch(k_cm_encode, dim3(njobs), dim3(256), 0, s, d_jobs);
 }
 
@@ -1208,11 +1439,15 @@ void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int v
 #ifdef BZ3_EMU
     if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_decode_rows_test, dim3(njobs), dim3(320), 0, s, d_jobs);
     if (variant == CM_VARIANT_LOCK_TEST) return launch(k_cm_decode_lock_test, dim3(njobs), dim3(256), 0, s, d_jobs);
+    if (variant == CM_VARIANT_SYNC_TEST) return launch(k_cm_decode_sync_test, dim3(njobs), dim3(320), 0, s, d_jobs);
 #endif
-    if (variant == CM_VARIANT_LOCK3) launch(k_cm_decode_lock3, dim3(njobs), dim3(256), 0, s, d_jobs);
+    if (variant == CM_VARIANT_SYNC) launch(k_cm_decode_sync, dim3(njobs), dim3(320), 0, s, d_jobs);
+    else if (variant == CM_VARIANT_SYNC2) launch(k_cm_decode_sync2, dim3(njobs), dim3(320), 0, s, d_jobs);
+    else if (variant == CM_VARIANT_SYNC3) launch(k_cm_decode_sync3, dim3(njobs), dim3(320), 0, s, d_jobs);
+    else if (variant == CM_VARIANT_LOCK3) launch(k_cm_decode_lock3, dim3(njobs), dim3(256), 0, s, d_jobs);
     else if (variant == CM_VARIANT_LOCK2) launch(k_cm_decode_lock2, dim3(njobs), dim3(256), 0, s, d_jobs);
     else if (variant == CM_VARIANT_ROWS3) launch(k_cm_decode_rows3, dim3(njobs), dim3(320), 0, s, d_jobs);
-    else if (variant != CM_VARIANT_FULL) launch(k_cm_decode_rows, dim3(njobs), dim3(320), 0, s, d_jobs);
+    else if (variant == CM_VARIANT_ROWS) launch(k_cm_decode_rows, dim3(njobs), dim3(320), 0, s, d_jobs);
     else launch(k_cm_decode, dim3(njobs), dim3(320), 0, s, d_jobs);
 }
 

@@ -226,7 +226,20 @@ def test_cm_row_cache_kernels_match_oracle(emu, oracle, cm_mode):
             assert g.cm_decode(c[: len(c) // 2], len(d)) == oracle.cm_decode(c[: len(c) // 2], len(d)), (mode, name)
     junk = bytes(rng.integers(0, 256, size=900, dtype=np.uint8))  # arbitrary input: 256 live rows, handed back
     assert g.cm_decode(junk, 2000) == oracle.cm_decode(junk, 2000)
-    assert emu.bz3_hip_set_cm_mode(7) == -1
+    # the barrier-synchronised guess-ahead decoder (CM_VARIANT_SYNC*: speculative table beside the walk, one barrier per byte on a
+    # right guess, two on a wrong one): tiny cache (11), whole model (5), 96 rows (6), 56 rows (7)
+    for mode in (11, 5, 6, 7):
+        assert cm_mode(mode) == 0
+        for name in (("skew60", "flat200", "tiny", "one") if mode == 11 else ("text", "tiny", "one")):
+            d = cases[name][0]
+            c = oracle.cm_encode(d)
+            n0 = emu.bz3_hip_cm_blocks_given_up()
+            assert g.cm_encode(d) == c and g.cm_decode(c, len(d)) == d, (mode, name)
+            if mode == 11:
+                assert emu.bz3_hip_cm_blocks_given_up() - n0 == (2 if cases[name][1] else 0), (mode, name)
+            assert g.cm_decode(c[: len(c) // 2], len(d)) == oracle.cm_decode(c[: len(c) // 2], len(d)), (mode, name)
+        assert g.cm_decode(junk, 2000) == oracle.cm_decode(junk, 2000), mode
+    assert emu.bz3_hip_set_cm_mode(8) == -1
 
 
 def test_batch_api_through_row_cache_kernels(emu, oracle, cm_mode):
@@ -354,7 +367,8 @@ def test_cm_protocols_survive_stalled_waves(emu):
     workgroup are put to sleep for dozens of scheduler sweeps at random).  Round 1 found this way that a model wave of the
     CM decoder which is held up for longer than the walker needs for one byte missed the walker's verdict in the one-word
     mailbox and waited for ever (on the GPU: two stalled runs with several workgroups per CU); the verdict is now recovered
-    from the following one.  Runs in a subprocess because the scheduler mode is fixed when the library is loaded."""
+    from the following one.  Round 2 found the same way that the barrier-synchronised decoder needs TWO words for the decoded
+    byte (the walker stores byte i+1 while a stalled model wave has not read byte i yet).  Runs in a subprocess because the scheduler mode is fixed when the library is loaded."""
     import subprocess
 
     code = r'''
@@ -367,13 +381,13 @@ lib = bzip3_amd._declare(C.CDLL(build()))
 o, g = Oracle(), bzip3_amd.StageApi(lib)
 d = o.bwt(datagen.shakespeare()[100000:101500])[1]
 c = o.cm_encode(d)
-for mode in (0, 9):
+for mode in (0, 9, 11, 5):  # polling decoder (whole model / tiny cache), barrier-synchronised decoder (tiny cache / whole model)
     assert lib.bz3_hip_set_cm_mode(mode) == 0
     assert g.cm_encode(d) == c and g.cm_decode(c, len(d)) == d
     assert g.cm_decode(c[: len(c) // 2], len(d)) == o.cm_decode(c[: len(c) // 2], len(d))
 print("ok")
 ''' % (os.path.dirname(HERE), HERE, os.path.join(HERE, "emu"))
-    for seed in ("-1", "-3"):
+    for seed in ("-1", "-3", "-7"):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BZ3_EMU_SCHED=seed), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (seed, r.stdout[-300:], r.stderr[-800:])
 

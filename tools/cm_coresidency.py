@@ -17,7 +17,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import bzip3_amd  # noqa: E402
 import datagen  # noqa: E402
 
-MODES = {"full": 0, "rows": 1, "rows3": 2, "lock2": 4, "lock3": 3}
+MODES = {"full": 0, "rows": 1, "rows3": 2, "lock2": 4, "lock3": 3, "sync": 5, "sync2": 6, "sync3": 7}
 
 
 def main():
@@ -34,7 +34,10 @@ def main():
     coded = g.cm_encode(plain)                              # coded by the full-model kernel; every variant must decode it back
     inb = bzip3_amd._cbuf(coded, len(coded))
     out = (C.c_uint8 * n)()
+    only = [a[len("--only="):].split(",") for a in sys.argv if a.startswith("--only=")]
     for name, mode in MODES.items():
+        if only and name not in only[0]:
+            continue
         assert lib.bz3_hip_set_cm_mode(mode) == 0
         for k in copies:
             os.environ.pop("BZ3_CM_DEBUG", None)
@@ -49,7 +52,8 @@ def main():
                 a = np.frombuffer(cnt, dtype=np.uint64).reshape(k, 16).astype(np.float64).mean(axis=0)
                 rec["walker_cyc_per_byte"] = {"wait": round(a[0] / n, 1), "walk": round(a[1] / n, 1)}
                 rec["walker_share"] = {"slow_path": round(a[2] / n, 3), "wrong_guess": round(a[3] / n, 3)}
-                rec["model_wave_cyc_per_byte"] = {"speculate": round(a[8] / n, 1), "wait": round(a[9] / n, 1), "redo": round(a[10] / n, 1)}
+                if not name.startswith("sync"):
+                    rec["model_wave_cyc_per_byte"] = {"speculate": round(a[8] / n, 1), "wait": round(a[9] / n, 1), "redo": round(a[10] / n, 1)}
             print(json.dumps(rec), flush=True)
     os.environ.pop("BZ3_CM_DEBUG", None)
     lib.bz3_hip_set_cm_mode(-1)
