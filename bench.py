@@ -50,7 +50,7 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 ALG_BYTES_ROUND_TRIP = 32.4  # 17.2 B/B encode + 15.2 B/B decode
 ALG_BYTES_BWT = 11.0
 CFG3_BYTES = 1_000_000_000  # BASELINE.json configs[2]: "enwik9 (1 GB), -b 256, single MI355X"
-CM_MODES = {"auto": -1, "full": 0, "rows": 1, "rows3": 2, "lock3": 3, "lock2": 4, "sync": 5, "sync2": 6, "sync3": 7, "measured": 100}
+CM_MODES = {"auto": -1, "full": 0, "rows": 1, "rows3": 2, "lock3": 3, "lock2": 4, "sync": 5, "sync2": 6, "sync3": 7, "solo2": 8, "solo3": 12, "measured": 100}
 
 T_START = time.perf_counter()
 RANK = int(os.environ.get("RANK", "0"))
@@ -295,7 +295,7 @@ def main():
     assert lib.bz3_hip_device_count() > 0, "no HIP device"
     assert lib.bz3_hip_bind_device(local_rank) == 0
     assert lib.bz3_hip_set_cm_mode(CM_MODES[a.cm_mode]) == 0
-    per_cu = {"rows": 2, "lock2": 2, "sync2": 2, "rows3": 3, "lock3": 3, "sync3": 3, "measured": 3, "auto": 3, "full": 1, "sync": 1}[a.cm_mode]  # blocks per CU the mode is made for
+    per_cu = {"rows": 2, "lock2": 2, "sync2": 2, "rows3": 3, "lock3": 3, "sync3": 3, "solo3": 3, "solo2": 2, "measured": 3, "auto": 3, "full": 1, "sync": 1}[a.cm_mode]  # blocks per CU the mode is made for
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     nblk = a.blocks if a.blocks > 0 else cus * per_cu
     lean = a.lean == 1 or (a.lean < 0 and nblk > cus)
@@ -460,8 +460,10 @@ def main():
         # launching stream (api.hip run_cm_jobs).
         dec_dominant = cm_dec_ms >= cm_enc_ms
         dom_ms = cm_dec_ms if dec_dominant else cm_enc_ms
-        enc_names = ["k_cm_encode", "k_cm_encode_rows", "k_cm_encode_rows3", "k_cm_encode_rows3", "k_cm_encode_rows", "k_cm_encode", "k_cm_encode_rows", "k_cm_encode_rows3"]
-        dec_names = ["k_cm_decode", "k_cm_decode_rows", "k_cm_decode_rows3", "k_cm_decode_lock3", "k_cm_decode_lock2", "k_cm_decode_sync", "k_cm_decode_sync2", "k_cm_decode_sync3"]
+        enc_names = {0: "k_cm_encode", 1: "k_cm_encode_rows", 2: "k_cm_encode_rows3", 3: "k_cm_encode_rows3", 4: "k_cm_encode_rows", 5: "k_cm_encode", 6: "k_cm_encode_rows",
+                     7: "k_cm_encode_rows3", 8: "k_cm_encode_rows", 12: "k_cm_encode_rows3"}
+        dec_names = {0: "k_cm_decode", 1: "k_cm_decode_rows", 2: "k_cm_decode_rows3", 3: "k_cm_decode_lock3", 4: "k_cm_decode_lock2", 5: "k_cm_decode_sync", 6: "k_cm_decode_sync2",
+                     7: "k_cm_decode_sync3", 8: "k_cm_decode_solo2", 12: "k_cm_decode_solo3"}
         kern = (dec_names if dec_dominant else enc_names)[lib.bz3_hip_cm_variant_for(local_rank, nblk, 0 if dec_dominant else 1)]
         cm_bytes = n_dec * nblk + comp_total
         # HBM traffic of the dominant kernel from the PMC pass (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs,

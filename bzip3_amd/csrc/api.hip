@@ -203,6 +203,8 @@ int cm_mode() {
         else if (e && !strcmp(e, "sync")) m = CM_VARIANT_SYNC;
         else if (e && !strcmp(e, "sync2")) m = CM_VARIANT_SYNC2;
         else if (e && !strcmp(e, "sync3")) m = CM_VARIANT_SYNC3;
+        else if (e && !strcmp(e, "solo2")) m = CM_VARIANT_SOLO2;
+        else if (e && !strcmp(e, "solo3")) m = CM_VARIANT_SOLO3;
         else if (e && !strcmp(e, "measured")) m = CM_MODE_MEASURED;
 #ifdef BZ3_EMU
         else if (e && !strcmp(e, "rows-test")) m = CM_VARIANT_ROWS_TEST;
@@ -257,8 +259,8 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
         for (size_t i = 0; i < jobs.size(); i++) {
             jobs[i].spill = dev_addr(spill + i * CM_SPILL_BYTES);
             jobs[i].status = dev_addr(d_status + i);
-            jobs[i].miss_base = variant >= CM_VARIANT_ROWS_TEST ? 64u : 256u;
-            jobs[i].miss_shift = variant >= CM_VARIANT_ROWS_TEST ? 3u : 8u;  // give up beyond 0.4 % misses (test variants: 12.5 %)
+            jobs[i].miss_base = cm_variant_is_test(variant) ? 64u : 256u;
+            jobs[i].miss_shift = cm_variant_is_test(variant) ? 3u : 8u;  // give up beyond 0.4 % misses (test variants: 12.5 %)
         }
     }
     if (const char * t = getenv("BZ3_CM_TUNE"))  // kernel experiments (cm.hip `tune`); no effect on the output bytes
@@ -1418,9 +1420,9 @@ BZIP3_API int bz3_hip_bind_device(int device) {
 BZIP3_API int bz3_hip_state_device(struct bz3_state * st) { return st->device; }
 
 BZIP3_API int bz3_hip_set_cm_mode(int mode) {
-    bool ok = (mode >= -1 && mode <= CM_VARIANT_SYNC3) || mode == CM_MODE_MEASURED;
+    bool ok = (mode >= -1 && mode <= CM_VARIANT_SOLO2) || mode == CM_VARIANT_SOLO3 || mode == CM_MODE_MEASURED;
 #ifdef BZ3_EMU
-    ok = ok || mode == CM_VARIANT_ROWS_TEST || mode == CM_VARIANT_LOCK_TEST || mode == CM_VARIANT_SYNC_TEST;
+    ok = ok || mode == CM_VARIANT_ROWS_TEST || mode == CM_VARIANT_LOCK_TEST || mode == CM_VARIANT_SYNC_TEST || mode == CM_VARIANT_SOLO_TEST;
 #endif
     if (!ok) return -1;
     g_cm_mode.store(mode);
@@ -1644,8 +1646,8 @@ void stage_cm_job(StageEnv & e, Job job, Launch && go) {
         status = (u32 *)e.dev(64);
         HIP_CHECK(hipMemsetAsync(status, 0, 64, e.s));  // on the launching stream: a non-blocking stream does not order with the null stream
         job.status = dev_addr(status);
-        job.miss_base = variant >= CM_VARIANT_ROWS_TEST ? 64u : 256u;
-        job.miss_shift = variant >= CM_VARIANT_ROWS_TEST ? 3u : 8u;
+        job.miss_base = cm_variant_is_test(variant) ? 64u : 256u;
+        job.miss_shift = cm_variant_is_test(variant) ? 3u : 8u;
     }
     Job * d_job = (Job *)e.dev(sizeof job, &job, sizeof job);
     go(d_job, 1u, e.s, variant);

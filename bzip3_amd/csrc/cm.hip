@@ -556,6 +556,8 @@ constexpr int CM_ROWS_ENC = 96;   // 48 KiB of C1 rows: 79.5 KB of LDS per workg
 constexpr int CM_ROWS_DEC = 96;   // 48 KiB of C1 rows: 72.1 KB of LDS per workgroup (112 rows = 80.6 KB: measured, two of those do NOT share a CU)
 constexpr int CM_ROWS3_ENC = 44;  // 22 KiB of C1 rows: 52.9 KB of LDS per workgroup, three workgroups per CU (a chunk pins up to 34 rows)
 constexpr int CM_ROWS3_DEC = 56;  // 28 KiB of C1 rows: 50.8 KB of LDS per workgroup
+constexpr int CM_ROWS_SOLO3 = 64;  // single-wave decoder: 32 KiB of C1 rows, 50.9 KB of LDS per workgroup, three per CU
+constexpr int CM_ROWS_SOLO2 = 112; // 56 KiB of C1 rows: 75.5 KB, two per CU
 #ifdef BZ3_EMU
 constexpr int CM_ROWS_TEST = 40;  // emulator tests: small enough that short inputs recycle slots all the time
 #endif
@@ -1192,14 +1194,17 @@ __device__ __forceinline__ void cm_decode_block_lockstep(const CmDecodeJob * __r
 // read into registers before barrier 1 of byte i; byte i+1 is stored in the other word than byte i, which a model wave may read
 // arbitrarily late after barrier 1 (found by the emulator's stalled-wave scheduling).
 // ------------------------------------------------------------------------------------------------
+// The model tables live in DYNAMIC LDS (size passed at launch).  With a large static LDS array the compiler pads the kernel's
+// register allocation up to what its LDS-derived occupancy estimate allows -- 97 VGPRs for 50 KB, i.e. four waves per SIMD --
+// and three five-wave workgroups then no longer fit a CU although their LDS does (measured: the 320-thread decoders ran two per
+// CU, the third waited for a second round; tools/occupancy_probe.hip shows that the hardware co-schedules the shape happily).
 template <int R>
-__device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restrict__ jobs) {
+__device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restrict__ jobs, CmLdsT<R> & m) {
     const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 in_size = jobs[blockIdx.x].in_size;
     u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
     const u32 n = jobs[blockIdx.x].n;
     const u32 debug = jobs[blockIdx.x].debug & 15u;  // 3: cycle counters instead of the first output bytes (profiling only)
-    __shared__ CmLdsT<R> m;
     __shared__ u32 ptab[2][256];  // (18-bit probability of node) << 14
     __shared__ u32 s_done[2];     // [i & 1] = byte i, written by the walker before barrier 1 of byte i.  Two words: after a right guess the
                                   // walker decodes byte i+1 and stores it while a model wave that was held up may not have read byte i yet
@@ -1397,6 +1402,217 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
     }
 #undef CM_SYNC_FETCH
 }
+
+// ------------------------------------------------------------------------------------------------
+// decode, single wave ("solo"): ONE wave per block, no hand-off between waves at all.
+//
+// The other decoders evaluate all 255 tree nodes of every byte (four waves), although a byte only ever uses 8 of them,
+// because the walker speculates the first six decisions across its 64 lanes and then needs the level-6 / level-7 nodes of
+// whatever prefix wins.  At three blocks per CU that evaluation is what fills the CU's issue slots
+// (profiles/r02_cm_coresidency*.txt: 2,200 cycles per byte and block for the lock-step decoder).  This decoder evaluates
+// what can be needed and nothing else:
+//   E1   lane l (1..63) evaluates node l (levels 0-5).  Its counters stay in registers from byte to byte: C0[l], and the
+//        order-1 cells C1[c1][l], C1[c2][l] (a byte that repeats its predecessor -- 60-70 % of BWT output -- needs no LDS
+//        read at all for them); the probabilities travel to the lanes that walk them by ds_bpermute, not through memory;
+//   walk lane l walks the six levels along prefix l (the same lane-speculated walk as the other decoders, same checked
+//        variant when a renormalisation falls into these levels);
+//   E2   the three nodes below the decoded prefix q (64|q, 128|2q, 128|2q+1) are evaluated by lanes 0-2;
+//   tail levels 6 and 7 are decoded on the scalar unit, with the reference's renormalisation test after each bit;
+//   update, row bookkeeping (one directory, the wave moves whole rows: four cells per lane).
+// ~190 wave-instructions per byte instead of ~380-460, one wave instead of four or five, nothing to synchronise.
+// ------------------------------------------------------------------------------------------------
+struct CmNodeEval {
+    u32 P;   // (18-bit probability) << 14
+    u32 ci;  // index of the first of the two C2 cells
+    u32 w;   // both cells, x1 | x2 << 16
+};
+template <class M>
+__device__ __forceinline__ CmNodeEval cm_evaluate_node(const M & m, u32 node, u32 c0, u32 p1, u32 p2, u32 f) {  // :377-388
+    CmNodeEval e;
+    const int p = (int)(((c0 + p1) * 7u + 2u * p2) >> 4);
+    e.ci = (2u * node + f) * CM_C2_STRIDE + (u32)(p >> 12);
+    e.w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[e.ci]));
+    const int x1 = (int)(e.w & 0xFFFFu), x2 = (int)(e.w >> 16);
+    const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);
+    e.P = (u32)(ssep * 3 + p) << 14;
+    return e;
+}
+
+template <int R>
+__device__ __forceinline__ void cm_decode_block_solo(const CmDecodeJob * __restrict__ jobs, CmLdsT<R> & m) {
+    static_assert(R > 0, "row-cache kernel");
+    const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
+    const u32 in_size = jobs[blockIdx.x].in_size;
+    u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
+    const u32 n = jobs[blockIdx.x].n;
+    const u32 debug = jobs[blockIdx.x].debug & 15u;  // 3: cycle counters instead of the first output bytes (profiling only)
+    __shared__ CmRowCache<R> rc;
+    cm_model_init(m);
+    if (n == 0) return;
+    const int lane = lane_id();
+    const u32 ul = (u32)lane;
+    // E1 side: lane l owns node l (lane 0: none)
+    const u32 lvl = ul ? (u32)(31 - __clz((int)ul)) : 0u;
+    const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
+    u32 c0 = 32768u;           // C0[l]
+    u32 v1 = 32768u;           // C1[c1][l]  (row1 * 256 + l)
+    u32 v2 = 32768u;           // C1[c2][l]
+    // walk side: lane l assumes bits b0..b5 = l
+    const bool as0 = (ul >> 5) & 1u, as1 = (ul >> 4) & 1u, as2 = (ul >> 3) & 1u, as3 = (ul >> 2) & 1u, as4 = (ul >> 1) & 1u, as5 = ul & 1u;
+    const u32 nb0 = (u32)as0 - 1u, nb1 = (u32)as1 - 1u, nb2 = (u32)as2 - 1u, nb3 = (u32)as3 - 1u, nb4 = (u32)as4 - 1u, nb5 = (u32)as5 - 1u;
+    const int ix1 = (int)(2u | (ul >> 5)), ix2 = (int)(4u | (ul >> 4)), ix3 = (int)(8u | (ul >> 3)), ix4 = (int)(16u | (ul >> 2)), ix5 = (int)(32u | (ul >> 1));
+    u32 low_u = 0, range_u = 0xFFFFFFFFu, code = 0;
+    u32 ip = 0, ibase = 0;
+    u32 window = (ibase + lane < in_size) ? in[ibase + lane] : 0xFFFFFFFFu;
+    for (int j = 0; j < 4; j++) {  // :438-441; bytes past the end read as -1 (:345)
+        u32 b;
+        CM_NEXT_BYTE(b);
+        code = (code << 8) + b;
+    }
+    CmRowState rs;
+    u16 * __restrict__ spill = global_ptr<u16>(jobs[blockIdx.x].spill);
+    const u32 miss_base = jobs[blockIdx.x].miss_base, miss_shift = jobs[blockIdx.x].miss_shift;
+    cm_rows_init<R>(rc);
+    u32 c1 = 0, c2 = 0, run = 0;
+    u32 row1 = 0, row2 = 0;  // slots of the rows of c1 and c2 (byte value 0 before the block starts: slot 0)
+    u32 staged = 0;
+    u64 prof_e1 = 0, prof_walk = 0, prof_e2 = 0, prof_tail = 0, prof_slow = 0;
+    for (u32 i = 0; i < n; i++) {
+        u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if (debug == 3) t0 = cm_clock();
+        run = (c1 == c2) ? run + 1 : 0;  // :367-372
+        const u32 f = run > 2 ? 1u : 0u;
+        // ---- E1: levels 0-5, one node per lane, counters from registers ----------------------------------------------
+        const CmNodeEval e1 = cm_evaluate_node(m, ul, c0, v1, v2, f);
+        const u32 P0 = (u32)__shfl((int)e1.P, 1), P1 = (u32)__shfl((int)e1.P, ix1), P2 = (u32)__shfl((int)e1.P, ix2), P3 = (u32)__shfl((int)e1.P, ix3),
+                  P4 = (u32)__shfl((int)e1.P, ix4), P5 = (u32)__shfl((int)e1.P, ix5);
+        if (debug == 3) t1 = cm_clock();
+        // ---- six speculated levels ----------------------------------------------------------------------------------------
+        u32 q;  // the decoded prefix b0..b5
+        {
+            u32 range = range_u, low;  // per-lane copies of the wave-uniform coder state
+            u32 d = code - low_u;
+            const bool inside = d <= range_u;  // low <= code <= high: always, unless a truncated stream fed -1 bytes (:345)
+            u32 acc = 0;
+            CM_FAST_SPEC(P0, nb0, as0);  // :453-489
+            CM_FAST_SPEC(P1, nb1, as1);
+            CM_FAST_SPEC(P2, nb2, as2);
+            CM_FAST_SPEC(P3, nb3, as3);
+            CM_FAST_SPEC(P4, nb4, as4);
+            CM_FAST_SPEC(P5, nb5, as5);
+            const u64 ok = __ballot(acc == ul);  // exactly one lane decoded the six bits it had assumed
+            const int w = __ffsll((unsigned long long)ok) - 1;
+            const u32 low_f = code - cm_readlane(d, w), range_f = cm_readlane(range, w);
+            if (__builtin_expect(inside && (low_f ^ (low_f + range_f)) >= (1u << 24), 1)) {
+                low_u = low_f;
+                range_u = range_f;
+                q = (u32)w;
+            } else {  // a renormalisation was due within these levels: walk them again, checking every level
+                prof_slow++;
+                low = low_u;
+                range = range_u;
+                u64 valid = ~0ull;
+                CM_SPEC_LEVEL(P0, nb0, 0xFFFFFFFF00000000ull);
+                CM_SPEC_LEVEL(P1, nb1, 0xFFFF0000FFFF0000ull);
+                CM_SPEC_LEVEL(P2, nb2, 0xFF00FF00FF00FF00ull);
+                CM_SPEC_LEVEL(P3, nb3, 0xF0F0F0F0F0F0F0F0ull);
+                CM_SPEC_LEVEL(P4, nb4, 0xCCCCCCCCCCCCCCCCull);
+                CM_SPEC_LEVEL(P5, nb5, 0xAAAAAAAAAAAAAAAAull);
+                const int w2 = __ffsll((unsigned long long)valid) - 1;  // exactly one lane survives
+                low_u = cm_readlane(low, w2);
+                range_u = cm_readlane(range, w2);
+                q = (u32)w2;
+            }
+        }
+        if (debug == 3) t2 = cm_clock();
+        // ---- E2: the three nodes below prefix q, lanes 0-2 (the other lanes ride along on node 64|q) ---------------------
+        const u32 child = (128u | (q << 1)) + (ul - 1u);               // lanes 1, 2: the two level-7 nodes
+        const u32 node2 = (ul - 1u) < 2u ? child : (64u | q);          // (one v_cndmask: nested selects compile to divergent branches)
+        const u32 a2 = row1 * 256u + node2;
+        const u32 c0b = m.c0[node2];
+        const u32 p1b = m.c1[a2];
+        const u32 p2b = m.c1[row2 * 256u + node2];
+        const CmNodeEval e2 = cm_evaluate_node(m, node2, c0b, p1b, p2b, f);
+        const u32 P6 = cm_readlane(e2.P, 0), P7a = cm_readlane(e2.P, 1), P7b = cm_readlane(e2.P, 2);
+        if (debug == 3) t3 = cm_clock();
+        // ---- levels 6 and 7 on the scalar unit, renormalisation test after each bit (:464-474) ----------------------------
+        u32 bit6, bit7;
+#define CM_SCALAR_LEVEL(P, BIT)                                                                       \
+        do {                                                                                          \
+            const u32 t_ = (u32)(((u64)range_u * (P)) >> 32);                                         \
+            const u32 mid_ = low_u + t_;                                                              \
+            BIT = code <= mid_ ? 1u : 0u;                                                             \
+            range_u = BIT ? t_ : range_u - t_ - 1u;                                                   \
+            low_u = BIT ? low_u : mid_ + 1u;                                                          \
+            while (__builtin_expect((low_u ^ (low_u + range_u)) < (1u << 24), 0)) {                   \
+                low_u <<= 8;                                                                          \
+                range_u = (range_u << 8) | 0xFFu;                                                     \
+                u32 b_;                                                                               \
+                CM_NEXT_BYTE(b_);                                                                     \
+                code = (code << 8) + b_;                                                              \
+            }                                                                                         \
+        } while (0)
+        CM_SCALAR_LEVEL(P6, bit6);
+        const u32 P7 = bit6 ? P7b : P7a;
+        CM_SCALAR_LEVEL(P7, bit7);
+#undef CM_SCALAR_LEVEL
+        const u32 c = (q << 2) | (bit6 << 1) | bit7;
+        // ---- counter updates (:396-399, :411-414; branch-free, see cm_upd) ------------------------------------------------
+        if ((hibit | (c >> shr)) == ul) {  // the six lanes whose node is on the path (lane 0 never matches: c >> 8 == 0, hibit == 1)
+            const u32 mk = 0u - ((c >> bitpos) & 1u);
+            c0 = cm_upd(c0, 2, mk & 16383u);
+            v1 = cm_upd(v1, 4, mk & 4095u);
+            m.c1[row1 * 256u + ul] = (u16)v1;
+            reinterpret_cast<PackedU32 *>(&m.c2[e1.ci])->v = cm_upd_pair6(e1.w, mk & 0x03FF03FFu);
+        }
+        if (ul == 0u || ul == 1u + bit6) {  // node 64|q with bit 6, node 128|2q|bit6 with bit 7
+            const u32 mk = 0u - (ul == 0u ? bit6 : bit7);
+            m.c0[node2] = (u16)cm_upd(c0b, 2, mk & 16383u);
+            m.c1[a2] = (u16)cm_upd(p1b, 4, mk & 4095u);
+            reinterpret_cast<PackedU32 *>(&m.c2[e2.ci])->v = cm_upd_pair6(e2.w, mk & 0x03FF03FFu);
+        }
+        if (ul == (i & 63u)) staged = c;
+        if ((i & 63u) == 63u || i + 1 == n) {
+            const u32 first = i & ~63u;
+            if (first + ul <= i) out[first + ul] = (u8)staged;
+        }
+        // ---- contexts of the next byte: its order-1 row must be resident; the register copies follow the rows -----------------
+        c2 = c1;
+        c1 = c;
+        row2 = row1;
+        v2 = v1;  // C1[new c2][l] = what C1[old c1][l] has just become
+        if (c1 != c2) {
+            u32 row = cm_uniform((u32)rc.row_of[c]);
+            if (__builtin_expect(row >= CM_ROW_SPILLED, 0)) {
+                rs.tick++;
+                if (lane == 0) rc.stamp[row2] = rs.tick;  // the row of c2 is still needed
+                wave_sync();
+                row = cm_rows_fetch<R, 4>(m, rc, rs, spill, c, row, ul);
+                if (__builtin_expect(rs.misses > miss_base + (i >> miss_shift), 0)) {  // the working set does not fit: give the block up
+                    if (lane == 0) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
+                    return;
+                }
+            }
+            row1 = row;
+            v1 = m.c1[row1 * 256u + ul];
+        }
+        if (debug == 3) {
+            const u64 t4 = cm_clock();
+            prof_e1 += t1 - t0;
+            prof_walk += t2 - t1;
+            prof_e2 += t3 - t2;
+            prof_tail += t4 - t3;
+        }
+    }
+    if (debug == 3 && n >= 256 && lane == 0) {  // profiling only: the first output bytes become counters
+        u64 * o = reinterpret_cast<u64 *>(out);
+        o[0] = prof_e1;
+        o[1] = prof_walk;
+        o[2] = prof_slow;
+        o[3] = prof_e2;
+        o[4] = prof_tail;
+    }
+}
 #undef CM_NEXT_BYTE
 #undef CM_RENORM
 #undef CM_SPEC_LEVEL
@@ -1409,11 +1625,26 @@ __global__ void __launch_bounds__(320) k_cm_decode_rows(const CmDecodeJob * __re
 __global__ void __launch_bounds__(320) k_cm_decode_rows3(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<CM_ROWS3_DEC>(jobs); }
 __global__ void __launch_bounds__(256) k_cm_decode_lock3(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_lockstep<CM_ROWS3_DEC>(jobs); }
 __global__ void __launch_bounds__(256) k_cm_decode_lock2(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_lockstep<CM_ROWS_DEC>(jobs); }
-__global__ void __launch_bounds__(320) k_cm_decode_sync(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_sync<0>(jobs); }
-__global__ void __launch_bounds__(320) k_cm_decode_sync2(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_sync<CM_ROWS_DEC>(jobs); }
-__global__ void __launch_bounds__(320) k_cm_decode_sync3(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_sync<CM_ROWS3_DEC>(jobs); }
+template <int R>
+__device__ __forceinline__ void cm_decode_solo_entry(const CmDecodeJob * __restrict__ jobs) {
+    BZ3_DYN_SMEM(dyn_lds);
+    cm_decode_block_solo<R>(jobs, *reinterpret_cast<CmLdsT<R> *>(dyn_lds));
+}
+__global__ void __launch_bounds__(64) k_cm_decode_solo2(const CmDecodeJob * __restrict__ jobs) { cm_decode_solo_entry<CM_ROWS_SOLO2>(jobs); }
+__global__ void __launch_bounds__(64) k_cm_decode_solo3(const CmDecodeJob * __restrict__ jobs) { cm_decode_solo_entry<CM_ROWS_SOLO3>(jobs); }
 #ifdef BZ3_EMU
-__global__ void __launch_bounds__(320) k_cm_decode_sync_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_sync<CM_ROWS_TEST>(jobs); }
+__global__ void __launch_bounds__(64) k_cm_decode_solo_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_solo_entry<CM_ROWS_TEST>(jobs); }
+#endif
+template <int R>
+__device__ __forceinline__ void cm_decode_sync_entry(const CmDecodeJob * __restrict__ jobs) {
+    BZ3_DYN_SMEM(dyn_lds);
+    cm_decode_block_sync<R>(jobs, *reinterpret_cast<CmLdsT<R> *>(dyn_lds));
+}
+__global__ void __launch_bounds__(320) k_cm_decode_sync(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<0>(jobs); }
+__global__ void __launch_bounds__(320) k_cm_decode_sync2(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS_DEC>(jobs); }
+__global__ void __launch_bounds__(320) k_cm_decode_sync3(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS3_DEC>(jobs); }
+#ifdef BZ3_EMU
+__global__ void __launch_bounds__(320) k_cm_decode_sync_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS_TEST>(jobs); }
 #endif
 #ifdef BZ3_EMU
 __global__ void __launch_bounds__(256) k_cm_decode_lock_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_lockstep<CM_ROWS_TEST>(jobs); }
@@ -1425,12 +1656,12 @@ __global__ void __launch_bounds__(320) k_cm_decode_rows_test(const CmDecodeJob *
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant) {
     if (!njobs) return;
 #ifdef BZ3_EMU
-    if (variant == CM_VARIANT_ROWS_TEST || variant == CM_VARIANT_LOCK_TEST || variant == CM_VARIANT_SYNC_TEST)
+    if (variant == CM_VARIANT_ROWS_TEST || variant == CM_VARIANT_LOCK_TEST || variant == CM_VARIANT_SYNC_TEST || variant == CM_VARIANT_SOLO_TEST)
         return launch(k_cm_encode_rows_test, dim3(njobs), dim3(256), 0, s, d_jobs);
 #endif
     // the encoder has three kernels; the decoder variants pair up with the one that puts as many blocks on a CU
-    if (variant == CM_VARIANT_ROWS3 || variant == CM_VARIANT_LOCK3 || variant == CM_VARIANT_SYNC3) launch(k_cm_encode_rows3, dim3(njobs), dim3(256), 0, s, d_jobs);
-    else if (variant == CM_VARIANT_ROWS || variant == CM_VARIANT_LOCK2 || variant == CM_VARIANT_SYNC2) launch(k_cm_encode_rows, dim3(njobs), dim3(256), 0, s, d_jobs);
+    if (variant == CM_VARIANT_ROWS3 || variant == CM_VARIANT_LOCK3 || variant == CM_VARIANT_SYNC3 || variant == CM_VARIANT_SOLO3) launch(k_cm_encode_rows3, dim3(njobs), dim3(256), 0, s, d_jobs);
+    else if (variant == CM_VARIANT_ROWS || variant == CM_VARIANT_LOCK2 || variant == CM_VARIANT_SYNC2 || variant == CM_VARIANT_SOLO2) launch(k_cm_encode_rows, dim3(njobs), dim3(256), 0, s, d_jobs);
     else launch(k_cm_encode, dim3(njobs), dim3(256), 0, s, d_jobs);
 }
 
@@ -1439,11 +1670,21 @@ void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int v
 #ifdef BZ3_EMU
     if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_decode_rows_test, dim3(njobs), dim3(320), 0, s, d_jobs);
     if (variant == CM_VARIANT_LOCK_TEST) return launch(k_cm_decode_lock_test, dim3(njobs), dim3(256), 0, s, d_jobs);
-    if (variant == CM_VARIANT_SYNC_TEST) return launch(k_cm_decode_sync_test, dim3(njobs), dim3(320), 0, s, d_jobs);
+    if (variant == CM_VARIANT_SYNC_TEST) return launch(k_cm_decode_sync_test, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS_TEST>), s, d_jobs);
+    if (variant == CM_VARIANT_SOLO_TEST) return launch(k_cm_decode_solo_test, dim3(njobs), dim3(64), sizeof(CmLdsT<CM_ROWS_TEST>), s, d_jobs);
+#else
+    static const bool big_lds_ok = [] {  // dynamic LDS beyond 64 KB has to be asked for once per kernel
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_solo2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<CM_ROWS_SOLO2>)) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_sync), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<0>)) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_sync2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<CM_ROWS_DEC>)) == hipSuccess;
+    }();
+    if (!big_lds_ok) throw HipError{hipErrorUnknown, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", __FILE__, __LINE__};
 #endif
-    if (variant == CM_VARIANT_SYNC) launch(k_cm_decode_sync, dim3(njobs), dim3(320), 0, s, d_jobs);
-    else if (variant == CM_VARIANT_SYNC2) launch(k_cm_decode_sync2, dim3(njobs), dim3(320), 0, s, d_jobs);
-    else if (variant == CM_VARIANT_SYNC3) launch(k_cm_decode_sync3, dim3(njobs), dim3(320), 0, s, d_jobs);
+    if (variant == CM_VARIANT_SOLO3) launch(k_cm_decode_solo3, dim3(njobs), dim3(64), sizeof(CmLdsT<CM_ROWS_SOLO3>), s, d_jobs);
+    else if (variant == CM_VARIANT_SOLO2) launch(k_cm_decode_solo2, dim3(njobs), dim3(64), sizeof(CmLdsT<CM_ROWS_SOLO2>), s, d_jobs);
+    else if (variant == CM_VARIANT_SYNC) launch(k_cm_decode_sync, dim3(njobs), dim3(320), sizeof(CmLdsT<0>), s, d_jobs);
+    else if (variant == CM_VARIANT_SYNC2) launch(k_cm_decode_sync2, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS_DEC>), s, d_jobs);
+    else if (variant == CM_VARIANT_SYNC3) launch(k_cm_decode_sync3, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS3_DEC>), s, d_jobs);
     else if (variant == CM_VARIANT_LOCK3) launch(k_cm_decode_lock3, dim3(njobs), dim3(256), 0, s, d_jobs);
     else if (variant == CM_VARIANT_LOCK2) launch(k_cm_decode_lock2, dim3(njobs), dim3(256), 0, s, d_jobs);
     else if (variant == CM_VARIANT_ROWS3) launch(k_cm_decode_rows3, dim3(njobs), dim3(320), 0, s, d_jobs);

@@ -124,12 +124,15 @@ struct CmDecodeJob {
 // cached in LDS: two or three workgroups per CU; they may give a block up, see status).
 // CM_VARIANT_LOCK3: row-cache encoder as ROWS3, but the lock-step decoder (cm.hip), three blocks per CU.
 // CM_VARIANT_LOCK2: the same pair with the 96-row caches, two blocks per CU.
+// CM_VARIANT_SOLO2 / SOLO3: the single-wave decoder (cm.hip: one wave per block, evaluates only the nodes a byte can need) with 112 / 64
+// rows in LDS (two / three blocks per CU), paired with the rows / rows3 encoder.
 // CM_VARIANT_SYNC / SYNC2 / SYNC3: the barrier-synchronised guess-ahead decoder (cm.hip) with the whole model / 96 rows / 56 rows
 // in LDS (one / two / three blocks per CU), paired with the full-model / rows / rows3 encoder.
 enum { CM_VARIANT_FULL = 0, CM_VARIANT_ROWS = 1, CM_VARIANT_ROWS3 = 2, CM_VARIANT_LOCK3 = 3, CM_VARIANT_LOCK2 = 4,
-       CM_VARIANT_SYNC = 5, CM_VARIANT_SYNC2 = 6, CM_VARIANT_SYNC3 = 7,
-       CM_VARIANT_ROWS_TEST = 9, CM_VARIANT_LOCK_TEST = 10, CM_VARIANT_SYNC_TEST = 11 /* emulator builds only: tiny cache */ };
+       CM_VARIANT_SYNC = 5, CM_VARIANT_SYNC2 = 6, CM_VARIANT_SYNC3 = 7, CM_VARIANT_SOLO2 = 8, CM_VARIANT_SOLO3 = 12,
+       CM_VARIANT_ROWS_TEST = 9, CM_VARIANT_LOCK_TEST = 10, CM_VARIANT_SYNC_TEST = 11, CM_VARIANT_SOLO_TEST = 13 /* emulator builds only: tiny cache */ };
 inline bool cm_variant_has_rows(int v) { return v != CM_VARIANT_FULL && v != CM_VARIANT_SYNC; }
+inline bool cm_variant_is_test(int v) { return v == CM_VARIANT_ROWS_TEST || v == CM_VARIANT_LOCK_TEST || v == CM_VARIANT_SYNC_TEST || v == CM_VARIANT_SOLO_TEST; }
 constexpr size_t CM_SPILL_BYTES = 256 * 256 * 2;
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL);
 void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL);

@@ -32,7 +32,7 @@ while time.time() - t0 < budget:
     else:
         d = bytes(rng.integers(0, 256, size=n, dtype=np.uint8))
     if not d: continue
-    mode = int(rng.choice([9, 10, 11, 11, 1, 2, 3, 4, 5, 6, 7]))
+    mode = int(rng.choice([9, 10, 11, 13, 13, 13, 1, 2, 3, 4, 5, 6, 7, 8, 12]))
     lib.bz3_hip_set_cm_mode(mode)
     c = o.cm_encode(d)
     e = g.cm_encode(d); dd = g.cm_decode(c, len(d))

@@ -228,18 +228,19 @@ def test_cm_row_cache_kernels_match_oracle(emu, oracle, cm_mode):
     assert g.cm_decode(junk, 2000) == oracle.cm_decode(junk, 2000)
     # the barrier-synchronised guess-ahead decoder (CM_VARIANT_SYNC*: speculative table beside the walk, one barrier per byte on a
     # right guess, two on a wrong one): tiny cache (11), whole model (5), 96 rows (6), 56 rows (7)
-    for mode in (11, 5, 6, 7):
+    # ... and the single-wave decoder (CM_VARIANT_SOLO*: one wave per block, only the nodes a byte can need): tiny cache (13), 112 rows (8), 64 rows (12)
+    for mode in (11, 5, 6, 7, 13, 8, 12):
         assert cm_mode(mode) == 0
-        for name in (("skew60", "flat200", "tiny", "one") if mode == 11 else ("text", "tiny", "one")):
+        for name in (("skew60", "flat200", "tiny", "one") if mode in (11, 13) else ("text", "tiny", "one")):
             d = cases[name][0]
             c = oracle.cm_encode(d)
             n0 = emu.bz3_hip_cm_blocks_given_up()
             assert g.cm_encode(d) == c and g.cm_decode(c, len(d)) == d, (mode, name)
-            if mode == 11:
+            if mode in (11, 13):
                 assert emu.bz3_hip_cm_blocks_given_up() - n0 == (2 if cases[name][1] else 0), (mode, name)
             assert g.cm_decode(c[: len(c) // 2], len(d)) == oracle.cm_decode(c[: len(c) // 2], len(d)), (mode, name)
         assert g.cm_decode(junk, 2000) == oracle.cm_decode(junk, 2000), mode
-    assert emu.bz3_hip_set_cm_mode(8) == -1
+    assert emu.bz3_hip_set_cm_mode(14) == -1
 
 
 def test_batch_api_through_row_cache_kernels(emu, oracle, cm_mode):
@@ -381,7 +382,7 @@ lib = bzip3_amd._declare(C.CDLL(build()))
 o, g = Oracle(), bzip3_amd.StageApi(lib)
 d = o.bwt(datagen.shakespeare()[100000:101500])[1]
 c = o.cm_encode(d)
-for mode in (0, 9, 11, 5):  # polling decoder (whole model / tiny cache), barrier-synchronised decoder (tiny cache / whole model)
+for mode in (0, 9, 11, 5, 13):  # polling decoder (whole model / tiny cache), barrier-synchronised decoder (tiny cache / whole model), single-wave decoder
     assert lib.bz3_hip_set_cm_mode(mode) == 0
     assert g.cm_encode(d) == c and g.cm_decode(c, len(d)) == d
     assert g.cm_decode(c[: len(c) // 2], len(d)) == o.cm_decode(c[: len(c) // 2], len(d))

@@ -17,7 +17,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import bzip3_amd  # noqa: E402
 import datagen  # noqa: E402
 
-MODES = {"full": 0, "rows": 1, "rows3": 2, "lock2": 4, "lock3": 3, "sync": 5, "sync2": 6, "sync3": 7}
+MODES = {"full": 0, "rows": 1, "rows3": 2, "lock2": 4, "lock3": 3, "sync": 5, "sync2": 6, "sync3": 7, "solo2": 8, "solo3": 12}
 
 
 def main():
@@ -50,6 +50,11 @@ def main():
                 cnt = (C.c_uint64 * (16 * k))()
                 lib.bz3_hip_stage_cm_decode_many(inb, len(coded), out, n, k, cnt)
                 a = np.frombuffer(cnt, dtype=np.uint64).reshape(k, 16).astype(np.float64).mean(axis=0)
+                if name.startswith("solo"):
+                    rec["cyc_per_byte"] = {"e1": round(a[0] / n, 1), "walk6": round(a[1] / n, 1), "e2": round(a[3] / n, 1), "tail": round(a[4] / n, 1)}
+                    rec["slow_path_share"] = round(a[2] / n, 3)
+                    print(json.dumps(rec), flush=True)
+                    continue
                 rec["walker_cyc_per_byte"] = {"wait": round(a[0] / n, 1), "walk": round(a[1] / n, 1)}
                 rec["walker_share"] = {"slow_path": round(a[2] / n, 3), "wrong_guess": round(a[3] / n, 3)}
                 if not name.startswith("sync"):
