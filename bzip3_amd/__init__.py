@@ -69,6 +69,7 @@ def _declare(L):
         "bz3_hip_stage_cm_encode": (i32, [vp, i32, vp]),
         "bz3_hip_stage_cm_decode": (None, [vp, i32, vp, i32]),
         "bz3_hip_stage_cm_decode_many": (C.c_float, [vp, i32, vp, i32, i32, vp]),
+        "bz3_hip_stage_cm_encode_many": (C.c_float, [vp, i32, vp, C.POINTER(i32), i32]),
         "bz3_hip_encode_stream": (C.c_int, [C.c_int, C.c_int, i32, i32]),
         "bz3_hip_decode_stream": (C.c_int, [C.c_int, C.c_int, i32]),
     }

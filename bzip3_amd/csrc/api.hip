@@ -232,14 +232,15 @@ int cm_variant_for(const DeviceCtx * ctx, size_t njobs, bool encode) {
         return (encode && njobs > c) ? CM_VARIANT_ROWS : CM_VARIANT_FULL;
     }
     if (m >= 0) return m;
-    // auto, by batch size (profiles/r02_cm_coresidency.txt, MI355X): up to one block per CU the full-model kernels have the
-    // lowest latency per block; beyond that the CM launch would need a second round of workgroups, and the row-cache kernels
-    // put two / three blocks on a CU instead -- the encoder's model waves interleave well (x1.5 / x2.0 throughput), and the
-    // lock-step decoder (barriers instead of polling) loses only 9 % / 16 % per block with one / two neighbours
-    // (x1.6 / x2.25 throughput; the guess-ahead decoder gains nothing at two per CU and x1.4 at three).
-    if (njobs > 2 * c) return CM_VARIANT_LOCK3;  // rows3 encoder + lock-step decoder, three blocks per CU
-    if (njobs > c) return CM_VARIANT_LOCK2;      // rows encoder + lock-step decoder, two blocks per CU
-    return CM_VARIANT_FULL;
+    // auto, by batch size (profiles/r02_cm_coresidency*.txt, MI355X, ns per byte and block of a 2 MiB text block).  Up to one block
+    // per CU the whole model sits in LDS; beyond that the CM launch would need a second round of workgroups, and the row-cache
+    // kernels put two / three blocks on a CU instead.  The encoder's model waves interleave well (x1.5 / x2.0 throughput).
+    // Decoders: the barrier-synchronised guess-ahead decoder (sync) is the fastest at every co-residency -- 653 / 807 / 880 ns with
+    // one / two / three blocks per CU, against 687 / (no co-residency) for the polling decoder and 787 / 853 / 915 ns for the
+    // lock-step one; the single-wave decoder (solo) needs 919 / 970 / 1000 ns.
+    if (njobs > 2 * c) return CM_VARIANT_SYNC3;  // rows3 encoder + sync decoder with 56 rows, three blocks per CU
+    if (njobs > c) return CM_VARIANT_SYNC2;      // rows encoder + sync decoder with 96 rows, two blocks per CU
+    return CM_VARIANT_SYNC;                      // full-model encoder + sync decoder with the whole model
 }
 
 size_t cm_scratch_bytes(size_t njobs) { return njobs * (CM_SPILL_BYTES + 256) + 4096; }
@@ -252,7 +253,7 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
     const int variant = cm_variant_for(ctx, jobs.size(), std::is_same<Job, CmEncodeJob>::value);
     const size_t mk = arena.mark();
     u32 * d_status = nullptr;
-    if (variant != CM_VARIANT_FULL) {
+    if (cm_variant_has_rows(variant)) {
         u8 * spill = arena.take<u8>(jobs.size() * CM_SPILL_BYTES);
         d_status = arena.take<u32>(jobs.size());
         HIP_CHECK(hipMemsetAsync(d_status, 0, jobs.size() * 4, s));
@@ -272,7 +273,7 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
     HIP_CHECK(hipEventRecord(ev1, s));
     HIP_CHECK(hipStreamSynchronize(s));
     (void)hipEventElapsedTime(&ms, ev0, ev1);
-    if (variant != CM_VARIANT_FULL) {
+    if (cm_variant_has_rows(variant)) {
         std::vector<u32> status(jobs.size());
         HIP_CHECK(hipMemcpyAsync(status.data(), d_status, jobs.size() * 4, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
@@ -283,7 +284,7 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
         if (!again.empty()) {
             HIP_CHECK(hipMemcpyAsync(d_jobs, again.data(), sizeof(Job) * again.size(), hipMemcpyHostToDevice, s));
             HIP_CHECK(hipEventRecord(ev0, s));
-            go(d_jobs, (u32)again.size(), s, (int)CM_VARIANT_FULL);
+            go(d_jobs, (u32)again.size(), s, (int)CM_VARIANT_SYNC);  // whole model in LDS: nothing to give up
             HIP_CHECK(hipEventRecord(ev1, s));
             HIP_CHECK(hipStreamSynchronize(s));
             (void)hipEventElapsedTime(&ms2, ev0, ev1);
@@ -1641,7 +1642,7 @@ extern "C++" template <class Job, class Launch>
 void stage_cm_job(StageEnv & e, Job job, Launch && go) {
     const int variant = cm_variant_for(e.ctx, 1, std::is_same<Job, CmEncodeJob>::value);
     u32 * status = nullptr;
-    if (variant != CM_VARIANT_FULL) {
+    if (cm_variant_has_rows(variant)) {
         job.spill = dev_addr(e.dev(CM_SPILL_BYTES));
         status = (u32 *)e.dev(64);
         HIP_CHECK(hipMemsetAsync(status, 0, 64, e.s));  // on the launching stream: a non-blocking stream does not order with the null stream
@@ -1651,9 +1652,9 @@ void stage_cm_job(StageEnv & e, Job job, Launch && go) {
     }
     Job * d_job = (Job *)e.dev(sizeof job, &job, sizeof job);
     go(d_job, 1u, e.s, variant);
-    if (variant != CM_VARIANT_FULL && e.word(status) != 0u) {
+    if (cm_variant_has_rows(variant) && e.word(status) != 0u) {
         g_cm_given_up.fetch_add(1u);
-        go(d_job, 1u, e.s, (int)CM_VARIANT_FULL);
+        go(d_job, 1u, e.s, (int)CM_VARIANT_SYNC);
     }
 }
 
@@ -1722,7 +1723,7 @@ BZIP3_API float bz3_hip_stage_cm_decode_many(const uint8_t * in, int32_t in_size
         const char * tune = getenv("BZ3_CM_TUNE");
         const u32 debug = (dbg ? (u32)atoi(dbg) : 0u) | ((tune ? (u32)atoi(tune) : 0u) << 4);
         const int variant = cm_variant_for(e.ctx, (size_t)copies, false);
-        u8 * spill = variant != CM_VARIANT_FULL ? e.dev(CM_SPILL_BYTES * (size_t)copies) : nullptr;
+        u8 * spill = cm_variant_has_rows(variant) ? e.dev(CM_SPILL_BYTES * (size_t)copies) : nullptr;
         u32 * status = (u32 *)e.dev(4 * (size_t)copies + 64);
         HIP_CHECK(hipMemsetAsync(status, 0, 4 * (size_t)copies, e.s));
         std::vector<CmDecodeJob> jobs;
@@ -1758,6 +1759,54 @@ BZIP3_API float bz3_hip_stage_cm_decode_many(const uint8_t * in, int32_t in_size
                 if (memcmp(other.data(), out, (size_t)n) != 0) return -2.f;
             }
         }
+        return ms;
+    });
+}
+
+// Profiling: `copies` identical CM encode jobs in ONE launch through the encoder of the current CM kernel variant; returns the launch
+// time in ms (HIP events) and the coded size of copy 0 in *coded (its bytes in `out`, capacity bz3_bound(n)).  BZ3_CM_DEBUG=1 / 2 runs
+// the coder wave / the model waves alone (output invalid): which side of the LDS ring limits the kernel at a given co-residency.
+BZIP3_API float bz3_hip_stage_cm_encode_many(const uint8_t * in, int32_t n, uint8_t * out, int32_t * coded, int32_t copies) {
+    return stage_guard([&]() -> float {
+        StageEnv e;
+        if (copies < 1 || n < 1) return -1.f;
+        u8 * d = e.dev((size_t)n + 64, in, (size_t)n);
+        const size_t stride = (bz3_bound((size_t)n) + 64 + 255) & ~(size_t)255;
+        u8 * o = e.dev(stride * (size_t)copies);
+        u32 * w = (u32 *)e.dev(16 * (size_t)copies + 64);
+        const char * dbg = getenv("BZ3_CM_DEBUG");
+        const char * tune = getenv("BZ3_CM_TUNE");
+        const u32 debug = (dbg ? (u32)atoi(dbg) : 0u) | ((tune ? (u32)atoi(tune) : 0u) << 4);
+        const int variant = cm_variant_for(e.ctx, (size_t)copies, true);
+        u8 * spill = cm_variant_has_rows(variant) ? e.dev(CM_SPILL_BYTES * (size_t)copies) : nullptr;
+        u32 * status = (u32 *)e.dev(4 * (size_t)copies + 64);
+        HIP_CHECK(hipMemsetAsync(status, 0, 4 * (size_t)copies, e.s));
+        std::vector<CmEncodeJob> jobs;
+        for (int32_t k = 0; k < copies; k++) {
+            CmEncodeJob j{dev_addr(d), dev_addr(o + stride * (size_t)k), dev_addr(w + 4 * (size_t)k), (u32)n, debug};
+            if (spill) {
+                j.spill = dev_addr(spill + CM_SPILL_BYTES * (size_t)k);
+                j.status = dev_addr(status + k);
+                j.miss_base = 256u;
+                j.miss_shift = 8u;
+            }
+            jobs.push_back(j);
+        }
+        CmEncodeJob * d_jobs = (CmEncodeJob *)e.dev(sizeof(CmEncodeJob) * jobs.size(), jobs.data(), sizeof(CmEncodeJob) * jobs.size());
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, e.s));
+        cm_encode_batch(d_jobs, (u32)copies, e.s, variant);
+        HIP_CHECK(hipEventRecord(e1, e.s));
+        HIP_CHECK(hipStreamSynchronize(e.s));
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        const u32 got = e.word(w);
+        if (coded) *coded = (int32_t)got;
+        if (got != 0xFFFFFFFFu && got <= bz3_bound((size_t)n) && !(debug & 15u)) e.down(out, o, (size_t)got);
         return ms;
     });
 }

@@ -55,6 +55,13 @@ __device__ __forceinline__ u32 cm_uniform(u32 v) {
 #endif
 }
 
+// Nothing is scheduled across this point (keeps a prefetch where it is written instead of at the top of its basic block).
+__device__ __forceinline__ void cm_sched_fence() {
+#ifndef BZ3_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // Issue priority of the calling wave among the waves of its SIMD (s_setprio 3 = highest user level).
 __device__ __forceinline__ void cm_raise_priority() {
 #ifndef BZ3_EMU
@@ -191,6 +198,33 @@ __device__ __forceinline__ u32 cm_rows_fetch(M & m, CmRowCache<R> & rc, CmRowSta
     return slot;
 }
 
+// The LDS ring between the model waves and the coder: per byte slot the 8 coder events as a structure of arrays, so that the coder
+// fetches a byte with six 16-byte LDS reads (four for the addends, two for the multipliers) instead of sixteen 8- / 4-byte ones.
+struct CmRing {
+    uint2 k[CM_RING * 8];  // (-s, -s): the 64-bit addend of the coder's multiply-add, 0 or 2^64 - 1 (see the header comment)
+    u32 m[CM_RING * 8];    // the multiplier M = P or 2^18 - P
+};
+struct CmByteEvents {      // the events of one byte in registers
+    uint2 k[8];
+    u32 m[8];
+};
+__device__ __forceinline__ void cm_load_events(const CmRing & ring, u32 i, CmByteEvents & e) {
+    const u32 slot = (i & (CM_RING - 1)) * 8;
+    const uint4 * __restrict__ pk = reinterpret_cast<const uint4 *>(&ring.k[slot]);
+    const uint4 * __restrict__ pm = reinterpret_cast<const uint4 *>(&ring.m[slot]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint4 q = pk[j];
+        e.k[2 * j] = make_uint2(q.x, q.y);
+        e.k[2 * j + 1] = make_uint2(q.z, q.w);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const uint4 q = pm[j];
+        e.m[4 * j] = q.x; e.m[4 * j + 1] = q.y; e.m[4 * j + 2] = q.z; e.m[4 * j + 3] = q.w;
+    }
+}
+
 struct CmEvent {  // what the chain loop leaves for the event loop
     u32 px1;      // p | x1 << 16
     u32 x2b;      // x2 | bit << 16
@@ -253,7 +287,7 @@ __device__ __forceinline__ void cm_chain_step(M & m, CmEvent * __restrict__ ev_r
 
 // One chunk of one model wave.  NSLOT = nodes per lane (1 or 2).  lvl_lo / nlvl = tree levels this wave owns.
 template <int NSLOT, bool FULL, class M>
-__device__ __forceinline__ void cm_model_chunk(M & m, CmEvent * __restrict__ ev, uint4 * __restrict__ ring, const u32 packed, const u32 fmask,
+__device__ __forceinline__ void cm_model_chunk(M & m, CmEvent * __restrict__ ev, CmRing & ring, const u32 packed, const u32 fmask,
                                                const u32 cnt, const u32 base, const CmLane & L, const u32 lvl_lo, const u32 nlvl, u32 (&c0)[NSLOT]) {
     const int lane = lane_id();
     CmEvent * __restrict__ ev_lvl = ev + (L.lvl - lvl_lo) * CM_CHUNK;
@@ -283,7 +317,9 @@ __device__ __forceinline__ void cm_model_chunk(M & m, CmEvent * __restrict__ ev,
             const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);  // :385
             const u32 p18 = (u32)(ssep * 3 + p);                     // :388
             const u32 neg = bit ? 0u : 0xFFFFFFFFu;
-            ring[((base + r) & (CM_RING - 1)) * 8 + k] = make_uint4(neg, neg, bit ? p18 : (1u << 18) - p18, bit ^ 1u);
+            const u32 at = ((base + r) & (CM_RING - 1)) * 8 + k;
+            ring.k[at] = make_uint2(neg, neg);
+            ring.m[at] = bit ? p18 : (1u << 18) - p18;
         }
     }
 }
@@ -293,14 +329,14 @@ __device__ __forceinline__ void cm_model_chunk(M & m, CmEvent * __restrict__ ev,
 // interval shrank to a single value on the way (a renormalisation was due there, and a 0 bit coded from that state
 // wraps the range, after which the intervals are no longer nested).
 template <int K0, int CNT>
-__device__ __forceinline__ bool cm_code_bits(const uint4 (&ev)[8], u32 & r, u32 & l) {
+__device__ __forceinline__ bool cm_code_bits(const CmByteEvents & ev, u32 & r, u32 & l) {
     u32 rmin = 0xFFFFFFFFu;
 #pragma unroll
     for (int kk = K0; kk < K0 + CNT; kk++) {
-        const uint4 e = ev[kk];  // (-s, -s, M, s): see the header comment
-        const u64 prod = (u64)r * e.z + (((u64)e.y << 32) | e.x);
+        const uint2 ek = ev.k[kk];  // (-s, -s) and M: see the header comment
+        const u64 prod = (u64)r * ev.m[kk] + (((u64)ek.y << 32) | ek.x);
         const u32 r2 = (u32)(prod >> 18);
-        l += (r - r2) & e.x;
+        l += (r - r2) & ek.x;
         r = r2;
         rmin = r < rmin ? r : rmin;
     }
@@ -333,13 +369,13 @@ struct CmSink {
 
 // The same steps with the reference's test after every bit (:390-394).
 template <int K0, int CNT>
-__device__ __forceinline__ void cm_code_bits_checked(const uint4 (&ev)[8], u32 & range, u32 & low, CmSink & sink, u32 i) {
+__device__ __forceinline__ void cm_code_bits_checked(const CmByteEvents & ev, u32 & range, u32 & low, CmSink & sink, u32 i) {
 #pragma unroll
     for (int kk = K0; kk < K0 + CNT; kk++) {
-        const uint4 e = ev[kk];
-        const u64 prod = (u64)range * e.z + (((u64)e.y << 32) | e.x);
+        const uint2 ek = ev.k[kk];
+        const u64 prod = (u64)range * ev.m[kk] + (((u64)ek.y << 32) | ek.x);
         const u32 r2 = (u32)(prod >> 18);
-        low += (range - r2) & e.x;
+        low += (range - r2) & ek.x;
         range = r2;
         if (__builtin_expect(__ballot(range < (1u << 24)) != 0ull, 0)) {  // necessary for (low ^ high) < 2^24; the exact test follows
             while (__ballot((low ^ (low + range)) < (1u << 24)) != 0ull) {  // :390-394
@@ -394,14 +430,17 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     const u32 debug = jobs[blockIdx.x].debug & 15u;
     const u32 tune = jobs[blockIdx.x].debug >> 4;  // experiments: bit 0 = raise the coder wave's issue priority
     __shared__ CmLdsT<R> m;
-    __shared__ uint4 ring[CM_RING * 8];
+    __shared__ __attribute__((aligned(16))) CmRing ring;
     __shared__ CmEvent ev_a[6 * CM_CHUNK], ev_b[CM_CHUNK], ev_c[CM_CHUNK];
     __shared__ u32 s_prod[3], s_cons;
     __shared__ CmRowCache<R> rcs[R ? 3 : 1];  // R > 0: one private directory per model wave
     if (threadIdx.x < 3) s_prod[threadIdx.x] = 0;
     if (threadIdx.x == 3) s_cons = 0;
     if (debug == 1)  // profiling only: a ring full of p = 1/2 events, so the lone coder emits exactly one byte per input byte
-        for (u32 t = threadIdx.x; t < CM_RING * 8; t += blockDim.x) ring[t] = make_uint4(0u, 0u, 1u << 17, 0u);
+        for (u32 t = threadIdx.x; t < CM_RING * 8; t += blockDim.x) {
+            ring.k[t] = make_uint2(0u, 0u);
+            ring.m[t] = 1u << 17;
+        }
     cm_model_init(m);
     const int lane = lane_id();
     const u32 role = cm_uniform((u32)wave_id());
@@ -501,48 +540,74 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
 #endif
     u32 range = 0xFFFFFFFFu ^ vzero, low = vzero, prod_seen = debug == 1 ? 0xFFFFFFFFu : 0u;
     CmSink sink{out, global_ptr<u8>(jobs[blockIdx.x].side), jobs[blockIdx.x].gap, jobs[blockIdx.x].side_cap, n};
-    for (u32 i = 0; i < n; i++) {
+    // Fast path: all 8 bits of the byte without a single test.  While nothing is renormalised the intervals are
+    // nested, so "a renormalisation was due after some bit" is equivalent to "the final interval lies within one
+    // 2^24 bucket" (:390): one test per byte.  If it fires (about one byte in four) the byte is coded again in two
+    // halves of 4 bits, each first without tests and only then, if its own test fires, bit by bit.
+    // Branches are on wave-uniform conditions (ballot of the single live lane -> s_cbranch_vccnz): a divergent
+    // `if` would save/restore EXEC, and every EXEC write stalls the following VALU op.  __builtin_expect keeps
+    // the slow paths out of line: the common case must FALL THROUGH (a taken branch costs ~40 cycles on a lone wave).
+    //
+    // Two register sets: the events of byte i+1 are fetched from the ring in the MIDDLE of byte i's recurrence whenever they
+    // are there already (the model waves run a chunk of 32 bytes ahead), so their LDS latency hides behind bits 4-7 and
+    // nothing is waited for when byte i+1 starts.  (Issued at the top of a byte, the compiler's wait for the current byte's
+    // registers also waits for the loads just issued; the scheduling barriers keep the fetch where it is written.)
+    auto code_byte = [&](const CmByteEvents & ev, CmByteEvents & next, const u32 i) __attribute__((always_inline)) {
+        u32 r = range, l = low;
+        const bool bad_half = cm_code_bits<0, 4>(ev, r, l);
+        cm_sched_fence();
+        cm_load_events(ring, i + 1u, next);  // unconditional (a branch here would let the compiler move the fetch to the top of the byte): if byte i+1
+        cm_sched_fence();                     // is not there yet the slot still holds an older byte and the caller fetches again after waiting
+        const u32 r4 = r, l4 = l;
+        const bool bad = cm_code_bits<4, 4>(ev, r, l) || bad_half;  // (the half's own bucket test is implied by the final one; its range-reached-zero guard is not)
+        if (__builtin_expect(__ballot(bad) == 0ull, 1)) {
+            range = r;
+            low = l;
+        } else {
+            if (__ballot(bad_half) == 0ull) {
+                range = r4;
+                low = l4;
+            } else {
+                cm_code_bits_checked<0, 4>(ev, range, low, sink, i);
+            }
+            r = range, l = low;
+            if (__ballot(cm_code_bits<4, 4>(ev, r, l)) == 0ull) {
+                range = r;
+                low = l;
+            } else {
+                cm_code_bits_checked<4, 4>(ev, range, low, sink, i);
+            }
+        }
+        if ((i & 15u) == 15u) LDS_POKE(s_cons, i + 1);
+    };
+    // Waits until the model waves have published byte i (false: they gave the block up).
+    auto wait_for = [&](const u32 i) __attribute__((always_inline)) -> bool {
         while (prod_seen <= i) {
             const u32 a = LDS_PEEK(s_prod[0]), b = LDS_PEEK(s_prod[1]), c = LDS_PEEK(s_prod[2]);
             prod_seen = a < b ? (a < c ? a : c) : (b < c ? b : c);
             if (prod_seen <= i) BZ3_SPIN_PAUSE();
-            if (R && prod_seen == CM_ABORT_MARK) return;  // all three model waves gave the block up; nothing of it is coded past their last chunk
+            if (R && prod_seen == CM_ABORT_MARK) return false;  // all three model waves gave the block up; nothing of it is coded past their last chunk
         }
         lds_acquire();
-        const uint4 * __restrict__ evp = &ring[(i & (CM_RING - 1)) * 8];
-        uint4 ev[8];
-#pragma unroll
-        for (int kk = 0; kk < 8; kk++) ev[kk] = evp[kk];
-        // Fast path: all 8 bits of the byte without a single test.  While nothing is renormalised the intervals are
-        // nested, so "a renormalisation was due after some bit" is equivalent to "the final interval lies within one
-        // 2^24 bucket" (:390): one test per byte.  If it fires (about one byte in four) the byte is coded again in two
-        // halves of 4 bits, each first without tests and only then, if its own test fires, bit by bit.
-        // Branches are on wave-uniform conditions (ballot of the single live lane -> s_cbranch_vccnz): a divergent
-        // `if` would save/restore EXEC, and every EXEC write stalls the following VALU op.  __builtin_expect keeps
-        // the slow paths out of line: the common case must FALL THROUGH (a taken branch costs ~40 cycles on a lone wave).
-        {
-            u32 r = range, l = low;
-            if (__builtin_expect(__ballot(cm_code_bits<0, 8>(ev, r, l)) == 0ull, 1)) {
-                range = r;
-                low = l;
-            } else {
-                r = range, l = low;
-                if (__ballot(cm_code_bits<0, 4>(ev, r, l)) == 0ull) {
-                    range = r;
-                    low = l;
-                } else {
-                    cm_code_bits_checked<0, 4>(ev, range, low, sink, i);
-                }
-                r = range, l = low;
-                if (__ballot(cm_code_bits<4, 4>(ev, r, l)) == 0ull) {
-                    range = r;
-                    low = l;
-                } else {
-                    cm_code_bits_checked<4, 4>(ev, range, low, sink, i);
-                }
-            }
+        return true;
+    };
+    CmByteEvents eva, evb;
+    if (!wait_for(0)) return;
+    cm_load_events(ring, 0, eva);
+    for (u32 i = 0; i < n; i += 2) {
+        bool have = i + 1 < n && prod_seen > i + 1;
+        code_byte(eva, evb, i);
+        if (i + 1 >= n) break;
+        if (!have) {
+            if (!wait_for(i + 1)) return;
+            cm_load_events(ring, i + 1, evb);
         }
-        if ((i & 15u) == 15u) LDS_POKE(s_cons, i + 1);
+        have = i + 2 < n && prod_seen > i + 2;
+        code_byte(evb, eva, i + 1);
+        if (i + 2 < n && !have) {
+            if (!wait_for(i + 2)) return;
+            cm_load_events(ring, i + 2, eva);
+        }
     }
     for (int j = 0; j < 4; j++) {  // flush (:425-432)
         sink.put(low >> 24, n - 1u);

@@ -35,9 +35,12 @@ BZIP3_API int bz3_hip_state_device(struct bz3_state * state);
  * two / three blocks per CU; a block whose working set does not fit is handed back to variant 0 automatically);
  * 3 / 4 = as 2 / 1 with the lock-step decoder (barriers instead of polling: loses little when several blocks share a CU);
  * 100 = by batch size as measured (row-cache encoder beyond one block per CU, row-cache decoder beyond two);
- * -1 = automatic (default), by batch size: up to one block per CU variant 0, up to two per CU variant 4, beyond that variant 3
- *      (measured on MI355X: profiles/r02_cm_coresidency.txt).
- * Environment BZ3_HIP_CM_MODE=auto|full|rows|rows3|lock3|lock2|measured has the same effect.  Output bytes do not depend on
+ * 5 / 6 / 7 = the barrier-synchronised guess-ahead decoder (speculative table beside the walk, barriers instead of polled mailboxes) with
+ *      the whole model / 96 rows / 56 rows in LDS, paired with the encoder of variant 0 / 1 / 2;
+ * 8 / 12 = the single-wave decoder (one wave per block, evaluates only the nodes a byte can need) with 112 / 64 rows;
+ * -1 = automatic (default), by batch size: up to one block per CU variant 5, up to two per CU variant 6, beyond that variant 7
+ *      (measured on MI355X: profiles/r02_cm_coresidency*.txt).
+ * Environment BZ3_HIP_CM_MODE=auto|full|rows|rows3|lock3|lock2|sync|sync2|sync3|solo2|solo3|measured has the same effect.  Output bytes do not depend on
  * the variant.  Returns 0, or -1 for an invalid mode. */
 BZIP3_API int bz3_hip_set_cm_mode(int mode);
 /* Number of blocks the row-cache kernels have handed back to the full-model kernels so far (statistics). */
@@ -109,6 +112,10 @@ BZIP3_API int bz3_hip_decode_stream(int in_fd, int out_fd, int32_t blocks_per_ba
  * time in milliseconds, `out` receives the n (>= 256) decoded bytes of copy 0; with BZ3_CM_DEBUG=3 `counters` (u64[16] per
  * copy, may be NULL) receives the decoder's phase cycle counters instead of valid output (bzip3_amd/csrc/api.hip). */
 BZIP3_API float bz3_hip_stage_cm_decode_many(const uint8_t * in, int32_t in_size, uint8_t * out, int32_t n, int32_t copies, uint64_t * counters);
+
+/* The same for the encoder: `copies` identical CM encode jobs in one launch; *coded = coded size of copy 0, its bytes in `out`
+ * (capacity bz3_bound(n)).  BZ3_CM_DEBUG=1 / 2: coder wave / model waves alone (output invalid). */
+BZIP3_API float bz3_hip_stage_cm_encode_many(const uint8_t * in, int32_t n, uint8_t * out, int32_t * coded, int32_t copies);
 
 #ifdef __cplusplus
 }
