@@ -953,8 +953,7 @@ __device__ __forceinline__ void cm_decode_block(const CmDecodeJob * __restrict__
         const bool bit_ = d <= t_;                                                                    \
         acc = cm_shift_in(acc, __ballot(bit_), bit_);                                                 \
         range = cm_xad(t_, (NB), keep_);                           /* t  |  range - t - 1 */          \
-        const u32 d0_ = d + ~t_;                                                                      \
-        d = (AS) ? d : d0_;                                        /* d  |  d - t - 1     */          \
+        d = cm_xad(t_ | ~(NB), 0xFFFFFFFFu, d);                    /* d  |  d + ~t = d - t - 1: assumed 1 -> (~0 ^ ~0) + d */ \
     } while (0)
 #define CM_FAST_REAL(P, BIT)                                                                          \
     do {                                                                                              \
@@ -1296,6 +1295,9 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         u16 * __restrict__ spill = global_ptr<u16>(jobs[blockIdx.x].spill);
         const u32 miss_base = jobs[blockIdx.x].miss_base, miss_shift = jobs[blockIdx.x].miss_shift;
         if (R) cm_rows_init<R>(rc);
+        // the directory byte value -> slot also lives in a register (lane k: entries 4k .. 4k+3): the lookup on a wrong guess is a
+        // v_readlane instead of an LDS round trip on the path the walker waits for
+        u32 rowreg = R ? reinterpret_cast<const u32 *>(rc.row_of)[lane] : 0u;
         __syncthreads();  // barrier 0: table 0 is there
         for (u32 i = 1; i < n; i++) {
             u32 * __restrict__ pt = ptab[i & 1u];
@@ -1321,13 +1323,14 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
                 u32 row = c;
                 bool give_up = false;
                 if (R) {
-                    row = cm_uniform((u32)rc.row_of[c]);
+                    row = (cm_readlane(rowreg, (int)(c >> 2)) >> (8u * (c & 3u))) & 0xFFu;
                     if (__builtin_expect(row >= CM_ROW_SPILLED, 0)) {
                         // the only row still needed is the one of byte i-2 (prev.a1 points into it): pin it
                         rs.tick++;
                         if (lane == 0) rc.stamp[cm_uniform(prev.a1 >> 8)] = rs.tick;
                         wave_sync();
                         row = cm_rows_fetch<R, 1>(m, rc, rs, spill, c, row, node);
+                        rowreg = reinterpret_cast<const u32 *>(rc.row_of)[lane];
                         give_up = rs.misses > miss_base + (i >> miss_shift);  // the working set does not fit (every model wave gets here at the same byte)
                     }
                 }
@@ -1376,7 +1379,6 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         CM_NEXT_BYTE(b);
         code = (code << 8) + b;
     }
-    u32 staged = 0;
     u64 prof_wait = 0, prof_walk = 0, prof_slow = 0, prof_miss = 0;  // debug == 3
     u32 P0, P1, P2, P3, P4, P5, P6, P7a, P7b;  // this lane's slice of the table of the byte being decoded
 #define CM_SYNC_FETCH(BUF)                                                                            \
@@ -1438,11 +1440,7 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         if (debug == 3) t1 = cm_clock();
         const bool hit = c == c1;  // the models' guess for byte i was byte i-1 (0 before the block starts)
         c1 = c;
-        if ((u32)lane == (i & 63u)) staged = c;
-        if ((i & 63u) == 63u || i + 1 == n) {
-            const u32 first = i & ~63u;
-            if (first + lane <= i) out[first + lane] = (u8)staged;
-        }
+        out[i] = (u8)c;  // every lane stores the same byte to the same address: one instruction, where collecting 64 bytes per lane costs six per byte
         if (i + 1u < n) {
             __syncthreads();  // barrier 1: the speculative table of byte i+1 is complete, the models read byte i
             if (!hit) {
