@@ -91,6 +91,21 @@ def elapsed():
     return time.perf_counter() - T_START
 
 
+def plan_steps(left_s, t_first_s, req_steps, req_warmup):
+    """How to spend what is left of the wall budget after the first step has run (it took t_first_s).  Returns (warmup, more):
+    `warmup` = untimed steps in total, the first step included when it is one (0: the first step is the first timed step);
+    `more` = timed steps still to run.  At least one timed step always exists; a warmup is only spent when a second step still
+    fits; further warmups never displace requested timed steps."""
+    afford = int(max(0.0, left_s) // (t_first_s * 1.03)) if t_first_s > 0 else 0  # further steps that still fit
+    if afford < 1 or (req_warmup <= 0 and req_steps <= 1):
+        return 0, 0
+    if req_warmup > 0:
+        warmup = 1 + max(0, min(req_warmup - 1, afford - req_steps))
+        more = max(1, min(req_steps, afford - (warmup - 1)))
+        return warmup, more
+    return 0, max(0, min(req_steps - 1, afford))
+
+
 def progress(msg):
     """Milestones on stderr (stdout carries only the JSON line)."""
     if RANK == 0:
@@ -416,16 +431,11 @@ def main():
     barrier()
     t_first = max_over_ranks(time.perf_counter() - t0)
     left = agree(a.budget_s - elapsed()) - reserve
-    afford = int(max(0.0, left) // (t_first * 1.03))  # further steps that still fit
-    warmup_run, steps_run, timed = 0, 1, t_first
-    if afford >= 1 and (a.warmup > 0 or a.steps > 1):
-        if a.warmup > 0:  # the step just run becomes the warmup; more warmups only while timed steps are not displaced
-            warmup_run = 1 + max(0, min(a.warmup - 1, afford - a.steps))
-            for _ in range(warmup_run - 1):
-                one_step()
-            afford -= warmup_run - 1
-            steps_run, timed = 0, 0.0
-        more = max(1 - steps_run, min(a.steps - steps_run, afford))
+    warmup_run, more = plan_steps(left, t_first, a.steps, a.warmup)
+    steps_run, timed = (0, 0.0) if warmup_run else (1, t_first)  # with a warmup the step just run does not count
+    for _ in range(max(0, warmup_run - 1)):
+        one_step()
+    if more:
         barrier()
         t0 = time.perf_counter()
         for k in range(more):
