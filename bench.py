@@ -488,6 +488,19 @@ def main():
                 traffic = int(pm["fetch_bytes_per_input_byte"] * n_dec * nblk + pm["write_bytes_per_coded_byte"] * comp_total)
         except Exception:
             pass
+        # what the CM stage sees, on a 16 MiB sample of block 0 through the stage hooks (outside the timed region): how often a byte of
+        # the BWT output repeats its predecessor decides how often the decoder's guess-ahead is right
+        repeat_rate = None
+        try:
+            import numpy as np
+
+            g_ = bzip3_amd.StageApi(lib)
+            smp = bufs[0][: min(block_size, 16 << 20)].cpu().numpy().tobytes()
+            nl_, lz_ = g_.lzp_encode(smp)
+            u_ = np.frombuffer(g_.bwt(lz_ if nl_ > 0 else smp)[1], dtype=np.uint8)
+            repeat_rate = round(float((u_[1:] == u_[:-1]).mean()), 4)
+        except Exception as e:
+            progress(f"repeat-rate sample failed: {e}")
         out = {
             "metric": "MiB/s encode+decode round-trip, 256 MiB blocks",
             "value": round(value, 3),
@@ -514,6 +527,7 @@ def main():
                 "cm_mode": a.cm_mode,
                 "lean_states": bool(lean),
                 "cm_blocks_given_up": int(lib.bz3_hip_cm_blocks_given_up()),
+                "bwt_output_repeat_rate_16MiB_sample": repeat_rate,
                 "round_trip_check": f"position-weighted 64-bit fingerprint of every block + byte-for-byte comparison of {n_keep} blocks",
             },
             # dominant kernel by time: a CM launch (one workgroup per block; a serial integer recurrence,

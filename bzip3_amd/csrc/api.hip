@@ -13,6 +13,7 @@
 // bz3_new() returns NULL and the stage hooks abort loudly.
 #include <atomic>
 #include <chrono>
+#include <exception>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -366,6 +367,19 @@ struct DeviceGuard {
     explicit DeviceGuard(int d) { HIP_CHECK(hipSetDevice(d)); }
 };
 
+// A group call that is left by an exception must not leave kernels in flight on either stream of the device: the caller is about to
+// hand borrowed swap buffers back to the pool and to reuse the arena (the serial LZP kernels run on the second stream).
+struct DrainOnUnwind {
+    hipStream_t a, b;
+    int live = std::uncaught_exceptions();
+    ~DrainOnUnwind() {
+        if (std::uncaught_exceptions() > live) {
+            if (a) (void)hipStreamSynchronize(a);
+            if (b) (void)hipStreamSynchronize(b);
+        }
+    }
+};
+
 void state_release(bz3_state * st) {
     if (!st) return;
     (void)hipSetDevice(st->device);
@@ -592,6 +606,7 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     if (window < 1) window = 1;
     lead->ctx->ensure_aux();
     hipStream_t s = lead->stream, s2 = lead->ctx->aux;
+    DrainOnUnwind drain{s, s2};
     Arena arena = lead->ctx->arena_for(need + 2 * (size_t)window * (ctx_bytes + sizeof(LzpDriverJob) + 256) + (size_t)n * (sizeof(CmEncodeJob) + CM_SIDE_BYTES + 256) +
                                        cm_scratch_bytes((size_t)n) + 65536);
     CmEncodeJob * d_jobs = arena.take<CmEncodeJob>((size_t)n);
@@ -901,6 +916,7 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     }
     lead->ctx->ensure_aux();
     hipStream_t s2 = lead->ctx->aux;
+    DrainOnUnwind drain{s, s2};
     const s32 nwin = (n + tail_window - 1) / tail_window;
     for (s32 k = 0; k <= nwin; k++) {
         if (k < nwin) {  // window k: inverse BWTs on the group's stream, then its LZP decoders on the second stream

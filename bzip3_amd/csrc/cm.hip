@@ -19,6 +19,8 @@
 //    (the guess-ahead decoder even before that byte is known); the 8 serial decisions are speculated across lanes.
 // All arithmetic is integer and matches the reference bit for bit, including the signed interpolation
 // `x1 + (((x2 - x1) * (p & 4095)) >> 12)` with an arithmetic shift of a possibly negative product.
+#include <atomic>
+
 #include "prims.hpp"
 #include "stages.hpp"
 
@@ -1740,12 +1742,19 @@ void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int v
     if (variant == CM_VARIANT_SYNC_TEST) return launch(k_cm_decode_sync_test, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS_TEST>), s, d_jobs);
     if (variant == CM_VARIANT_SOLO_TEST) return launch(k_cm_decode_solo_test, dim3(njobs), dim3(64), sizeof(CmLdsT<CM_ROWS_TEST>), s, d_jobs);
 #else
-    static const bool big_lds_ok = [] {  // dynamic LDS beyond 64 KB has to be asked for once per kernel
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_solo2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<CM_ROWS_SOLO2>)) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_sync), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<0>)) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_sync2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<CM_ROWS_DEC>)) == hipSuccess;
-    }();
-    if (!big_lds_ok) throw HipError{hipErrorUnknown, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", __FILE__, __LINE__};
+    {  // dynamic LDS beyond 64 KB has to be asked for, once per kernel AND per device (a batch may span several GPUs of one process)
+        static std::atomic<u64> prepared[4] = {{0}, {0}, {0}, {0}};  // one bit per device ordinal (up to 256)
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        const u64 bit = 1ull << (dev & 63);
+        std::atomic<u64> & word = prepared[(dev >> 6) & 3];
+        if (!(word.load() & bit)) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_solo2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<CM_ROWS_SOLO2>)));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_sync), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<0>)));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_sync2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<CM_ROWS_DEC>)));
+            word.fetch_or(bit);
+        }
+    }
 #endif
     if (variant == CM_VARIANT_SOLO3) launch(k_cm_decode_solo3, dim3(njobs), dim3(64), sizeof(CmLdsT<CM_ROWS_SOLO3>), s, d_jobs);
     else if (variant == CM_VARIANT_SOLO2) launch(k_cm_decode_solo2, dim3(njobs), dim3(64), sizeof(CmLdsT<CM_ROWS_SOLO2>), s, d_jobs);
