@@ -4,7 +4,8 @@
 // cursors.  This is NOT a port of it: the suffix array is built by prefix doubling on top of the
 // stable LSD radix sorter of sort.hip, which is the HBM-streaming formulation the MI355X wants.
 //
-//   round 0 : key(i) = big-endian 8-byte prefix of suffix i (zero padded); sort all n (8 passes)
+//   round 0 : key(i) = the first 8 symbols of suffix i as ranks among the byte values present in the block (0 = past the end),
+//             most significant first; sort all n with one 8-bit LSD pass per bit of a rank (7 passes for text, 8 at most)
 //   round h : every suffix still sharing its h-prefix with another one ("active") gets the 64-bit key
 //             (group << 32) | rank(i + h); only the active elements are sorted, written back to their
 //             group's slots, re-grouped, and the now-unique ones are dropped.  h doubles: 8, 16, 32...
@@ -48,6 +49,55 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bwt_prefix_keys(const u8 * __restr
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         if (base + k < n) keys[base + k] = k == 0 ? a : ((a << (8 * k)) | (b >> (64 - 8 * k)));
+    }
+}
+
+// ---- alphabet compaction (round 2) ------------------------------------------------------------------------------------------
+// The initial sort orders all n suffixes by their first 8 symbols with one LSD radix pass per 8 key bits.  Text uses far fewer than
+// 256 byte values, so the bytes are replaced by their rank among the byte values PRESENT in the block (order-preserving, 1-based;
+// 0 = "past the end", which also makes a suffix that ends inside its 8-symbol prefix sort first right away): with s = present
+// values the 8 symbols need 8 * bits(s) key bits = bits(s) passes instead of 8 (7 for text, 5 for a 16-symbol source).
+__global__ void __launch_bounds__(BW_BLOCK) k_bwt_sym_hist(const u8 * __restrict__ t, u32 n, u32 * __restrict__ hist) {
+    __shared__ u32 bins[256];
+    bins[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * (BW_BLOCK * 64);
+    for (u32 k = 0; k < 64; k++) {
+        const u64 i = base + (u64)k * BW_BLOCK + threadIdx.x;
+        if (i < n) atomicAdd(&bins[t[i]], 1u);
+    }
+    __syncthreads();
+    if (bins[threadIdx.x]) atomicAdd(&hist[threadIdx.x], bins[threadIdx.x]);
+}
+
+// sym[c] (in: count of byte value c) -> 1-based rank of c among the present values (0 if absent); sym[256] = number of present values.
+__global__ void __launch_bounds__(256) k_bwt_sym_map(u32 * __restrict__ sym) {
+    __shared__ u32 lds[256 / WAVE + 1];
+    const u32 present = sym[threadIdx.x] ? 1u : 0u;
+    u32 total;
+    const u32 before = block_excl_add<256>(present, lds, total);
+    sym[threadIdx.x] = present ? before + 1u : 0u;
+    if (threadIdx.x == 0) sym[256] = total;
+}
+
+// 8 keys per thread: key(i) = the ranks of bytes i .. i+7, `bits` bits each, most significant first; 0 past the end.
+__global__ void __launch_bounds__(BW_BLOCK) k_bwt_prefix_keys_mapped(const u8 * __restrict__ t, u32 n, const u32 * __restrict__ sym, u32 bits, u64 * __restrict__ keys) {
+    __shared__ u32 map[256];
+    map[threadIdx.x] = sym[threadIdx.x];
+    __syncthreads();
+    const u64 base = ((u64)blockIdx.x * BW_BLOCK + threadIdx.x) * 8;
+    if (base >= n) return;
+    u32 m[15];
+#pragma unroll
+    for (int k = 0; k < 15; k++) m[k] = (base + k < n) ? map[t[base + k]] : 0u;
+    const u64 mask = (bits * 8u >= 64u) ? ~0ull : ((1ull << (bits * 8u)) - 1ull);
+    u64 key = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) key = (key << bits) | m[k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (base + k < n) keys[base + k] = key;
+        if (k < 7) key = ((key << bits) & mask) | m[k + 8];
     }
 }
 
@@ -127,7 +177,7 @@ static int bits_for(u64 x) {
 
 size_t bwt_workspace_bytes(u64 n) {
     // SA + ISA + 2 keys + 2 vals + 2 slots + 2 scan arrays + radix temp + slack
-    return n * (4 + 4 + 16 + 8 + 8 + 8) + radix_temp_bytes(n) + scan_temp_words(n) * 4 + (1u << 20);
+    return n * (4 + 4 + 16 + 8 + 8 + 8) + radix_temp_bytes(n) + scan_temp_words(n) * 4 + (1u << 20) + 4096;
 }
 
 s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, BwtStats * stats) {
@@ -146,22 +196,40 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     u32 * scanA = tmp.take<u32>(n);
     u32 * headslot = tmp.take<u32>(n);
     u32 * d_words = tmp.take<u32>(4);  // [0] = scan total, [1] = primary index
+    u32 * sym = tmp.take<u32>(264);    // byte value -> rank among the present values; [256] = how many are present
     BwtStats st;
 
     auto grid = [](u64 m) { return dim3((u32)((m + BW_BLOCK - 1) / BW_BLOCK)); };
 
-    // ---- round 0: all suffixes by their 8-byte prefix ------------------------------------------
-    launch(k_bwt_prefix_keys, grid(((u64)n + 7) / 8), dim3(BW_BLOCK), 0, s, d_in, n, key[0]);
+    // ---- round 0: all suffixes by their 8-symbol prefix ------------------------------------------
+    // bytes -> ranks among the byte values present (see k_bwt_sym_map): one LSD pass per bit of a rank instead of 8 passes
+    int key_bits = 64;
+    {
+        HIP_CHECK(hipMemsetAsync(sym, 0, 264 * sizeof(u32), s));
+        launch(k_bwt_sym_hist, grid(((u64)n + 63) / 64), dim3(BW_BLOCK), 0, s, d_in, n, sym);
+        launch(k_bwt_sym_map, dim3(1), dim3(256), 0, s, sym);
+        u32 present = 256;
+        HIP_CHECK(hipMemcpyAsync(&present, sym + 256, 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        const int bits = bits_for(present);  // ranks 0 .. present
+        static const bool plain = getenv("BZ3_BWT_PLAIN") != nullptr;  // experiments: always the plain-byte keys (8 passes)
+        if (bits < 8 && !plain) {
+            key_bits = 8 * bits;
+            launch(k_bwt_prefix_keys_mapped, grid(((u64)n + 7) / 8), dim3(BW_BLOCK), 0, s, d_in, n, (const u32 *)sym, (u32)bits, key[0]);
+        } else {  // (nearly) every byte value occurs: the bytes themselves, zero padded
+            launch(k_bwt_prefix_keys, grid(((u64)n + 7) / 8), dim3(BW_BLOCK), 0, s, d_in, n, key[0]);
+        }
+    }
     int cur = 0;
     {
         // first pass generates the suffix numbers on the fly (iota), later passes carry them
         radix_pass<u64>(key[0], key[1], (const u32 *)nullptr, val[1], n, 0, 0xFFFFFFFFu, 0u, tmp, s);
         cur = 1;
-        for (int shift = 8; shift < 64; shift += 8) {
+        for (int shift = 8; shift < key_bits; shift += 8) {
             radix_pass<u64>(key[cur], key[cur ^ 1], (const u32 *)val[cur], val[cur ^ 1], n, shift, 0xFFFFFFFFu, 0u, tmp, s);
             cur ^= 1;
         }
-        st.radix_passes += 8;
+        st.radix_passes += key_bits / 8;
         st.sorted_elements += n;
     }
     u32 m = n;              // elements in the current (sorted) active list

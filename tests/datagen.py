@@ -170,4 +170,11 @@ def nasty_cases():
         holes[k] = 35 + (k % 7)
     cases["holes"] = bytes(holes)
     cases["ff"] = b"\xff" * 700 + b"\xfe" * 300 + b"\xff" * 255
+    # alphabet sizes around the limits of the suffix sorter's alphabet compaction (ranks of the byte values present: 127 values still
+    # fit 7 bits next to the past-the-end rank 0, 128 do not; 255 / 256 values take the plain-byte path), zero bytes next to the end
+    for sigma in (127, 128, 255, 256):
+        vals = np.sort(rng.permutation(256)[:sigma]).astype(np.uint8)
+        body = vals[rng.integers(0, sigma, size=3000)]
+        cases["alpha%d" % sigma] = bytes(np.concatenate([vals, body, vals[::-1]]))
+    cases["zerotail"] = b"ab\0ab\0\0ab" * 40 + b"ab\0\0\0\0\0\0\0"
     return cases
