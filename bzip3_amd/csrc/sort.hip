@@ -88,6 +88,19 @@ constexpr int RS_WAVES = RS_BLOCK / WAVE;          // 4
 constexpr int RS_ROUNDS = RS_TILE / RS_BLOCK;      // 16 rounds of 64 keys per wave
 constexpr int RS_WAVE_SPAN = RS_TILE / RS_WAVES;   // 1024 keys per wave
 
+// XCD-aware tile assignment.  The dispatcher places workgroup b on XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup dispatch"; a
+// speed assumption only: every tile is processed exactly once whatever the placement), and every XCD has its own L2.  A radix
+// scatter writes ~16 keys of a tile to each of 256 bucket regions; the tiles that fill the neighbouring bytes of a cache line are
+// the NEXT tiles.  With tile = blockIdx they sit on the other seven XCDs and every L2 writes its partial lines back on its own
+// (measured in round 1: 4.6x write amplification); with a contiguous range of tiles per XCD they merge in one L2.
+// The grid is 8 * ceil(tiles / 8) workgroups; the padded ones (tile >= tiles) leave at once.
+__device__ __forceinline__ u32 rs_tile_of_block(u32 b, u32 tiles, bool xcd) {
+    if (!xcd) return b;
+    const u32 per = (tiles + 7u) / 8u;
+    return (b & 7u) * per + (b >> 3);
+}
+inline u32 rs_grid(u32 tiles, bool xcd) { return xcd ? 8u * ((tiles + 7u) / 8u) : tiles; }
+
 template <typename K>
 __device__ __forceinline__ u32 rs_digit(K key, int shift) {
     return (u32)(key >> shift) & 0xFFu;
@@ -112,15 +125,17 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_hist(const K * __restrict__ key
 template <typename K, bool IOTA, bool WKEYS>
 __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const K * __restrict__ kin, K * __restrict__ kout, const u32 * __restrict__ vin,
                                                         u32 * __restrict__ vout, u64 n, int shift, const u32 * __restrict__ offs, u32 tiles,
-                                                        u32 iota_split, u32 out_base) {
+                                                        u32 iota_split, u32 out_base, u32 xcd) {
     __shared__ u32 cnt[RS_WAVES][RS_RADIX];
     __shared__ u32 gbase[RS_RADIX];
+    const u32 tile = rs_tile_of_block(blockIdx.x, tiles, xcd != 0u);
+    if (tile >= tiles) return;
     const int w = wave_id(), l = lane_id();
 #pragma unroll
     for (int k = 0; k < RS_WAVES; k++) cnt[k][threadIdx.x] = 0;
     __syncthreads();
 
-    const u64 tile_base = (u64)blockIdx.x * RS_TILE;
+    const u64 tile_base = (u64)tile * RS_TILE;
     const u64 wbase = tile_base + (u64)w * RS_WAVE_SPAN + l;
     K key[RS_ROUNDS];
     u32 local[RS_ROUNDS];
@@ -156,7 +171,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const K * __restrict__ 
             cnt[k][d] = run;
             run += c;
         }
-        gbase[d] = offs[(u64)d * tiles + blockIdx.x] + out_base;
+        gbase[d] = offs[(u64)d * tiles + tile] + out_base;
     }
     __syncthreads();
 #pragma unroll
@@ -181,14 +196,16 @@ void radix_pass(const K * kin, K * kout, const u32 * vin, u32 * vout, u64 n, int
     launch(k_rs_hist<K>, dim3(tiles), dim3(RS_BLOCK), 0, s, kin, n, shift, hist, tiles);
     exclusive_scan_u32(hist, (u64)tiles * RS_RADIX, nullptr, tmp, s);
     const bool iota = vin == nullptr, wkeys = kout != nullptr;
+    static const u32 xcd = getenv("BZ3_RS_NO_XCD") ? 0u : 1u;  // experiments: BZ3_RS_NO_XCD=1 = tile = blockIdx
+    const dim3 sgrid(rs_grid(tiles, xcd != 0u));
     if (iota && wkeys)
-        launch(k_rs_scatter<K, true, true>, dim3(tiles), dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base);
+        launch(k_rs_scatter<K, true, true>, sgrid, dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base, xcd);
     else if (iota)
-        launch(k_rs_scatter<K, true, false>, dim3(tiles), dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base);
+        launch(k_rs_scatter<K, true, false>, sgrid, dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base, xcd);
     else if (wkeys)
-        launch(k_rs_scatter<K, false, true>, dim3(tiles), dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base);
+        launch(k_rs_scatter<K, false, true>, sgrid, dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base, xcd);
     else
-        launch(k_rs_scatter<K, false, false>, dim3(tiles), dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base);
+        launch(k_rs_scatter<K, false, false>, sgrid, dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base, xcd);
     tmp.release(m);
 }
 
