@@ -194,6 +194,32 @@ def gen_text_piece(torch, nbytes, seed, device):
     return out
 
 
+def seed_text_source(lib):
+    """The Markov generator's token table comes from the plaintext of the reference's fixture (tests/golden/shakespeare.txt.bz3).
+    tests/datagen.py recovers it with the CPU checker; here the PRODUCT decodes it (two blocks through bz3_decode_block), so that
+    nothing of bench.py's workload depends on oracle/ -- only the cpu_baseline leg uses the checker, as a baseline."""
+    import hashlib
+
+    import bzip3_amd
+    import datagen
+
+    if "txt" in datagen._cache:
+        return
+    try:
+        raw = open(os.path.join(datagen.GOLDEN, "shakespeare.txt.bz3"), "rb").read()
+        bs, chunks = datagen.parse_chunks(raw)
+        parts = []
+        for comp, orig, blk in chunks:
+            n, err, dec = bzip3_amd.decode_block(blk, orig, bs, lib)
+            assert n == orig and err == 0
+            parts.append(dec)
+        data = b"".join(parts)
+        assert hashlib.md5(data).hexdigest() == datagen.SHAKESPEARE_MD5
+        datagen._cache["txt"] = data
+    except Exception as e:  # fall back to datagen's own path
+        progress(f"fixture decode through the product failed ({e}); tests/datagen.py recovers the text instead")
+
+
 def fingerprint(torch, t):
     """Position-sensitive 64-bit fingerprint of a uint8 tensor (a permuted or shifted block does not pass):
     sum over 32-bit words of word * (1 + index mod 1000003), in chunks of 64 MiB."""
@@ -318,6 +344,8 @@ def main():
 
     block_size = int(a.block_mib * (1 << 20))
     cap = lib.bz3_bound(block_size) + 4096
+    if a.kind == "text":
+        seed_text_source(lib)
 
     # ---- synthetic input, resident in HBM ----------------------------------------------------------------
     t_gen = time.perf_counter()
