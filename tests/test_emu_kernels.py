@@ -594,3 +594,36 @@ print("ok")
 ''' % (os.path.dirname(HERE), HERE, os.path.join(HERE, "emu"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BZ3_EMU_DEVICES="2"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-300:], r.stderr[-1200:])
+
+
+def test_auto_cm_policy_and_encode_many_hook(oracle):
+    """The automatic CM policy by batch size (api.hip cm_variant_for; BZ3_HIP_CUS=2 pretends the GPU has two CUs): up to one block per CU
+    the whole-model kernels with the barrier-synchronised decoder (5), up to two per CU the 96-row pair (6), beyond that the three-per-CU
+    pair (7); a forced mode wins.  And the profiling hook that launches N copies of one CM encode job returns the oracle's bytes."""
+    import subprocess
+
+    code = r'''
+import sys, ctypes as C
+sys.path[:0] = [%r, %r, %r]
+import bzip3_amd, datagen
+from build_emu import build
+from oracle_lib import Oracle
+lib = bzip3_amd._declare(C.CDLL(build()))
+assert lib.bz3_hip_cm_variant_for(0, 1, 0) == 5 and lib.bz3_hip_cm_variant_for(0, 2, 1) == 5
+assert lib.bz3_hip_cm_variant_for(0, 3, 0) == 6 and lib.bz3_hip_cm_variant_for(0, 4, 1) == 6
+assert lib.bz3_hip_cm_variant_for(0, 5, 0) == 7 and lib.bz3_hip_cm_variant_for(0, 700, 1) == 7
+assert lib.bz3_hip_cm_variant_for(9, 5, 0) == -1
+assert lib.bz3_hip_set_cm_mode(3) == 0 and lib.bz3_hip_cm_variant_for(0, 1, 0) == 3
+assert lib.bz3_hip_set_cm_mode(-1) == 0
+o = Oracle()
+d = o.bwt(datagen.shakespeare()[200000:201200])[1]
+want = o.cm_encode(d)
+out = (C.c_uint8 * (lib.bz3_bound(len(d)) + 64))()
+coded = C.c_int32(0)
+for copies in (1, 3, 5):  # whole-model, rows and rows3 encoders
+    ms = lib.bz3_hip_stage_cm_encode_many(bzip3_amd._cbuf(d, len(d)), len(d), out, C.byref(coded), copies)
+    assert ms >= 0 and bytes(out[: coded.value]) == want, copies
+print("ok")
+''' % (os.path.dirname(HERE), HERE, os.path.join(HERE, "emu"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BZ3_HIP_CUS="2"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-300:], r.stderr[-1200:])
