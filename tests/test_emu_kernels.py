@@ -627,3 +627,41 @@ print("ok")
 ''' % (os.path.dirname(HERE), HERE, os.path.join(HERE, "emu"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BZ3_HIP_CUS="2"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-300:], r.stderr[-1200:])
+
+
+def test_pipelined_windows_of_a_large_batch(emu, oracle):
+    """A batch larger than the encoder's front-end windows (8 blocks: the LZP drivers of window k run on the device's second stream beside the
+    preparation of window k+1 and the completion of window k-1, over two context slots) and than the decoder's tail windows (32 blocks: LZP
+    decoders beside the next window's inverse BWTs): every block equals the oracle's both ways, with LZP applied, declined and skipped."""
+    bs = 65 * 1024
+    t = datagen.shakespeare()
+    blocks = []
+    for i in range(36):
+        if i % 5 == 3:
+            blocks.append((t[i * 400 : i * 400 + 150] * 3) + t[9000:9100])   # repeats: LZP applies (model & 2)
+        elif i % 7 == 6:
+            blocks.append(b"x" * (20 + i))                                   # stored (< 64 bytes)
+        else:
+            blocks.append(t[i * 400 : i * 400 + 260 + 7 * i])
+    n = len(blocks)
+    states = (C.c_void_p * n)(*[emu.bz3_new(bs) for _ in range(n)])
+    cap = emu.bz3_bound(bs) + 64
+    bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+    for b, d in zip(bufs, blocks):
+        C.memmove(b, d, len(d))
+    ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+    emu.bz3_encode_blocks(states, ptrs, sizes, n)
+    models = set()
+    for i, d in enumerate(blocks):
+        want = oracle.encode_block(d, bs)[2]
+        assert bytes(bufs[i][: sizes[i]]) == want, i
+        models.add(want[8] if len(d) >= 64 else -1)
+    assert {-1, 0, 2} <= models  # stored, plain and LZP-coded blocks all went through the windows
+    bsz = (C.c_size_t * n)(*[cap] * n)
+    orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+    emu.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+    for i, d in enumerate(blocks):
+        assert emu.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: len(d)]) == d, i
+    for s in states:
+        emu.bz3_free(s)
