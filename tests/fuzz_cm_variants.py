@@ -2,7 +2,9 @@
 lock-step decoders) against the oracle on random sources (Zipf alphabets of 2-255 symbols, BWT output of text, runs, noise),
 truncated streams included, plus block round trips with classic and lean states.  Not collected by pytest:
     python tests/fuzz_cm_variants.py <seed> <seconds>
-Round 1: seeds 1-3 x 2400 s = 2,389 stage iterations + 341 block round trips, 0 mismatches."""
+Round 1: seeds 1-3 x 2400 s = 2,389 stage iterations + 341 block round trips, 0 mismatches.
+Round 2 (sync / solo decoders, structure-of-arrays encoder ring added): seeds 61-66 x 2400 s, four of them with BZ3_EMU_SCHED = -3 / -9 / 7 / -21:
+4,541 stage iterations + 648 block round trips, 0 mismatches."""
 import sys, os, time, ctypes as C
 HERE = os.path.dirname(os.path.abspath(__file__)); sys.path[:0] = [os.path.dirname(HERE), HERE, os.path.join(HERE, 'emu')]
 import numpy as np
