@@ -46,7 +46,7 @@ BZIP3_API int bz3_hip_set_cm_mode(int mode);
 /* Number of blocks the row-cache kernels have handed back to the full-model kernels so far (statistics). */
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void);
 
-/* The CM kernel variant (0..4 as above) a batch of `blocks` blocks on `device` is coded (encode != 0) or decoded with under the
+/* The CM kernel variant (0..8, 12 as above) a batch of `blocks` blocks on `device` is coded (encode != 0) or decoded with under the
  * current mode; -1 for an invalid device. */
 BZIP3_API int bz3_hip_cm_variant_for(int device, int blocks, int encode);
 
