@@ -34,9 +34,14 @@ __device__ __forceinline__ u64 bswap64(u64 v) {
 
 __device__ __forceinline__ u64 load_be64_padded(const u8 * __restrict__ t, u64 i, u64 n) {
     if (i + 8 <= n && ((reinterpret_cast<uintptr_t>(t) + i) & 7) == 0) return bswap64(*reinterpret_cast<const u64 *>(t + i));
+    if (i >= n) return 0;
+    const u64 last = n - 1;
+    u8 c[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) c[k] = t[i + k < n ? i + k : last];  // in flight together (see sort.hip), masked below
     u64 v = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) v = (v << 8) | (i + k < n ? (u64)t[i + k] : 0ull);
+    for (int k = 0; k < 8; k++) v = (v << 8) | (i + k < n ? (u64)c[k] : 0ull);
     return v;
 }
 
@@ -61,10 +66,22 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bwt_sym_hist(const u8 * __restrict
     __shared__ u32 bins[256];
     bins[threadIdx.x] = 0;
     __syncthreads();
+    // 64 bytes per thread, 16 at a time, every load of a group in flight before the first is counted (sort.hip explains why the
+    // obvious `if (i < n) ... t[i]` loop is one exposed HBM round trip per byte); index clamped, lane masked.
     const u64 base = (u64)blockIdx.x * (BW_BLOCK * 64);
-    for (u32 k = 0; k < 64; k++) {
-        const u64 i = base + (u64)k * BW_BLOCK + threadIdx.x;
-        if (i < n) atomicAdd(&bins[t[i]], 1u);
+    const u64 last = (u64)n - 1;
+    for (u32 g = 0; g < 4; g++) {
+        u8 c[16];
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) {
+            const u64 i = base + (u64)(g * 16 + k) * BW_BLOCK + threadIdx.x;
+            c[k] = t[i < n ? i : last];
+        }
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) {
+            const u64 i = base + (u64)(g * 16 + k) * BW_BLOCK + threadIdx.x;
+            if (i < n) atomicAdd(&bins[c[k]], 1u);
+        }
     }
     __syncthreads();
     if (bins[threadIdx.x]) atomicAdd(&hist[threadIdx.x], bins[threadIdx.x]);
@@ -87,9 +104,23 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bwt_prefix_keys_mapped(const u8 * 
     __syncthreads();
     const u64 base = ((u64)blockIdx.x * BW_BLOCK + threadIdx.x) * 8;
     if (base >= n) return;
+    const u64 last = (u64)n - 1;
+    u8 c[16];
+    if (base + 16 <= n && ((reinterpret_cast<uintptr_t>(t) + base) & 7) == 0) {  // two aligned 8-byte loads (little endian)
+        const u64 a = *reinterpret_cast<const u64 *>(t + base);
+        const u64 b = *reinterpret_cast<const u64 *>(t + base + 8);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            c[k] = (u8)(a >> (8 * k));
+            c[k + 8] = (u8)(b >> (8 * k));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 15; k++) c[k] = t[base + k < n ? base + k : last];  // 15 loads in flight, then the table look-ups
+    }
     u32 m[15];
 #pragma unroll
-    for (int k = 0; k < 15; k++) m[k] = (base + k < n) ? map[t[base + k]] : 0u;
+    for (int k = 0; k < 15; k++) m[k] = (base + k < n) ? map[c[k]] : 0u;
     const u64 mask = (bits * 8u >= 64u) ? ~0ull : ((1ull << (bits * 8u)) - 1ull);
     u64 key = 0;
 #pragma unroll

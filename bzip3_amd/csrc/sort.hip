@@ -10,6 +10,12 @@
 //                  tile is walked wave-striped (wave w owns keys [1024w, 1024w+1024), 16 rounds of
 //                  64 consecutive keys) so the order of equal digits is preserved: the pass is stable.
 // Algorithmic traffic per pass and element: sizeof(K) (hist) + sizeof(K)+4 (read) + sizeof(K)+4 (write).
+//
+// Memory-level parallelism (round 2, found in the ISA): a load written as `if (i < n) x = p[i]` inside an unrolled loop compiles to
+// a branch around the load and an `s_waitcnt vmcnt(0)` before its first use, i.e. ONE load in flight per wave and one exposed HBM
+// round trip per round -- 16 (+16 for the values) per tile in the first version of k_rs_scatter, which is what held it at
+// ~1 TB/s.  Every streaming kernel here therefore issues ALL loads of its tile first, branch-free (the index is clamped to n-1
+// and the lane masked afterwards), and only then starts to consume them.
 #include "prims.hpp"
 #include "sort.hpp"
 
@@ -22,13 +28,32 @@ constexpr int SC_BLOCK = 256;
 constexpr int SC_ITEMS = 8;
 constexpr int SC_TILE = SC_BLOCK * SC_ITEMS;
 
+// The SC_ITEMS consecutive values of a thread: two 16-byte loads when the tile is whole and aligned, clamped scalar loads (all in
+// flight together, see the note on memory-level parallelism above) otherwise.  Values past n read as 0.
+__device__ __forceinline__ void scan_load_items(const u32 * __restrict__ data, u64 n, u64 base, u32 (&v)[SC_ITEMS]) {
+    static_assert(SC_ITEMS == 8, "two uint4 per thread");
+    if (base + SC_ITEMS <= n && (reinterpret_cast<uintptr_t>(data) & 15u) == 0) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(data + base);
+        const uint4 b = *reinterpret_cast<const uint4 *>(data + base + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        const u64 last = n - 1;  // n >= 1: the scan is never launched on nothing
+#pragma unroll
+        for (int k = 0; k < SC_ITEMS; k++) v[k] = data[base + k < n ? base + k : last];
+#pragma unroll
+        for (int k = 0; k < SC_ITEMS; k++) v[k] = base + k < n ? v[k] : 0u;
+    }
+}
+
 __global__ void __launch_bounds__(SC_BLOCK) k_scan_reduce(const u32 * __restrict__ data, u64 n, u32 * __restrict__ sums) {
     __shared__ u32 lds[SC_BLOCK / WAVE + 1];
     const u64 base = (u64)blockIdx.x * SC_TILE + (u64)threadIdx.x * SC_ITEMS;
+    u32 v[SC_ITEMS];
+    scan_load_items(data, n, base, v);
     u32 acc = 0;
 #pragma unroll
-    for (int k = 0; k < SC_ITEMS; k++)
-        if (base + k < n) acc += data[base + k];
+    for (int k = 0; k < SC_ITEMS; k++) acc += v[k];
     u32 tot = block_sum<SC_BLOCK>(acc, lds);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
@@ -39,19 +64,25 @@ __global__ void __launch_bounds__(SC_BLOCK) k_scan_apply(u32 * __restrict__ data
     __shared__ u32 lds[SC_BLOCK / WAVE + 1];
     const u64 base = (u64)blockIdx.x * SC_TILE + (u64)threadIdx.x * SC_ITEMS;
     u32 v[SC_ITEMS];
+    scan_load_items(data, n, base, v);
     u32 acc = 0;
 #pragma unroll
-    for (int k = 0; k < SC_ITEMS; k++) {
-        v[k] = (base + k < n) ? data[base + k] : 0u;
-        acc += v[k];
-    }
+    for (int k = 0; k < SC_ITEMS; k++) acc += v[k];
     u32 tot;
     u32 pre = block_excl_add<SC_BLOCK>(acc, lds, tot);
     if (sums) pre += sums[blockIdx.x];
+    if (base + SC_ITEMS <= n && (reinterpret_cast<uintptr_t>(data) & 15u) == 0) {
+        uint4 a, b;
+        a.x = pre; a.y = a.x + v[0]; a.z = a.y + v[1]; a.w = a.z + v[2];
+        b.x = a.w + v[3]; b.y = b.x + v[4]; b.z = b.y + v[5]; b.w = b.z + v[6];
+        *reinterpret_cast<uint4 *>(data + base) = a;
+        *reinterpret_cast<uint4 *>(data + base + 4) = b;
+    } else {
 #pragma unroll
-    for (int k = 0; k < SC_ITEMS; k++) {
-        if (base + k < n) data[base + k] = pre;
-        pre += v[k];
+        for (int k = 0; k < SC_ITEMS; k++) {
+            if (base + k < n) data[base + k] = pre;
+            pre += v[k];
+        }
     }
     if (total_out && gridDim.x == 1 && threadIdx.x == 0) *total_out = tot;
 }
@@ -107,19 +138,30 @@ __device__ __forceinline__ u32 rs_digit(K key, int shift) {
 }
 
 template <typename K>
-__global__ void __launch_bounds__(RS_BLOCK) k_rs_hist(const K * __restrict__ keys, u64 n, int shift, u32 * __restrict__ hist, u32 tiles) {
+__global__ void __launch_bounds__(RS_BLOCK) k_rs_hist(const K * __restrict__ keys, u64 n, int shift, u32 * __restrict__ hist, u32 tiles, u32 xcd) {
     __shared__ u32 bins[RS_RADIX];
+    // same tile assignment as the scatter: the counts of neighbouring tiles are neighbouring words of the digit-major table, so
+    // the tiles of one XCD fill whole lines of it in that XCD's L2 (and the scatter finds its tile's keys in the L2 that read them)
+    const u32 tile = rs_tile_of_block(blockIdx.x, tiles, xcd != 0u);
+    if (tile >= tiles) return;
     bins[threadIdx.x] = 0;
     __syncthreads();
-    const u64 tile_base = (u64)blockIdx.x * RS_TILE;
+    const u64 tile_base = (u64)tile * RS_TILE;
     const u64 wbase = tile_base + (u64)wave_id() * RS_WAVE_SPAN + lane_id();
-#pragma unroll 4
+    const u64 last = n - 1;
+    K key[RS_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {  // all 16 loads in flight before the first LDS atomic
+        const u64 i = wbase + (u64)r * WAVE;
+        key[r] = keys[i < n ? i : last];
+    }
+#pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const u64 i = wbase + (u64)r * WAVE;
-        if (i < n) atomicAdd(&bins[rs_digit(keys[i], shift)], 1u);
+        if (i < n) atomicAdd(&bins[rs_digit(key[r], shift)], 1u);
     }
     __syncthreads();
-    hist[(u64)threadIdx.x * tiles + blockIdx.x] = bins[threadIdx.x];
+    hist[(u64)threadIdx.x * tiles + tile] = bins[threadIdx.x];
 }
 
 template <typename K, bool IOTA, bool WKEYS>
@@ -140,12 +182,18 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const K * __restrict__ 
     K key[RS_ROUNDS];
     u32 local[RS_ROUNDS];
     const u64 lt = lanemask_lt();
+    const u64 last = n - 1;
 
+    // every key of the tile is requested before the ranking starts (branch-free: clamped index, the lane is masked below)
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const u64 i = wbase + (u64)r * WAVE;
+        key[r] = kin[i < n ? i : last];
+    }
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const u64 i = wbase + (u64)r * WAVE;
         const bool valid = i < n;
-        key[r] = valid ? kin[i] : (K)0;
         const u32 d = rs_digit(key[r], shift);
         u64 peers = __ballot(valid);
 #pragma unroll
@@ -161,6 +209,13 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const K * __restrict__ 
         wave_sync();
         local[r] = pre + below;
     }
+    // the values travel while the per-wave counts are turned into offsets
+    u32 val[RS_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const u64 i = wbase + (u64)r * WAVE;
+        val[r] = IOTA ? (u32)i + ((u32)i >= iota_split ? 1u : 0u) : vin[i < n ? i : last];
+    }
     __syncthreads();
     {
         const u32 d = threadIdx.x;
@@ -174,14 +229,122 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const K * __restrict__ 
         gbase[d] = offs[(u64)d * tiles + tile] + out_base;
     }
     __syncthreads();
+    // destinations first (32 LDS reads in flight together; a masked lane reads some valid counter and ignores it), stores after.
+    // A destination is < n + out_base, and n < 2^32 by the API (block sizes are int32).
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const u32 d = rs_digit(key[r], shift);
+        local[r] += gbase[d] + cnt[w][d];
+    }
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const u64 i = wbase + (u64)r * WAVE;
         if (i < n) {
-            const u32 d = rs_digit(key[r], shift);
-            const u64 pos = (u64)gbase[d] + cnt[w][d] + local[r];
-            if (WKEYS) kout[pos] = key[r];
-            vout[pos] = IOTA ? (u32)i + ((u32)i >= iota_split ? 1u : 0u) : vin[i];
+            if (WKEYS) kout[local[r]] = key[r];
+            vout[local[r]] = val[r];
+        }
+    }
+}
+
+// Opt-in variant (BZ3_RS_STAGED=1; NOT the default until it has been measured on the GPU): the tile is first put in digit order in
+// LDS, then written out with consecutive lanes on consecutive destinations -- a digit's ~16 keys of a tile leave as one run instead
+// of 16 separate 8-byte stores (round 1 measured 4.6x write amplification for the direct scatter; an earlier staged version showed
+// "no gain" at a time when the serialised loads above were what bounded the kernel, so the comparison has to be repeated).
+// Same arguments, same result: slot of a key inside the tile = start of its digit + keys of that digit in earlier waves + rank in
+// its own wave, which is the stable order.  LDS: sizeof(K) * 4096 + 16 KiB + 6 KiB (54 KiB for 8-byte keys: two workgroups per CU).
+template <typename K, bool IOTA, bool WKEYS>
+__global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter_staged(const K * __restrict__ kin, K * __restrict__ kout, const u32 * __restrict__ vin,
+                                                               u32 * __restrict__ vout, u64 n, int shift, const u32 * __restrict__ offs, u32 tiles,
+                                                               u32 iota_split, u32 out_base, u32 xcd) {
+    __shared__ u32 cnt[RS_WAVES][RS_RADIX];
+    __shared__ u32 dstart[RS_RADIX];   // first slot of a digit inside the tile
+    __shared__ u32 gdelta[RS_RADIX];   // global destination of a digit's first key - dstart (mod 2^32)
+    __shared__ u32 scan_lds[RS_BLOCK / WAVE + 1];
+    __shared__ K skey[RS_TILE];
+    __shared__ u32 sval[RS_TILE];
+    const u32 tile = rs_tile_of_block(blockIdx.x, tiles, xcd != 0u);
+    if (tile >= tiles) return;
+    const int w = wave_id(), l = lane_id();
+#pragma unroll
+    for (int k = 0; k < RS_WAVES; k++) cnt[k][threadIdx.x] = 0;
+    __syncthreads();
+
+    const u64 tile_base = (u64)tile * RS_TILE;
+    const u64 wbase = tile_base + (u64)w * RS_WAVE_SPAN + l;
+    K key[RS_ROUNDS];
+    u32 local[RS_ROUNDS];
+    const u64 lt = lanemask_lt();
+    const u64 last = n - 1;
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const u64 i = wbase + (u64)r * WAVE;
+        key[r] = kin[i < n ? i : last];
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const u64 i = wbase + (u64)r * WAVE;
+        const bool valid = i < n;
+        const u32 d = rs_digit(key[r], shift);
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const u64 bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const u32 below = (u32)__popcll(peers & lt);
+        const u32 pre = valid ? cnt[w][d] : 0u;
+        wave_sync();
+        if (valid && below == 0) cnt[w][d] = pre + (u32)__popcll(peers);
+        wave_sync();
+        local[r] = pre + below;
+    }
+    u32 val[RS_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const u64 i = wbase + (u64)r * WAVE;
+        val[r] = IOTA ? (u32)i + ((u32)i >= iota_split ? 1u : 0u) : vin[i < n ? i : last];
+    }
+    __syncthreads();
+    {
+        const u32 d = threadIdx.x;
+        u32 run = 0;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; k++) {
+            u32 c = cnt[k][d];
+            cnt[k][d] = run;
+            run += c;
+        }
+        u32 total;
+        const u32 start = block_excl_add<RS_BLOCK>(run, scan_lds, total);  // ends with a barrier
+        dstart[d] = start;
+        gdelta[d] = offs[(u64)d * tiles + tile] + out_base - start;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const u32 d = rs_digit(key[r], shift);
+        local[r] += dstart[d] + cnt[w][d];
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const u64 i = wbase + (u64)r * WAVE;
+        if (i < n) {
+            skey[local[r]] = key[r];
+            sval[local[r]] = val[r];
+        }
+    }
+    __syncthreads();
+    const u64 left = n - tile_base;
+    const u32 count = left < (u64)RS_TILE ? (u32)left : (u32)RS_TILE;
+#pragma unroll
+    for (int q = 0; q < RS_ROUNDS; q++) {
+        const u32 j = (u32)q * RS_BLOCK + threadIdx.x;
+        if (j < count) {
+            const K k = skey[j];
+            const u32 pos = gdelta[rs_digit(k, shift)] + j;
+            if (WKEYS) kout[pos] = k;
+            vout[pos] = sval[j];
         }
     }
 }
@@ -193,19 +356,27 @@ void radix_pass(const K * kin, K * kout, const u32 * vin, u32 * vout, u64 n, int
     const u32 tiles = (u32)((n + RS_TILE - 1) / RS_TILE);
     size_t m = tmp.mark();
     u32 * hist = tmp.take<u32>((size_t)tiles * RS_RADIX);
-    launch(k_rs_hist<K>, dim3(tiles), dim3(RS_BLOCK), 0, s, kin, n, shift, hist, tiles);
-    exclusive_scan_u32(hist, (u64)tiles * RS_RADIX, nullptr, tmp, s);
-    const bool iota = vin == nullptr, wkeys = kout != nullptr;
     static const u32 xcd = getenv("BZ3_RS_NO_XCD") ? 0u : 1u;  // experiments: BZ3_RS_NO_XCD=1 = tile = blockIdx
     const dim3 sgrid(rs_grid(tiles, xcd != 0u));
-    if (iota && wkeys)
-        launch(k_rs_scatter<K, true, true>, sgrid, dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base, xcd);
-    else if (iota)
-        launch(k_rs_scatter<K, true, false>, sgrid, dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base, xcd);
-    else if (wkeys)
-        launch(k_rs_scatter<K, false, true>, sgrid, dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base, xcd);
+    launch(k_rs_hist<K>, sgrid, dim3(RS_BLOCK), 0, s, kin, n, shift, hist, tiles, xcd);
+    exclusive_scan_u32(hist, (u64)tiles * RS_RADIX, nullptr, tmp, s);
+    const bool iota = vin == nullptr, wkeys = kout != nullptr;
+    static const bool staged = getenv("BZ3_RS_STAGED") != nullptr;  // experiments: the LDS-staged scatter (see k_rs_scatter_staged)
+#define BZ3_RS_LAUNCH(KERNEL, I, W) \
+    launch(KERNEL<K, I, W>, sgrid, dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base, xcd)
+#define BZ3_RS_DISPATCH(KERNEL)                           \
+    do {                                                  \
+        if (iota && wkeys) BZ3_RS_LAUNCH(KERNEL, true, true);        \
+        else if (iota) BZ3_RS_LAUNCH(KERNEL, true, false);           \
+        else if (wkeys) BZ3_RS_LAUNCH(KERNEL, false, true);          \
+        else BZ3_RS_LAUNCH(KERNEL, false, false);                    \
+    } while (0)
+    if (staged)
+        BZ3_RS_DISPATCH(k_rs_scatter_staged);
     else
-        launch(k_rs_scatter<K, false, false>, sgrid, dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base, xcd);
+        BZ3_RS_DISPATCH(k_rs_scatter);
+#undef BZ3_RS_DISPATCH
+#undef BZ3_RS_LAUNCH
     tmp.release(m);
 }
 

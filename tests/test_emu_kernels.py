@@ -665,3 +665,33 @@ def test_pipelined_windows_of_a_large_batch(emu, oracle):
         assert emu.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: len(d)]) == d, i
     for s in states:
         emu.bz3_free(s)
+
+
+@pytest.mark.parametrize("env", [{"BZ3_RS_STAGED": "1"}, {"BZ3_RS_STAGED": "1", "BZ3_RS_NO_XCD": "1"}, {"BZ3_RS_NO_XCD": "1"}], ids=["staged", "staged_noxcd", "noxcd"])
+def test_opt_in_radix_scatter_variants(oracle, env):
+    """The experiment switches of the radix sorter (sort.hip: BZ3_RS_STAGED = LDS-staged scatter, BZ3_RS_NO_XCD = tile = blockIdx)
+    are read once per process, so they get a process of their own: the three stages that sort (LZP links: u32 keys, BWT: u64 keys,
+    inverse BWT: u8 keys without key output, destinations shifted by one) give the oracle's bytes on whole tiles, ragged tails and
+    inputs smaller than a tile."""
+    import subprocess
+
+    code = r'''
+import sys, ctypes as C
+sys.path[:0] = [%r, %r, %r]
+import bzip3_amd, datagen
+from build_emu import build
+from oracle_lib import Oracle
+g = bzip3_amd.StageApi(bzip3_amd._declare(C.CDLL(build())))
+o = Oracle()
+t = datagen.shakespeare()
+cases = [t[1000:1000 + 4096 * 3], t[5000:5000 + 4096 * 2 + 17], t[:4095], t[:4097], t[:300], b"ab", datagen.random_bytes(9000),
+         datagen.low_entropy(12000), datagen.repeats(30000), bytes(8192), bytes(range(256)) * 40]
+for d in cases:
+    assert g.lzp_encode(d) == o.lzp_encode(d), len(d)
+    assert g.bwt(d) == o.bwt(d), len(d)
+    idx, u = o.bwt(d)
+    assert g.unbwt(u, idx) == (0, d), len(d)
+print("ok")
+''' % (os.path.dirname(HERE), HERE, os.path.join(HERE, "emu"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-300:], r.stderr[-1200:])
