@@ -13,6 +13,8 @@
 // bz3_new() returns NULL and the stage hooks abort loudly.
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <exception>
 #include <mutex>
 #include <new>
@@ -49,15 +51,17 @@ struct DeviceCtx {
     char * ws = nullptr;
     size_t ws_cap = 0;
     int cus = 256;          // compute units: one full-model CM workgroup fits per CU
-    // second stream of the device: the serial LZP drivers of one window of blocks run there while the calling thread drives
-    // the whole-GPU stages of the neighbouring windows on the group's stream (encode_group)
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_prep = nullptr, ev_d0[2] = {nullptr, nullptr}, ev_d1[2] = {nullptr, nullptr};
+    // side streams of the device: the serial LZP drivers of a window of blocks run there while the calling thread drives the
+    // whole-GPU stages of the neighbouring windows on the group's stream (encode_group: one side stream per context slot, so
+    // that the drivers of consecutive windows overlap; decode_group: aux[0] for both of its windows)
+    static constexpr int AUX = 4;
+    hipStream_t aux[AUX] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_prep = nullptr, ev_d0[AUX] = {nullptr, nullptr, nullptr, nullptr}, ev_d1[AUX] = {nullptr, nullptr, nullptr, nullptr};
     void ensure_aux() {  // caller holds mu
-        if (aux) return;
-        HIP_CHECK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        if (aux[0]) return;
         HIP_CHECK(hipEventCreate(&ev_prep));
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < AUX; k++) {
+            HIP_CHECK(hipStreamCreateWithFlags(&aux[k], hipStreamNonBlocking));
             HIP_CHECK(hipEventCreate(&ev_d0[k]));
             HIP_CHECK(hipEventCreate(&ev_d1[k]));
         }
@@ -370,12 +374,15 @@ struct DeviceGuard {
 // A group call that is left by an exception must not leave kernels in flight on either stream of the device: the caller is about to
 // hand borrowed swap buffers back to the pool and to reuse the arena (the serial LZP kernels run on the second stream).
 struct DrainOnUnwind {
-    hipStream_t a, b;
+    hipStream_t main;
+    hipStream_t * side;  // n_side side streams
+    int n_side;
     int live = std::uncaught_exceptions();
     ~DrainOnUnwind() {
         if (std::uncaught_exceptions() > live) {
-            if (a) (void)hipStreamSynchronize(a);
-            if (b) (void)hipStreamSynchronize(b);
+            if (main) (void)hipStreamSynchronize(main);
+            for (int k = 0; k < n_side; k++)
+                if (side[k]) (void)hipStreamSynchronize(side[k]);
         }
     }
 };
@@ -568,6 +575,32 @@ void encode_finish(bz3_state * st, float cm_ms) {
     st->result = total;
 }
 
+// Shape of the encoder's front-end pipeline: `contexts` LZP contexts fit into the memory budget, the batch has n blocks.
+// ns context slots (2..DeviceCtx::AUX) of `window` blocks each.  A window's drivers hide behind the whole-GPU work of ns-1 other
+// windows, so the drivers' share of the pace is T_driver / ((ns-1) * window) per block: more slots of fewer blocks get more out
+// of the same memory (4 x 4 hides as much as 2 x 12).  Small batches keep the two-slot form (nothing to overlap with anyway).
+// BZ3_HIP_LZP_PIPE="window,slots" overrides (tests / experiments).
+void pipeline_shape(s32 contexts, s32 n, s32 & window, s32 & ns) {
+    if (contexts < 2) contexts = 2;
+    ns = 2;
+    for (s32 cand = DeviceCtx::AUX; cand > 2; cand--)
+        if (contexts / cand >= 3 && n >= cand * 3) {
+            ns = cand;
+            break;
+        }
+    window = contexts / ns;
+    if (window > 8) window = 8;
+    if (const char * e = getenv("BZ3_HIP_LZP_PIPE")) {
+        int w = 0, q = 0;
+        if (sscanf(e, "%d,%d", &w, &q) == 2 && w >= 1 && q >= 2 && q <= DeviceCtx::AUX) {
+            window = w;
+            ns = q;
+        }
+    }
+    if (window > n) window = n;
+    if (window < 1) window = 1;
+}
+
 // Runs `n` blocks whose states live on ONE device.  bufs are device pointers.
 void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     if (n <= 0) return;
@@ -583,31 +616,33 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         const size_t w = workspace_bytes_for((u64)(sizes[i] > 0 ? sizes[i] : 0) + 64);
         if (w > need) need = w;
     }
-    // LZP drivers are serial single-workgroup kernels (~0.7 s for a 256 MiB text block, however many run side by side).
-    // The blocks go through the front end in WINDOWS, software-pipelined over two context slots: while the drivers of
-    // window k run on the device's second stream, this thread prepares window k+1 and finishes window k-1 (LZP emission,
-    // BWT, header) on the group's stream, so the drivers' latency hides behind whole-GPU work of other blocks.
+    // LZP drivers are serial single-workgroup kernels (0.75 s for a 256 MiB text block alone, ~1.2 s beside the whole-GPU
+    // kernels of other blocks, however many run side by side).  The blocks go through the front end in WINDOWS, software-pipelined
+    // over a ring of `ns` context slots with one side stream each: while the drivers of windows k-ns+2 .. k run on their side
+    // streams, this thread prepares window k+1 and finishes window k-ns+2 (LZP emission, BWT, header) on the group's stream, so a
+    // window's drivers hide behind ns-1 windows' worth of whole-GPU work.  Round 2 ran two slots of 6 blocks at 768 x 256 MiB:
+    // 128 windows x 1.23 s of drivers = 158 s against 146 s of whole-GPU work -- the driver chain, not the kernels, set the pace
+    // of the front end (profiles/r02_kernel_stats_bench_768x256MiB.txt: k_lzp_driver 137 calls, 1.23 s each).
     u64 n_max = 64;
     for (s32 i = 0; i < n; i++)
         if (sizes[i] > 0 && (u64)sizes[i] > n_max) n_max = (u64)sizes[i];
     const size_t ctx_bytes = lzp_encode_ctx_bytes(n_max + 64) + 65536;
-    // window = what fits twice into a third of the memory that is free right now; 8 blocks per window are plenty to hide a driver
-    size_t budget = (size_t)16 << 30;
+    // contexts = what fits into half of the memory that is free right now (the decode call that follows needs the other half:
+    // staged payloads + the swap buffers of its tail windows)
+    size_t budget = (size_t)32 << 30;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t have = lead->ctx->ws_cap;  // the arena already holds this much
-            budget = (free_b + have > need) ? (free_b + have - need) / 3 : 0;
+            budget = (free_b + have > need) ? (free_b + have - need) / 2 : 0;
         }
     }
-    s32 window = (s32)(budget / (2 * ctx_bytes));
-    if (window > 8) window = 8;
-    if (window > n) window = n;
-    if (window < 1) window = 1;
+    s32 window = 1, ns = 2;
+    pipeline_shape((s32)(budget / ctx_bytes < 1024 ? budget / ctx_bytes : 1024), n, window, ns);
     lead->ctx->ensure_aux();
-    hipStream_t s = lead->stream, s2 = lead->ctx->aux;
-    DrainOnUnwind drain{s, s2};
-    Arena arena = lead->ctx->arena_for(need + 2 * (size_t)window * (ctx_bytes + sizeof(LzpDriverJob) + 256) + (size_t)n * (sizeof(CmEncodeJob) + CM_SIDE_BYTES + 256) +
+    hipStream_t s = lead->stream;
+    DrainOnUnwind drain{s, lead->ctx->aux, DeviceCtx::AUX};
+    Arena arena = lead->ctx->arena_for(need + (size_t)ns * (size_t)window * (ctx_bytes + sizeof(LzpDriverJob) + 256) + (size_t)n * (sizeof(CmEncodeJob) + CM_SIDE_BYTES + 256) +
                                        cm_scratch_bytes((size_t)n) + 65536);
     CmEncodeJob * d_jobs = arena.take<CmEncodeJob>((size_t)n);
     u8 * sides = arena.take<u8>((size_t)n * CM_SIDE_BYTES);  // lean states only
@@ -617,20 +652,22 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         LzpDriverJob * d_lz = nullptr;
         std::vector<LzpEncodeCtx> ctxs;
         std::vector<LzpDriverJob> lz;      // host copy: stays alive until the window is finished
-    } win[2];
-    for (int k = 0; k < 2; k++) {
+    } win[DeviceCtx::AUX];
+    for (int k = 0; k < ns; k++) {
         win[k].slot.base = arena.take<char>((size_t)window * ctx_bytes);
         win[k].slot.cap = (size_t)window * ctx_bytes;
         win[k].d_lz = arena.take<LzpDriverJob>((size_t)window);
     }
     std::vector<CmEncodeJob> jobs;
     const s32 nwin = (n + window - 1) / window;
-    for (s32 k = 0; k <= nwin; k++) {
-        if (k < nwin) {  // prepare window k, then start its drivers on the second stream
-            Window & w = win[k & 1];
+    const s32 lag = ns - 1;  // window k is finished in iteration k + lag
+    for (s32 k = 0; k < nwin + lag; k++) {
+        if (k < nwin) {  // prepare window k, then start its drivers on the slot's side stream
+            const int q = (int)(k % ns);
+            Window & w = win[q];
             w.w0 = k * window;
             w.w1 = (w.w0 + window < n) ? w.w0 + window : n;
-            w.slot.used = 0;  // its previous tenant (window k-2) was finished one iteration ago, on this stream
+            w.slot.used = 0;  // its previous tenant (window k-ns) was finished one iteration ago, on this stream
             w.ctxs.assign((size_t)(w.w1 - w.w0), LzpEncodeCtx());
             w.lz.clear();
             for (s32 i = w.w0; i < w.w1; i++) {
@@ -638,19 +675,21 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
                 if (sts[i]->pending == bz3_state::ENC_CODED && w.ctxs[(size_t)(i - w.w0)].active) w.lz.push_back(lzp_driver_job(w.ctxs[(size_t)(i - w.w0)]));
             }
             if (!w.lz.empty()) {
+                hipStream_t sq = lead->ctx->aux[q];
                 HIP_CHECK(hipEventRecord(lead->ctx->ev_prep, s));  // the prepares above are in flight on the group's stream
-                HIP_CHECK(hipStreamWaitEvent(s2, lead->ctx->ev_prep, 0));
-                HIP_CHECK(hipEventRecord(lead->ctx->ev_d0[k & 1], s2));
-                lzp_driver_batch(w.lz.data(), w.d_lz, (u32)w.lz.size(), s2);
-                HIP_CHECK(hipEventRecord(lead->ctx->ev_d1[k & 1], s2));
+                HIP_CHECK(hipStreamWaitEvent(sq, lead->ctx->ev_prep, 0));
+                HIP_CHECK(hipEventRecord(lead->ctx->ev_d0[q], sq));
+                lzp_driver_batch(w.lz.data(), w.d_lz, (u32)w.lz.size(), sq);
+                HIP_CHECK(hipEventRecord(lead->ctx->ev_d1[q], sq));
             }
         }
-        if (k >= 1) {  // finish window k-1: its drivers have had the preparation of window k to themselves
-            Window & w = win[(k - 1) & 1];
+        if (k >= lag) {  // finish window k-lag: its drivers have had the whole-GPU work of `lag` other windows to hide behind
+            const int q = (int)((k - lag) % ns);
+            Window & w = win[q];
             float driver_ms = 0.f;
             if (!w.lz.empty()) {
-                HIP_CHECK(hipEventSynchronize(lead->ctx->ev_d1[(k - 1) & 1]));
-                (void)hipEventElapsedTime(&driver_ms, lead->ctx->ev_d0[(k - 1) & 1], lead->ctx->ev_d1[(k - 1) & 1]);
+                HIP_CHECK(hipEventSynchronize(lead->ctx->ev_d1[q]));
+                (void)hipEventElapsedTime(&driver_ms, lead->ctx->ev_d0[q], lead->ctx->ev_d1[q]);
             }
             for (s32 i = w.w0; i < w.w1; i++) {
                 encode_front_b(sts[i], arena, w.ctxs[(size_t)(i - w.w0)], driver_ms);
@@ -869,10 +908,22 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
         if (bytes > max_round) max_round = bytes;
         k = e;
     }
-    // tail windows of 32 blocks, software-pipelined like the encoder's front end: the serial LZP decoders of window k (one
-    // workgroup per block, ~0.8 s for a 256 MiB text block) run on the device's second stream while this thread drives the
-    // inverse BWTs of window k+1 on the group's stream; lean states hold a borrowed swap buffer for two windows at most
-    const s32 tail_window = n < 32 ? n : 32;
+    // tail windows, software-pipelined like the encoder's front end: the serial LZP decoders of a window (one workgroup per
+    // block, ~1 s for a 256 MiB text block beside other blocks' kernels) run on a side stream while this thread drives the inverse
+    // BWTs of the next windows and the mRLE / CRC stages of the previous ones on the group's stream.  Lean states hold a borrowed
+    // swap buffer while their window is in flight: 64 buffers at most either way -- two slots of 32 blocks for small batches, four
+    // slots of 16 for large ones (a window's decoders then hide behind three other windows' whole-GPU work: 1 s / 48 blocks
+    // instead of 1 s / 32, which starts to matter once the inverse BWT of a block takes less than ~30 ms).
+    s32 tail_slots = n >= 128 ? 4 : 2;
+    s32 tail_window = tail_slots == 4 ? 16 : 32;
+    if (const char * e = getenv("BZ3_HIP_TAIL_PIPE")) {  // "window,slots": tests / experiments
+        int w = 0, q = 0;
+        if (sscanf(e, "%d,%d", &w, &q) == 2 && w >= 1 && q >= 2 && q <= DeviceCtx::AUX) {
+            tail_window = w;
+            tail_slots = q;
+        }
+    }
+    if (tail_window > n) tail_window = n;
     size_t lzp_in_window = 0;
     for (s32 w0 = 0; w0 < n; w0 += tail_window) {
         size_t c = 0;
@@ -880,7 +931,7 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
             if (sts[i]->pending == bz3_state::DEC_CODED && (sts[i]->model & 2)) c++;
         if (c > lzp_in_window) lzp_in_window = c;
     }
-    Arena arena = lead->ctx->arena_for(need + 2 * lzp_in_window * (LZP_LUT_WORDS * 4 + sizeof(LzpDecodeJob) + 256) + (size_t)n * 256 + cm_scratch_bytes(coded.size()) + max_round + 65536);
+    Arena arena = lead->ctx->arena_for(need + (size_t)tail_slots * lzp_in_window * (LZP_LUT_WORDS * 4 + sizeof(LzpDecodeJob) + 256) + (size_t)n * 256 + cm_scratch_bytes(coded.size()) + max_round + 65536);
     // ---- phase 2: the CM launches (one workgroup per block) ------------------------------------------------------
     float cm_ms = 0.f;
     for (size_t r = 0, k0 = 0; r < round_end.size(); k0 = round_end[r++]) {
@@ -909,18 +960,20 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
         std::vector<char> alive;
         LzpDecodeJob * d_lz = nullptr;
         u32 * luts = nullptr;
-    } tw[2];
-    for (int k = 0; k < 2; k++) {
+    } tw[DeviceCtx::AUX];
+    for (int k = 0; k < tail_slots; k++) {
         tw[k].d_lz = lzp_in_window ? arena.take<LzpDecodeJob>(lzp_in_window) : nullptr;
         tw[k].luts = lzp_in_window ? arena.take<u32>(lzp_in_window * LZP_LUT_WORDS) : nullptr;
     }
     lead->ctx->ensure_aux();
-    hipStream_t s2 = lead->ctx->aux;
-    DrainOnUnwind drain{s, s2};
+    DrainOnUnwind drain{s, lead->ctx->aux, DeviceCtx::AUX};
     const s32 nwin = (n + tail_window - 1) / tail_window;
-    for (s32 k = 0; k <= nwin; k++) {
-        if (k < nwin) {  // window k: inverse BWTs on the group's stream, then its LZP decoders on the second stream
-            TailWindow & w = tw[k & 1];
+    const s32 lag = tail_slots - 1;  // window k is finished in iteration k + lag
+    for (s32 k = 0; k < nwin + lag; k++) {
+        if (k < nwin) {  // window k: inverse BWTs on the group's stream, then its LZP decoders on the slot's side stream
+            const int q = (int)(k % tail_slots);
+            hipStream_t s2 = lead->ctx->aux[q];
+            TailWindow & w = tw[q];
             w.w0 = k * tail_window;
             w.w1 = (w.w0 + tail_window < n) ? w.w0 + tail_window : n;
             w.lz_jobs.clear();
@@ -957,17 +1010,18 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
             if (!w.lz_jobs.empty()) {
                 HIP_CHECK(hipEventRecord(lead->ctx->ev_prep, s));  // the inverse BWTs above are in flight on the group's stream
                 HIP_CHECK(hipStreamWaitEvent(s2, lead->ctx->ev_prep, 0));
-                HIP_CHECK(hipEventRecord(lead->ctx->ev_d0[k & 1], s2));
+                HIP_CHECK(hipEventRecord(lead->ctx->ev_d0[q], s2));
                 lzp_decode_batch(w.lz_jobs.data(), w.d_lz, (u32)w.lz_jobs.size(), s2);
-                HIP_CHECK(hipEventRecord(lead->ctx->ev_d1[k & 1], s2));
+                HIP_CHECK(hipEventRecord(lead->ctx->ev_d1[q], s2));
             }
         }
-        if (k >= 1) {  // finish window k-1: its LZP decoders have had the inverse BWTs of window k to themselves
-            TailWindow & w = tw[(k - 1) & 1];
+        if (k >= lag) {  // finish window k-lag: its LZP decoders have had the inverse BWTs of `lag` other windows to hide behind
+            const int q = (int)((k - lag) % tail_slots);
+            TailWindow & w = tw[q];
             if (!w.lz_jobs.empty()) {
-                HIP_CHECK(hipEventSynchronize(lead->ctx->ev_d1[(k - 1) & 1]));
+                HIP_CHECK(hipEventSynchronize(lead->ctx->ev_d1[q]));
                 float ms = 0.f;
-                (void)hipEventElapsedTime(&ms, lead->ctx->ev_d0[(k - 1) & 1], lead->ctx->ev_d1[(k - 1) & 1]);
+                (void)hipEventElapsedTime(&ms, lead->ctx->ev_d0[q], lead->ctx->ev_d1[q]);
                 for (s32 i : w.lz_owner) sts[i]->t[BZ3_HIP_T_LZP] = ms;
                 // lean state whose buffer is smaller than the reference's swap buffer: the decoder stops at the cap (:211) and
                 // returns it, where the reference would have gone on to bz3_bound(block_size) and then either reported a larger

@@ -9,8 +9,8 @@
 //      T[i] = F[psi^i(idx)], where F[row] is recovered from the 257-entry cumulative symbol table.
 //   2. The single chain is cut at pseudo-random splitter rows (a multiplicative hash of the row
 //      number, plus rows idx and 0).  One lane per splitter walks to the next splitter and records
-//      the segment length (latency-bound, ~n/1024-way parallel random 4-byte reads).
-//   3. The ~n/1024-element splitter list is ranked by pointer jumping (log2 rounds, tiny).
+//      the segment length (latency-bound, ~n/256-way parallel random 4-byte reads).
+//   3. The ~n/256-element splitter list is ranked by pointer jumping (log2 rounds, tiny).
 //   4. Each lane re-walks its segment and writes the text bytes at their now-known positions.
 //   5. Input that is NOT a genuine BWT (a corrupted block) must still decode to what the reference produces, because
 //      the CRC / LZP / size checks that follow decide the error code.  psi(0) = idx puts rows 0 and idx on one
@@ -18,7 +18,7 @@
 //      laid out from position 0 and k_ub_tail reproduces what the reference's bigram chase emits once it is stuck
 //      on its zero-filled table entries (oracle/bz3_oracle.c orc_unbwt spells the rules out; pinned against the
 //      reference on random inputs).
-// HBM layout: psi u32[n+1], splitter-id u32[n+1], a few arrays of n/1024 words.
+// HBM layout: psi u32[n+1], splitter-id u32[n+1], a few arrays of n/256 words.
 // Algorithmic traffic: 11 B per byte; the walks are random 4-byte reads.
 #include "prims.hpp"
 #include "sort.hpp"
@@ -195,8 +195,19 @@ void bwt_inverse(const u8 * d_in, u32 n, u32 idx, u8 * d_out, Arena & tmp, hipSt
     radix_pass<u8>(d_in, (u8 *)nullptr, (const u32 *)nullptr, psi, n, 0, idx, 1u, tmp, s);
 
     // 2. splitters
+    // Segment lengths are geometric (splitters are a hash of the row number), every lane walks its whole segment, and all lanes of
+    // a launch are resident at once, so a walk lasts as long as its LONGEST segment: mean x ln(number of segments) dependent HBM
+    // round trips.  Round 2 measured 14.7 / 19.2 ms for the two walks of a 256 MiB block at one splitter per 1024 rows -- 12.8 k
+    // round trips of 1.15 / 1.5 us, while the 268 M reads themselves need ~11 ms at the random-access rate the other kernels reach.
+    // One splitter per 256 rows (the workspace is sized for it) cuts the longest segment to ~3.5 k steps and doubles the
+    // lanes with a load in flight; the list ranking grows to n / 256 elements (tens of microseconds per jump round).
+    static const int max_log_stride = [] {  // experiments: BZ3_UB_LOG_STRIDE=10 is the round-2 measured configuration
+        const char * e = getenv("BZ3_UB_LOG_STRIDE");
+        const int v = e ? atoi(e) : 8;
+        return v >= 8 && v <= 10 ? v : 8;  // the workspace holds n / 256 splitters
+    }();
     int log_stride = 0;
-    while (log_stride < 10 && ((u64)rows >> (log_stride + 1)) >= 65536) log_stride++;
+    while (log_stride < max_log_stride && ((u64)rows >> (log_stride + 1)) >= 65536) log_stride++;
     const dim3 grows((rows + UB_BLOCK - 1) / UB_BLOCK);
     launch(k_ub_flags, grows, dim3(UB_BLOCK), 0, s, rows, idx, log_stride, sid);
     exclusive_scan_u32(sid, rows, d_total, tmp, s);

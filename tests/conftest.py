@@ -14,6 +14,47 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _prebuild_shared_artifacts():
+    """Everything several tests build on first use, built once before the workers start (their builders are not made for
+    concurrent callers): the product library (hipcc cross-compiles gfx950 without a GPU), the CPU checkers under oracle/, the
+    emulator build of the kernel sources, the decoded fixture text."""
+    from bzip3_amd.build import build as build_product
+
+    build_product()
+    from oracle_lib import build_oracle
+
+    build_oracle()
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    from build_emu import build as build_emu
+
+    build_emu()
+    import datagen
+
+    datagen.shakespeare()
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (`-m "not gpu"`) is dominated by the kernel sources running under the fiber emulator, one test after the
+    other: ten minutes on one core.  When pytest-xdist is installed the tests are spread over the machine's cores instead
+    (BZ3_TEST_WORKERS=<n> picks the number, 0 or 1 keeps the run serial; an explicit -n wins).  The GPU suite is never
+    distributed: its tests share one device and the opt-in machinery runs after the default-path tests."""
+    if hasattr(config, "workerinput"):
+        return None
+    opt = config.option
+    if (getattr(opt, "markexpr", "") or "").replace(" ", "") != "notgpu" or not config.pluginmanager.hasplugin("xdist"):
+        return None
+    if getattr(opt, "numprocesses", None) is not None or getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False):
+        return None
+    env = os.environ.get("BZ3_TEST_WORKERS", "")
+    workers = int(env) if env.isdigit() else min(os.cpu_count() or 1, 8)
+    if workers < 2:
+        return None
+    _prebuild_shared_artifacts()
+    opt.numprocesses = workers
+    return None
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle_lib import Oracle

@@ -629,10 +629,18 @@ print("ok")
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-300:], r.stderr[-1200:])
 
 
-def test_pipelined_windows_of_a_large_batch(emu, oracle):
-    """A batch larger than the encoder's front-end windows (8 blocks: the LZP drivers of window k run on the device's second stream beside the
-    preparation of window k+1 and the completion of window k-1, over two context slots) and than the decoder's tail windows (32 blocks: LZP
-    decoders beside the next window's inverse BWTs): every block equals the oracle's both ways, with LZP applied, declined and skipped."""
+@pytest.mark.parametrize("pipe", [None, "1,4", "5,3", "40,2"], ids=["auto", "w1s4", "w5s3", "w40s2"])
+def test_pipelined_windows_of_a_large_batch(emu, oracle, pipe, monkeypatch):
+    """A batch larger than the encoder's front-end windows (the LZP drivers of window k run on a side stream of the device beside the
+    preparation of the next windows and the completion of the previous ones, over a ring of 2-4 context slots: api.hip pipeline_shape /
+    encode_group) and than the decoder's tail windows (32 blocks: LZP decoders beside the next window's inverse BWTs): every block equals
+    the oracle's both ways, with LZP applied, declined and skipped.  BZ3_HIP_LZP_PIPE = "window,slots" forces the ring's shape: windows of
+    one block (36 windows through 4 slots), a ragged last window through 3 slots, a single window larger than the batch."""
+    for var in ("BZ3_HIP_LZP_PIPE", "BZ3_HIP_TAIL_PIPE"):  # the decoder's tail windows take the same shape (decode_group)
+        if pipe:
+            monkeypatch.setenv(var, pipe)
+        else:
+            monkeypatch.delenv(var, raising=False)
     bs = 65 * 1024
     t = datagen.shakespeare()
     blocks = []

@@ -1,0 +1,50 @@
+#!/bin/bash
+# First GPU call of round 3: time everything that went into the source AFTER round 2's GPU budget was spent, each against the
+# configuration the round measured.  About 12 GPU-minutes; every leg writes a small text file under <out>.
+#   bash tools/r03_first_call.sh gpurun_out/r03_first
+# Legs:
+#   parity     the stage / block parity tests of the GPU suite (the changed kernels are in every one of them)
+#   rs_ab      radix sorter: default (16 loads in flight) | LDS-staged scatter | no XCD mapping      (tools/rs_ab.sh, 256 MiB block)
+#   ub_ab      inverse BWT: one splitter per 256 rows (default) | per 1024 rows (round 2)             (BZ3_UB_LOG_STRIDE)
+#   pipe_ab    front-end / tail rings: auto (4 slots) | two slots of 6 / 32 blocks (round 2)          (BZ3_HIP_LZP_PIPE, BZ3_HIP_TAIL_PIPE)
+#              on 768 x 32 MiB blocks (one step is ~1 min instead of ~8): t_enc - cm and t_dec - cm are the front end and the tail
+set -e
+OUT=$(realpath -m "$1")
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p "$OUT"
+cd "$REPO"
+
+echo "== parity" | tee "$OUT/summary.txt"
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "stage_parity or block_parity or batch_api or device_resident" > "$OUT/parity.log" 2>&1 || true
+tail -2 "$OUT/parity.log" | tee -a "$OUT/summary.txt"
+
+echo "== rs_ab" | tee -a "$OUT/summary.txt"
+bash tools/rs_ab.sh "$OUT" 256 | tee -a "$OUT/summary.txt"
+
+echo "== ub_ab" | tee -a "$OUT/summary.txt"
+ub() {  # name, env assignment
+    local name=$1; shift
+    ( cd /tmp && export TMPDIR=/tmp && rm -rf "$OUT/$name" &&
+      env "$@" rocprofv3 --kernel-trace -d "$OUT/$name" -o pass -- python "$REPO/tools/stage_probe.py" 256 > "$OUT/$name.log" 2>&1 )
+    local db; db=$(find "$OUT/$name" -name "*.db" | head -1)
+    python tools/rocpd_summary.py "$db" "rocprofv3 --kernel-trace -- $* python tools/stage_probe.py 256   (MI355X, ROCm 7.2)" > "$OUT/ub_ab_$name.txt"
+    rm -rf "$OUT/$name"
+    echo "$name: $(grep -E 'k_ub_walk_(len|emit)|k_ub_jump' "$OUT/ub_ab_$name.txt" | awk '{print $1, $(NF-4) " ms;"}' | tr '\n' ' ')"
+}
+ub stride256 BZ3_UB_LOG_STRIDE=8 | tee -a "$OUT/summary.txt"
+ub stride1024 BZ3_UB_LOG_STRIDE=10 | tee -a "$OUT/summary.txt"
+
+echo "== pipe_ab" | tee -a "$OUT/summary.txt"
+pipe() {  # name, env assignments
+    local name=$1; shift
+    env "$@" python bench.py --gpus 1 --steps 1 --warmup 0 --blocks 768 --block-mib 32 --no-cpu-baseline --no-extras > "$OUT/pipe_$name.json" 2> "$OUT/pipe_$name.progress.txt" || true
+    python - "$OUT/pipe_$name.json" "$name" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+st = d["stages"]
+print(f"{sys.argv[2]:<10} value {d['value']:8.1f} MiB/s   front end {st['t_enc_s'] - st['enc']['cm'] / 1e3:6.1f} s   tail {st['t_dec_s'] - st['dec']['cm'] / 1e3:6.1f} s   "
+      f"(cm enc {st['enc']['cm'] / 1e3:.1f} s, dec {st['dec']['cm'] / 1e3:.1f} s; lzp driver window {st['enc']['lzp']:.0f} ms)")
+PY
+}
+pipe ring BZ3_PIPE_DUMMY=0 | tee -a "$OUT/summary.txt"
+pipe round2 BZ3_HIP_LZP_PIPE=6,2 BZ3_HIP_TAIL_PIPE=32,2 | tee -a "$OUT/summary.txt"
