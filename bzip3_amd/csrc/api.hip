@@ -124,6 +124,7 @@ int g_device_count = -1;
 std::atomic<int> g_bound_device{-2};  // -2 = not initialised from the environment yet, -1 = round robin
 std::atomic<unsigned> g_rr{0};
 std::atomic<int> g_lean{-1};  // -1 = not read from the environment yet; see bz3_hip_set_lean_states
+std::atomic<int> g_front_end_ring{0};  // window | slots << 16 of the last encode_group (bz3_hip_debug_front_end_ring)
 std::atomic<unsigned> g_cm_given_up{0};  // blocks the row-cache CM kernels handed back to the full-model kernels (statistics)
 
 int device_count() {
@@ -642,8 +643,20 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     lead->ctx->ensure_aux();
     hipStream_t s = lead->stream;
     DrainOnUnwind drain{s, lead->ctx->aux, DeviceCtx::AUX};
-    Arena arena = lead->ctx->arena_for(need + (size_t)ns * (size_t)window * (ctx_bytes + sizeof(LzpDriverJob) + 256) + (size_t)n * (sizeof(CmEncodeJob) + CM_SIDE_BYTES + 256) +
-                                       cm_scratch_bytes((size_t)n) + 65536);
+    Arena arena;
+    for (;;) {  // hipMemGetInfo's figure is not a promise (fragmentation, another process on the device): shrink the ring before giving up
+        try {
+            arena = lead->ctx->arena_for(need + (size_t)ns * (size_t)window * (ctx_bytes + sizeof(LzpDriverJob) + 256) +
+                                         (size_t)n * (sizeof(CmEncodeJob) + CM_SIDE_BYTES + 256) + cm_scratch_bytes((size_t)n) + 65536);
+            break;
+        } catch (const HipError & e) {
+            if (e.code != hipErrorOutOfMemory || (ns == 2 && window == 1)) throw;
+            (void)hipGetLastError();
+            if (ns > 2) ns = 2;
+            else window = (window + 1) / 2;
+        }
+    }
+    g_front_end_ring.store(window | (ns << 16));
     CmEncodeJob * d_jobs = arena.take<CmEncodeJob>((size_t)n);
     u8 * sides = arena.take<u8>((size_t)n * CM_SIDE_BYTES);  // lean states only
     struct Window {
@@ -1506,6 +1519,8 @@ BZIP3_API int bz3_hip_cm_variant_for(int device, int blocks, int encode) {
     DeviceCtx * c = get_ctx(device);
     return (c && blocks > 0) ? cm_variant_for(c, (size_t)blocks, encode != 0) : -1;
 }
+
+BZIP3_API int bz3_hip_debug_front_end_ring(void) { return g_front_end_ring.load(); }
 
 BZIP3_API int bz3_hip_debug_peak_concurrent_groups(int reset) {
     const int v = g_groups_peak.load();

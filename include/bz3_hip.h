@@ -54,6 +54,11 @@ BZIP3_API int bz3_hip_cm_variant_for(int device, int blocks, int encode);
  * last reset (a batch whose states live on G GPUs runs G groups concurrently, one host thread per GPU). */
 BZIP3_API int bz3_hip_debug_peak_concurrent_groups(int reset);
 
+/* Test hook: shape of the ring the last bz3_encode_blocks / bz3_hip_encode_blocks_device group ran its front end through:
+ * blocks per window | context slots << 16 (0 before the first call).  The serial LZP drivers of a window run on a side stream
+ * while the whole-GPU stages of the other slots' windows run on the group's stream; the shape follows the free memory. */
+BZIP3_API int bz3_hip_debug_front_end_ring(void);
+
 /* Lean states (process-wide switch, read by bz3_new; environment BZ3_HIP_LEAN=1 has the same effect).  A state
  * normally owns its swap buffer (the reference's swap_buffer, bz3_bound(block_size) bytes of HBM) for life, so a
  * batch of N blocks holds 2 N block-sized buffers.  A lean state owns none: it borrows one from a per-GPU pool only

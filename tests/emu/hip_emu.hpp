@@ -43,7 +43,7 @@ typedef int hipError_t;
 typedef void * hipStream_t;
 struct emu_event { std::chrono::steady_clock::time_point t; };
 typedef emu_event * hipEvent_t;
-enum { hipSuccess = 0, hipErrorUnknown = 999 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorUnknown = 999 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault, hipMemcpyHostToHost };
 enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDisableTiming = 2 };
 
@@ -201,7 +201,13 @@ template <typename T> inline T atomicExch(T * p, T v) { T o = *p; *p = v; return
 template <typename T> inline T atomicCAS(T * p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
 
 // ---- runtime API subset -------------------------------------------------------------------
-inline hipError_t hipMalloc(void ** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorUnknown; }
+// BZ3_EMU_MALLOC_LIMIT=<bytes>: a single allocation larger than this fails with hipErrorOutOfMemory (tests of the fallback paths)
+inline hipError_t hipMalloc(void ** p, size_t n) {
+    if (const char * e = getenv("BZ3_EMU_MALLOC_LIMIT"))
+        if (n > (size_t)strtoull(e, nullptr, 10)) { *p = nullptr; return hipErrorOutOfMemory; }
+    *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 template <typename T> inline hipError_t hipMalloc(T ** p, size_t n) { return hipMalloc((void **)p, n); }
 inline hipError_t hipFree(void * p) { free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void ** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }

@@ -596,6 +596,60 @@ print("ok")
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-300:], r.stderr[-1200:])
 
 
+def test_front_end_ring_follows_the_memory_and_shrinks_when_the_arena_does_not_fit():
+    """Shape of the encoder's front-end ring (api.hip pipeline_shape / encode_group): four context slots when the memory holds at
+    least three blocks per slot and the batch is large enough, two otherwise; when the workspace allocation fails although
+    hipMemGetInfo promised the room (BZ3_EMU_MALLOC_LIMIT: allocations above the limit fail with hipErrorOutOfMemory), the ring
+    shrinks -- first to two slots, then window by window -- instead of failing the batch, and the blocks still equal the oracle's."""
+    import subprocess
+
+    code = r'''
+import os, sys, ctypes as C
+sys.path[:0] = [%r, %r, %r]
+import bzip3_amd, datagen
+from build_emu import build
+from oracle_lib import Oracle
+lib = bzip3_amd._declare(C.CDLL(build()))
+o = Oracle()
+bs = 65 * 1024
+t = datagen.shakespeare()
+def run(n, size=300):
+    blocks = [t[i * 700 : i * 700 + size + 11 * i] for i in range(n)]
+    states = (C.c_void_p * n)(*[lib.bz3_new(bs) for _ in range(n)])
+    cap = lib.bz3_bound(bs) + 64
+    bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+    for b, d in zip(bufs, blocks):
+        C.memmove(b, d, len(d))
+    ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+    lib.bz3_encode_blocks(states, ptrs, sizes, n)
+    for i, d in enumerate(blocks):
+        assert lib.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: sizes[i]]) == o.encode_block(d, bs)[2], (n, i)
+    for s in states:
+        lib.bz3_free(s)
+    ring = lib.bz3_hip_debug_front_end_ring()
+    return ring & 0xFFFF, ring >> 16
+assert lib.bz3_hip_debug_front_end_ring() == 0
+assert run(5) == (5, 2)            # small batch: one window, two slots
+assert run(13) == (8, 4)           # 16 GiB "free": windows of 8 through four slots
+lib.bz3_hip_release_cached_memory()  # drop the workspace: the next call has to allocate again
+os.environ["BZ3_EMU_MALLOC_LIMIT"] = str(16 << 20)
+w, ns = run(13, 60000)             # an LZP context is ~8.6 bytes per input byte: 4 x 8 of them + the sorter's workspace need ~28 MiB
+assert ns == 2 and 1 <= w < 8, (w, ns)   # ... which did not fit 16 MiB: two slots, smaller windows
+os.environ["BZ3_EMU_MALLOC_LIMIT"] = str(1 << 20)
+lib.bz3_hip_release_cached_memory()
+blocks = [t[:300]]
+st = lib.bz3_new(bs)
+buf = (C.c_uint8 * (lib.bz3_bound(bs) + 64))()
+C.memmove(buf, blocks[0], 300)
+assert lib.bz3_encode_block(st, buf, 300) == -1 and lib.bz3_last_error(st) != 0   # nothing fits: an error, not a crash
+lib.bz3_free(st)
+print("ok")
+''' % (os.path.dirname(HERE), HERE, os.path.join(HERE, "emu"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-300:], r.stderr[-1200:])
+
+
 def test_auto_cm_policy_and_encode_many_hook(oracle):
     """The automatic CM policy by batch size (api.hip cm_variant_for; BZ3_HIP_CUS=2 pretends the GPU has two CUs): up to one block per CU
     the whole-model kernels with the barrier-synchronised decoder (5), up to two per CU the 96-row pair (6), beyond that the three-per-CU
