@@ -373,7 +373,7 @@ struct DeviceGuard {
 };
 
 // A group call that is left by an exception must not leave kernels in flight on either stream of the device: the caller is about to
-// hand borrowed swap buffers back to the pool and to reuse the arena (the serial LZP kernels run on the second stream).
+// hand borrowed swap buffers back to the pool and to reuse the arena (the serial LZP kernels run on the side streams).
 struct DrainOnUnwind {
     hipStream_t main;
     hipStream_t * side;  // n_side side streams

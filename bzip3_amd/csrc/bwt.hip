@@ -146,7 +146,12 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bwt_head_slots(const u64 * __restr
     if (k == 0 || keys[k] != keys[k - 1]) headslot[excl[k]] = slots ? slots[k] : k;
 }
 
-// Writes SA / ISA for every sorted element and flags the ones that stay active (group size > 1).
+// Publishes the rank (ISA) of every sorted element, the SA entry of the ones that just became unique, and flags the ones that
+// stay active (group size > 1).  Both scatters are random 4-byte stores, the costliest thing here, so none is made in vain:
+// SA is only read by k_bwt_emit, and a suffix that stays active gets its slot again in a later round, when it is unique; in a
+// doubling round (DOUBLING) the upper key word IS the suffix's current rank (k_bwt_doubling_keys), and the first sub-group of
+// every group keeps it.
+template <bool DOUBLING>
 __global__ void __launch_bounds__(BW_BLOCK) k_bwt_assign(const u64 * __restrict__ keys, const u32 * __restrict__ vals, const u32 * __restrict__ excl,
                                                         const u32 * __restrict__ slots, const u32 * __restrict__ headslot, u32 m, u32 * __restrict__ sa,
                                                         u32 * __restrict__ isa, u32 * __restrict__ keep) {
@@ -157,9 +162,11 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bwt_assign(const u64 * __restrict_
     const bool next_head = (k + 1 == m) || keys[k + 1] != key;
     const u32 gid = excl[k] + (head ? 1u : 0u) - 1u;
     const u32 v = vals[k];
-    sa[slots ? slots[k] : k] = v;
-    isa[v] = headslot[gid];
-    keep[k] = (head && next_head) ? 0u : 1u;
+    const u32 rank = headslot[gid];
+    const bool unique = head && next_head;
+    if (unique) sa[slots ? slots[k] : k] = v;
+    if (!DOUBLING || rank != (u32)(key >> 32)) isa[v] = rank;
+    keep[k] = unique ? 0u : 1u;
 }
 
 // Stream compaction of the still-active elements.  `excl` = exclusive scan of keep flags, which are
@@ -274,8 +281,12 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
         exclusive_scan_u32(scanA, m, nullptr, tmp, s);
         launch(k_bwt_head_slots, grid(m), dim3(BW_BLOCK), 0, s, (const u64 *)key[cur], (const u32 *)scanA, slots, m, headslot);
         u32 * keep = val[cur ^ 1];  // free buffer at this point
-        launch(k_bwt_assign, grid(m), dim3(BW_BLOCK), 0, s, (const u64 *)key[cur], (const u32 *)val[cur], (const u32 *)scanA, slots, (const u32 *)headslot, m,
-               sa, isa, keep);
+        if (slots)  // a doubling round: the keys carry the current ranks
+            launch(k_bwt_assign<true>, grid(m), dim3(BW_BLOCK), 0, s, (const u64 *)key[cur], (const u32 *)val[cur], (const u32 *)scanA, slots, (const u32 *)headslot,
+                   m, sa, isa, keep);
+        else
+            launch(k_bwt_assign<false>, grid(m), dim3(BW_BLOCK), 0, s, (const u64 *)key[cur], (const u32 *)val[cur], (const u32 *)scanA, slots, (const u32 *)headslot,
+                   m, sa, isa, keep);
         exclusive_scan_u32(keep, m, d_words, tmp, s);
         u32 m_next = 0;
         HIP_CHECK(hipMemcpyAsync(&m_next, d_words, 4, hipMemcpyDeviceToHost, s));

@@ -42,9 +42,13 @@ def pytest_cmdline_main(config):
     if hasattr(config, "workerinput"):
         return None
     opt = config.option
-    if (getattr(opt, "markexpr", "") or "").replace(" ", "") != "notgpu" or not config.pluginmanager.hasplugin("xdist"):
+    if getattr(opt, "collectonly", False) or not config.pluginmanager.hasplugin("xdist"):
         return None
-    if getattr(opt, "numprocesses", None) is not None or getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False):
+    if getattr(opt, "numprocesses", None) is not None:  # an explicit -n: the workers still must not build side by side
+        if opt.numprocesses:
+            _prebuild_shared_artifacts()
+        return None
+    if (getattr(opt, "markexpr", "") or "").replace(" ", "") != "notgpu" or getattr(opt, "usepdb", False):
         return None
     env = os.environ.get("BZ3_TEST_WORKERS", "")
     workers = int(env) if env.isdigit() else min(os.cpu_count() or 1, 8)
