@@ -195,6 +195,200 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bwt_doubling_keys(const u32 * __re
     keys[k] = ((u64)isa[s] << 32) | lo;
 }
 
+// ---- fused grouping (opt-in: BZ3_BWT_FUSED=1; NOT the default until it has been timed on the GPU) ---------------------------
+// The regrouping of a freshly sorted list above is seven launches that stream the list again and again: head flags (write), scan,
+// head slots, assign (flags recomputed, keep flags written), scan, compact, a copy of the compacted suffixes -- about 110 bytes of
+// sequential traffic per element and round beside the one random store that is the actual work.  Here it is two passes over tiles
+// of 2048 elements (8 consecutive elements per thread) and a one-workgroup spine between them:
+//   k_bg_reduce : per tile, the position of its last group head and the number of elements that stay active
+//   k_bg_spine  : exclusive running maximum / sum over the tiles (at most n / 2048 of them)
+//   k_bg_apply  : flags again from the keys; in-tile running maximum of the head positions (+ the tile's carry) gives every
+//                 element its group head, hence its rank; in-tile sum of the keep flags (+ the tile's offset) gives the slot in
+//                 the compacted list; writes SA / ISA as k_bwt_assign does and the compacted (suffix, slot, rank) triples --
+//                 the rank rides along so that k_bwt_doubling_keys_grp reads it in order instead of gathering isa[s]
+// ~45 bytes of sequential traffic per element and round; same SA / ISA / active list by construction.
+constexpr int BG_ITEMS = 8;
+constexpr int BG_TILE = BW_BLOCK * BG_ITEMS;
+struct alignas(16) BgU64x2 { u64 x, y; };
+struct alignas(16) BgU32x4 { u32 x, y, z, w; };
+
+// kv[j + 1] = keys[base + j] for j = -1 .. BG_ITEMS (indices clamped into [0, m - 1]: a clamped copy only ever meets a flag test
+// that is overridden by its own bounds check).  Whole tiles: four 16-byte loads + the two neighbours, all in flight together.
+__device__ __forceinline__ void bg_load_keys(const u64 * __restrict__ keys, u32 m, u64 base, u64 (&kv)[BG_ITEMS + 2]) {
+    const u64 last = (u64)m - 1;
+    kv[0] = keys[base > 0 ? (base - 1 < last ? base - 1 : last) : 0];
+    kv[BG_ITEMS + 1] = keys[base + BG_ITEMS < last ? base + BG_ITEMS : last];
+    if (base + BG_ITEMS <= m) {
+        const BgU64x2 * __restrict__ q = reinterpret_cast<const BgU64x2 *>(keys + base);  // base is a multiple of 8 elements, the array 256-byte aligned
+#pragma unroll
+        for (int j = 0; j < BG_ITEMS / 2; j++) {
+            const BgU64x2 t = q[j];
+            kv[1 + 2 * j] = t.x;
+            kv[2 + 2 * j] = t.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < BG_ITEMS; j++) kv[1 + j] = keys[base + j < last ? base + j : last];
+    }
+}
+__device__ __forceinline__ void bg_load_u32(const u32 * __restrict__ a, u32 m, u64 base, u32 (&v)[BG_ITEMS]) {
+    if (base + BG_ITEMS <= m) {
+        const BgU32x4 * __restrict__ q = reinterpret_cast<const BgU32x4 *>(a + base);
+        const BgU32x4 t0 = q[0], t1 = q[1];
+        v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
+        v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+    } else {
+        const u64 last = (u64)m - 1;
+#pragma unroll
+        for (int j = 0; j < BG_ITEMS; j++) v[j] = a[base + j < last ? base + j : last];
+    }
+}
+// flags of element k = base + j (k < m): head = first of its group, uniq = a group of one
+#define BG_FLAGS(j, k, head, uniq)                                                   \
+    const bool head = (k) == 0 || kv[(j) + 1] != kv[(j)];                            \
+    const bool uniq = head && ((k) + 1 == (u64)m || kv[(j) + 2] != kv[(j) + 1])
+
+__global__ void __launch_bounds__(BW_BLOCK) k_bg_reduce(const u64 * __restrict__ keys, u32 m, u32 * __restrict__ tile_head, u32 * __restrict__ tile_keep) {
+    __shared__ u32 lds[BW_BLOCK / WAVE + 1];
+    const u64 base = (u64)blockIdx.x * BG_TILE + (u64)threadIdx.x * BG_ITEMS;
+    u64 kv[BG_ITEMS + 2];
+    bg_load_keys(keys, m, base < m ? base : (u64)m - 1, kv);
+    u32 hp = 0, keep = 0;  // hp = 1 + position of the last head seen (0 = none)
+#pragma unroll
+    for (int j = 0; j < BG_ITEMS; j++) {
+        const u64 k = base + j;
+        if (k < m) {
+            BG_FLAGS(j, k, head, uniq);
+            if (head) hp = (u32)k + 1u;
+            keep += uniq ? 0u : 1u;
+        }
+    }
+    hp = block_max<BW_BLOCK>(hp, lds);
+    keep = block_sum<BW_BLOCK>(keep, lds);
+    if (threadIdx.x == 0) {
+        tile_head[blockIdx.x] = hp;
+        tile_keep[blockIdx.x] = keep;
+    }
+}
+
+template <int BLOCK>
+__device__ __forceinline__ u32 bg_block_excl_max(u32 v, u32 * lds) {  // lds: BLOCK / 64 words; ends with a barrier
+    const u32 incl = wave_incl_max(v);
+    if (lane_id() == WAVE - 1) lds[wave_id()] = incl;
+    u32 up = __shfl_up(incl, 1u);
+    if (lane_id() == 0) up = 0u;
+    __syncthreads();
+    u32 carry = 0;
+    for (int w = 0; w < wave_id(); w++) carry = lds[w] > carry ? lds[w] : carry;
+    __syncthreads();
+    return up > carry ? up : carry;
+}
+
+// One workgroup: tile_head[t] <- maximum over the tiles before t, tile_keep[t] <- sum over the tiles before t, *total <- sum of all.
+constexpr int BG_SPINE = 1024;
+__global__ void __launch_bounds__(BG_SPINE) k_bg_spine(u32 * __restrict__ tile_head, u32 * __restrict__ tile_keep, u32 tiles, u32 * __restrict__ total) {
+    __shared__ u32 lds[BG_SPINE / WAVE + 1];
+    const u32 per = (tiles + BG_SPINE - 1) / BG_SPINE;
+    const u32 t0 = threadIdx.x * per, t1 = t0 + per < tiles ? t0 + per : tiles;
+    u32 hp = 0, sum = 0;
+    for (u32 t = t0; t < t1; t++) {
+        const u32 h = tile_head[t];
+        hp = h > hp ? h : hp;
+        sum += tile_keep[t];
+    }
+    u32 run_hp = bg_block_excl_max<BG_SPINE>(hp, lds);
+    u32 all;
+    u32 run_sum = block_excl_add<BG_SPINE>(sum, lds, all);
+    for (u32 t = t0; t < t1; t++) {
+        const u32 h = tile_head[t], c = tile_keep[t];
+        tile_head[t] = run_hp;
+        tile_keep[t] = run_sum;
+        run_hp = h > run_hp ? h : run_hp;
+        run_sum += c;
+    }
+    if (threadIdx.x == 0) *total = all;
+}
+
+template <bool DOUBLING>
+__global__ void __launch_bounds__(BW_BLOCK) k_bg_apply(const u64 * __restrict__ keys, const u32 * __restrict__ vals, const u32 * __restrict__ slots, u32 m,
+                                                      const u32 * __restrict__ tile_head, const u32 * __restrict__ tile_keep, u32 * __restrict__ sa,
+                                                      u32 * __restrict__ isa, u32 * __restrict__ vals_out, u32 * __restrict__ slots_out, u32 * __restrict__ grp_out) {
+    __shared__ u32 lds[BW_BLOCK / WAVE + 1];
+    const u64 base = (u64)blockIdx.x * BG_TILE + (u64)threadIdx.x * BG_ITEMS;
+    const u64 lbase = base < m ? base : (u64)m - 1;  // threads past the end load something valid and use none of it
+    u64 kv[BG_ITEMS + 2];
+    u32 v[BG_ITEMS], sl[BG_ITEMS];
+    bg_load_keys(keys, m, lbase, kv);
+    bg_load_u32(vals, m, lbase, v);
+    if (slots) {
+        bg_load_u32(slots, m, lbase, sl);
+    } else {
+#pragma unroll
+        for (int j = 0; j < BG_ITEMS; j++) sl[j] = (u32)(base + j);
+    }
+    const u32 carry_hp = tile_head[blockIdx.x], tile_off = tile_keep[blockIdx.x];
+    // this thread's own last head and keep count
+    u32 hp = 0, keep = 0;
+#pragma unroll
+    for (int j = 0; j < BG_ITEMS; j++) {
+        const u64 k = base + j;
+        if (k < m) {
+            BG_FLAGS(j, k, head, uniq);
+            if (head) hp = (u32)k + 1u;
+            keep += uniq ? 0u : 1u;
+        }
+    }
+    u32 run_hp = bg_block_excl_max<BW_BLOCK>(hp, lds);
+    run_hp = carry_hp > run_hp ? carry_hp : run_hp;
+    u32 all;
+    u32 out = tile_off + block_excl_add<BW_BLOCK>(keep, lds, all);
+    // rank of an element = slot of its group's head.  The head of the group that reaches into this thread's elements from the left
+    // costs one gather; from the first head on, the slots are in registers (sl[j] = k itself in the first round).
+    u32 run_rank = 0;  // run_hp == 0 only where element 0 of the list starts the thread, and that one is a head
+    if (run_hp > 0 && base < m) run_rank = slots ? slots[run_hp - 1u] : run_hp - 1u;
+    u32 rank[BG_ITEMS];
+#pragma unroll
+    for (int j = 0; j < BG_ITEMS; j++) {
+        const u64 k = base + j;
+        rank[j] = 0;
+        if (k < m) {
+            BG_FLAGS(j, k, head, uniq);
+            (void)uniq;
+            if (head) run_rank = sl[j];
+            rank[j] = run_rank;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BG_ITEMS; j++) {
+        const u64 k = base + j;
+        if (k < m) {
+            BG_FLAGS(j, k, head, uniq);
+            (void)head;
+            if (!DOUBLING || rank[j] != (u32)(kv[j + 1] >> 32)) isa[v[j]] = rank[j];
+            if (uniq) {
+                sa[sl[j]] = v[j];
+            } else {
+                vals_out[out] = v[j];
+                slots_out[out] = sl[j];
+                grp_out[out] = rank[j];
+                out++;
+            }
+        }
+    }
+}
+#undef BG_FLAGS
+
+// key(k) = (current rank of suffix s, carried along by k_bg_apply) << 32 | rank of suffix s + h
+__global__ void __launch_bounds__(BW_BLOCK) k_bwt_doubling_keys_grp(const u32 * __restrict__ vals, const u32 * __restrict__ grp, const u32 * __restrict__ isa, u32 m,
+                                                                   u32 n, u32 h, u64 * __restrict__ keys) {
+    const u32 k = blockIdx.x * BW_BLOCK + threadIdx.x;
+    if (k >= m) return;
+    const u32 s = vals[k];
+    const u64 j = (u64)s + h;
+    const u32 lo = (j < n) ? isa[j] + h : (n - 1u - s);
+    keys[k] = ((u64)grp[k] << 32) | lo;
+}
+
 __global__ void __launch_bounds__(BW_BLOCK) k_bwt_emit(const u8 * __restrict__ t, const u32 * __restrict__ sa, const u32 * __restrict__ isa, u32 n,
                                                       u8 * __restrict__ out, u32 * __restrict__ idx_out) {
     const u32 i = blockIdx.x * BW_BLOCK + threadIdx.x;
@@ -274,6 +468,48 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     const u32 * slots = nullptr;  // nullptr = identity (round 0 covers every slot)
     int scur = 0;           // slot[scur] holds the slots of the active list (when slots != nullptr)
     u32 h = 8;
+    // experiments: BZ3_BWT_FUSED=1 = the two-pass regrouping (k_bg_*); read per call so that tests can switch it in-process
+    const bool fused = getenv("BZ3_BWT_FUSED") != nullptr;
+    if (fused) {
+        u32 * vcur = val[cur], * vfree = val[cur ^ 1];  // suffixes of the sorted list / a free buffer of the same size
+        const u32 max_tiles = (u32)(((u64)n + BG_TILE - 1) / BG_TILE);
+        u32 * tile_head = scanA;  // the flag / scan buffer of the seven-launch form is free here
+        u32 * tile_keep = scanA + (((size_t)max_tiles + 63) & ~(size_t)63);
+        u32 * grp = headslot;     // ranks of the compacted suffixes
+        for (;;) {
+            st.rounds++;
+            const u32 tiles = (u32)(((u64)m + BG_TILE - 1) / BG_TILE);
+            launch(k_bg_reduce, dim3(tiles), dim3(BW_BLOCK), 0, s, (const u64 *)key[cur], m, tile_head, tile_keep);
+            launch(k_bg_spine, dim3(1), dim3(BG_SPINE), 0, s, tile_head, tile_keep, tiles, d_words);
+            if (slots)
+                launch(k_bg_apply<true>, dim3(tiles), dim3(BW_BLOCK), 0, s, (const u64 *)key[cur], (const u32 *)vcur, slots, m, (const u32 *)tile_head,
+                       (const u32 *)tile_keep, sa, isa, vfree, slot[scur ^ 1], grp);
+            else
+                launch(k_bg_apply<false>, dim3(tiles), dim3(BW_BLOCK), 0, s, (const u64 *)key[cur], (const u32 *)vcur, slots, m, (const u32 *)tile_head,
+                       (const u32 *)tile_keep, sa, isa, vfree, slot[scur ^ 1], grp);
+            u32 m_next = 0;
+            HIP_CHECK(hipMemcpyAsync(&m_next, d_words, 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            if (m_next == 0) break;
+            scur ^= 1;
+            slots = slot[scur];
+            m = m_next;
+            // the active suffixes are in vfree now, their ranks in grp; the old list (key[cur], vcur) is dead
+            launch(k_bwt_doubling_keys_grp, grid(m), dim3(BW_BLOCK), 0, s, (const u32 *)vfree, (const u32 *)grp, (const u32 *)isa, m, n, h, key[0]);
+            u32 * vv[2] = {vfree, vcur};
+            const int lo_bits = bits_for((u64)n + h);
+            const int hi_bits = bits_for(n);
+            int c = radix_sort_pairs<u64>(key[0], key[1], vv[0], vv[1], m, 0, lo_bits, tmp, s);
+            c ^= radix_sort_pairs<u64>(key[c], key[c ^ 1], vv[c], vv[c ^ 1], m, 32, 32 + hi_bits, tmp, s);
+            cur = c;
+            vcur = vv[c];
+            vfree = vv[c ^ 1];
+            st.radix_passes += (lo_bits + 7) / 8 + (hi_bits + 7) / 8;
+            st.sorted_elements += m;
+            if (h >= 0x40000000u) throw HipError{hipErrorUnknown, "suffix sort did not converge", __FILE__, __LINE__};
+            h *= 2;
+        }
+    } else
     for (;;) {
         st.rounds++;
         // ---- regroup the freshly sorted list, publish SA/ISA, drop the singletons ---------------

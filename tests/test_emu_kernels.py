@@ -729,6 +729,22 @@ def test_pipelined_windows_of_a_large_batch(emu, oracle, pipe, monkeypatch):
         emu.bz3_free(s)
 
 
+def test_opt_in_fused_regrouping_of_the_suffix_sorter(emu, oracle, monkeypatch):
+    """BZ3_BWT_FUSED=1 (bwt.hip k_bg_*: the regrouping of a sorted list as two passes over 2048-element tiles and a one-workgroup
+    spine instead of seven launches; read per call): same primary index and bytes as the oracle on lists that end inside a tile,
+    on a tile boundary and just behind it, on runs (one group that shrinks by one per round), alternations and repeated text."""
+    monkeypatch.setenv("BZ3_BWT_FUSED", "1")
+    g = bzip3_amd.StageApi(emu)
+    t = datagen.shakespeare()
+    cases = [t[777 : 777 + n] for n in (2, 3, 9, 2047, 2048, 2049, 4097, 6143, 20000)]
+    cases += [b"a" * n for n in (2, 2048, 2049, 5000)] + [(b"ab" * 2100)[:n] for n in (2049, 4096)]
+    cases += [t[5000:5600] * 30, datagen.repeats(30000), datagen.low_entropy(20000), datagen.random_bytes(9000), bytes(range(256)) * 20]
+    for d in cases:
+        assert g.bwt(d) == oracle.bwt(d), len(d)
+    d = t[40000:70000] + t[40000:52000]
+    assert bzip3_amd.encode_block(d, 65 * 1024, emu)[2] == oracle.encode_block(d, 65 * 1024)[2]
+
+
 @pytest.mark.parametrize("env", [{"BZ3_RS_STAGED": "1"}, {"BZ3_RS_STAGED": "1", "BZ3_RS_NO_XCD": "1"}, {"BZ3_RS_NO_XCD": "1"}], ids=["staged", "staged_noxcd", "noxcd"])
 def test_opt_in_radix_scatter_variants(oracle, env):
     """The experiment switches of the radix sorter (sort.hip: BZ3_RS_STAGED = LDS-staged scatter, BZ3_RS_NO_XCD = tile = blockIdx)

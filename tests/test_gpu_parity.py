@@ -222,6 +222,62 @@ def test_batch_api_host_buffers(gpu_lib, oracle, text):
         gpu_lib.bz3_free(s)
 
 
+@pytest.mark.parametrize("pipe", [None, "1,4", "5,3", "6,2"], ids=["auto", "w1s4", "w5s3", "w6s2"])
+def test_front_end_and_tail_rings_on_gpu(gpu_lib, oracle, text, pipe, monkeypatch):
+    """The encoder's front end and the decoder's tail run their serial LZP kernels on side streams over a ring of context slots
+    (api.hip encode_group / decode_group).  Under the CPU emulator kernels run at launch, so only here do the side streams really
+    overlap the group's stream: 40 blocks (LZP applied, declined, stored) through forced ring shapes -- windows of one block
+    through four slots, a ragged last window through three, round 2's two slots of six -- and the automatic one, classic and lean
+    states: the oracle's bytes both ways."""
+    for var in ("BZ3_HIP_LZP_PIPE", "BZ3_HIP_TAIL_PIPE"):
+        if pipe:
+            monkeypatch.setenv(var, pipe)
+        else:
+            monkeypatch.delenv(var, raising=False)
+    bs = 1 << 20
+    distinct = []
+    for i in range(10):
+        if i % 5 == 3:
+            distinct.append(text[i * 50000 : i * 50000 + 60000] * 4 + text[900000:930000])  # long repeats: LZP applies (model & 2)
+        elif i == 6:
+            distinct.append(b"x" * 41)                                                       # stored (< 64 bytes)
+        elif i == 4:
+            distinct.append(datagen.random_bytes(150000, seed=4))                            # LZP declines (model 0)
+        else:
+            distinct.append(text[i * 90000 : i * 90000 + 180000 + 9000 * i])
+    want = [oracle.encode_block(d, bs)[2] for d in distinct]
+    assert {w[8] for w, d in zip(want, distinct) if len(d) >= 64} >= {0, 2}
+    blocks = [distinct[(7 * k) % 10] for k in range(40)]
+    n = len(blocks)
+    try:
+        for lean in (0, 1):
+            assert gpu_lib.bz3_hip_set_lean_states(lean) == 0
+            states = (C.c_void_p * n)(*[gpu_lib.bz3_new(bs) for _ in range(n)])
+            assert all(states)
+            cap = gpu_lib.bz3_bound(bs) + 64
+            bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+            for b, d in zip(bufs, blocks):
+                C.memmove(b, d, len(d))
+            ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+            sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+            gpu_lib.bz3_encode_blocks(states, ptrs, sizes, n)
+            if pipe:
+                w, q = (int(x) for x in pipe.split(","))
+                ring = gpu_lib.bz3_hip_debug_front_end_ring()
+                assert (ring & 0xFFFF, ring >> 16) == (w, q)
+            for k in range(n):
+                assert bytes(bufs[k][: sizes[k]]) == want[(7 * k) % 10], (lean, k)
+            bsz = (C.c_size_t * n)(*[cap] * n)
+            orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+            gpu_lib.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+            for k, d in enumerate(blocks):
+                assert gpu_lib.bz3_last_error(states[k]) == 0 and bytes(bufs[k][: len(d)]) == d, (lean, k)
+            for st in states:
+                gpu_lib.bz3_free(st)
+    finally:
+        gpu_lib.bz3_hip_set_lean_states(0)
+
+
 def test_device_resident_api(gpu_lib, oracle, text):
     import torch
 

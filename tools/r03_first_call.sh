@@ -4,8 +4,9 @@
 #   bash tools/r03_first_call.sh gpurun_out/r03_first
 # Legs:
 #   parity     the stage / block parity tests of the GPU suite (the changed kernels are in every one of them)
-#   rs_ab      radix sorter: default (16 loads in flight) | LDS-staged scatter | no XCD mapping      (tools/rs_ab.sh, 256 MiB block)
-#   ub_ab      inverse BWT: one splitter per 256 rows (default) | per 1024 rows (round 2)             (BZ3_UB_LOG_STRIDE)
+#   probes     tools/stage_probe.py on one 256 MiB text block under rocprofv3 --kernel-trace, kernel time by group:
+#              default | inverse BWT with round 2's splitters (BZ3_UB_LOG_STRIDE=10) | two-pass BWT regrouping (BZ3_BWT_FUSED=1) |
+#              LDS-staged radix scatter (BZ3_RS_STAGED=1) | radix tiles without the XCD mapping (BZ3_RS_NO_XCD=1)
 #   pipe_ab    front-end / tail rings: auto (4 slots) | two slots of 6 / 32 blocks (round 2)          (BZ3_HIP_LZP_PIPE, BZ3_HIP_TAIL_PIPE)
 #              on 768 x 32 MiB blocks (one step is ~1 min instead of ~8): t_enc - cm and t_dec - cm are the front end and the tail
 set -e
@@ -15,24 +16,37 @@ mkdir -p "$OUT"
 cd "$REPO"
 
 echo "== parity" | tee "$OUT/summary.txt"
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "stage_parity or block_parity or batch_api or device_resident" > "$OUT/parity.log" 2>&1 || true
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "stage_parity or block_parity or batch_api or device_resident or front_end_and_tail_rings" > "$OUT/parity.log" 2>&1 || true
 tail -2 "$OUT/parity.log" | tee -a "$OUT/summary.txt"
 
-echo "== rs_ab" | tee -a "$OUT/summary.txt"
-bash tools/rs_ab.sh "$OUT" 256 | tee -a "$OUT/summary.txt"
-
-echo "== ub_ab" | tee -a "$OUT/summary.txt"
-ub() {  # name, env assignment
+echo "== stage probes (256 MiB text block, rocprofv3 --kernel-trace; ms over both repetitions of tools/stage_probe.py)" | tee -a "$OUT/summary.txt"
+probe() {  # name, env assignments
     local name=$1; shift
     ( cd /tmp && export TMPDIR=/tmp && rm -rf "$OUT/$name" &&
-      env "$@" rocprofv3 --kernel-trace -d "$OUT/$name" -o pass -- python "$REPO/tools/stage_probe.py" 256 > "$OUT/$name.log" 2>&1 )
+      env "$@" rocprofv3 --kernel-trace -d "$OUT/$name" -o pass -- python "$REPO/tools/stage_probe.py" 256 > "$OUT/$name.log" 2>&1 ) || { tail -5 "$OUT/$name.log"; return; }
     local db; db=$(find "$OUT/$name" -name "*.db" | head -1)
-    python tools/rocpd_summary.py "$db" "rocprofv3 --kernel-trace -- $* python tools/stage_probe.py 256   (MI355X, ROCm 7.2)" > "$OUT/ub_ab_$name.txt"
+    python tools/rocpd_summary.py "$db" "rocprofv3 --kernel-trace -- $* python tools/stage_probe.py 256   (MI355X, ROCm 7.2)" > "$OUT/probe_$name.txt"
     rm -rf "$OUT/$name"
-    echo "$name: $(grep -E 'k_ub_walk_(len|emit)|k_ub_jump' "$OUT/ub_ab_$name.txt" | awk '{print $1, $(NF-4) " ms;"}' | tr '\n' ' ')"
+    python - "$OUT/probe_$name.txt" "$name" <<'PY'
+import sys
+groups = {"sorter (k_rs_*, k_scan_*)": ("k_rs_", "k_scan_"), "BWT regrouping (k_bwt_*, k_bg_*)": ("k_bwt_", "k_bg_"), "unBWT walks": ("k_ub_walk",),
+          "LZP links": ("k_lzp_links",), "LZP driver": ("k_lzp_driver",)}
+tot = dict.fromkeys(groups, 0.0)
+for line in open(sys.argv[1]):
+    f = line.split()
+    if line.startswith("#") or len(f) < 6 or not f[-5].replace(".", "").isdigit():
+        continue
+    for g, pats in groups.items():
+        if any(p in line[:110] for p in pats):
+            tot[g] += float(f[-5])
+print(f"{sys.argv[2]:<12}" + "   ".join(f"{g} {v:8.1f}" for g, v in tot.items()))
+PY
 }
-ub stride256 BZ3_UB_LOG_STRIDE=8 | tee -a "$OUT/summary.txt"
-ub stride1024 BZ3_UB_LOG_STRIDE=10 | tee -a "$OUT/summary.txt"
+probe default BZ3_PROBE_DUMMY=0 | tee -a "$OUT/summary.txt"          # what the library does now
+probe stride1024 BZ3_UB_LOG_STRIDE=10 | tee -a "$OUT/summary.txt"    # inverse BWT: round 2's one splitter per 1024 rows
+probe fused BZ3_BWT_FUSED=1 | tee -a "$OUT/summary.txt"              # BWT: two-pass regrouping (opt-in)
+probe staged BZ3_RS_STAGED=1 | tee -a "$OUT/summary.txt"             # sorter: LDS-staged scatter (opt-in)
+probe noxcd BZ3_RS_NO_XCD=1 | tee -a "$OUT/summary.txt"              # sorter: tile = blockIdx
 
 echo "== pipe_ab" | tee -a "$OUT/summary.txt"
 pipe() {  # name, env assignments
