@@ -628,14 +628,15 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     for (s32 i = 0; i < n; i++)
         if (sizes[i] > 0 && (u64)sizes[i] > n_max) n_max = (u64)sizes[i];
     const size_t ctx_bytes = lzp_encode_ctx_bytes(n_max + 64) + 65536;
-    // contexts = what fits into half of the memory that is free right now (the decode call that follows needs the other half:
-    // staged payloads + the swap buffers of its tail windows)
+    // contexts = what fits into 7/10 of the memory that is free right now beside the sorter's workspace (the rest: the blocks' borrowed
+    // swap buffers, allocator slack).  A workspace that grew far beyond the sorter's needs for this is handed back when the call
+    // ends (below): the decode call that follows needs the room for staged payloads and the swap buffers of its tail windows.
     size_t budget = (size_t)32 << 30;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t have = lead->ctx->ws_cap;  // the arena already holds this much
-            budget = (free_b + have > need) ? (free_b + have - need) / 2 : 0;
+            budget = (free_b + have > need) ? (free_b + have - need) / 10 * 7 : 0;
         }
     }
     s32 window = 1, ns = 2;
@@ -723,6 +724,12 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     const float cm_ms = run_cm_jobs(lead->ctx, arena, jobs, d_jobs, lead->stream, lead->ev0, lead->ev1,
                                     [](const CmEncodeJob * j, u32 nj, hipStream_t st, int variant) { cm_encode_batch(j, nj, st, variant); });
     for (s32 i = 0; i < n; i++) encode_finish(sts[i], cm_ms);
+    if (lead->ctx->ws_cap > 2 * need + ((size_t)1 << 30)) {  // mostly LZP contexts of a large batch: hand the memory back (see above)
+        HIP_CHECK(hipStreamSynchronize(s));  // the side streams are idle: every driver launch has been waited for
+        (void)hipFree(lead->ctx->ws);
+        lead->ctx->ws = nullptr;
+        lead->ctx->ws_cap = 0;
+    }
 }
 
 // ======================================================================================================
