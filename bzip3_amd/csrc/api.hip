@@ -60,8 +60,14 @@ struct DeviceCtx {
     void ensure_aux() {  // caller holds mu
         if (aux[0]) return;
         HIP_CHECK(hipEventCreate(&ev_prep));
+        // experiments: BZ3_HIP_AUX_PRIO=1 creates the side streams with the highest stream priority (the serial kernels on them are
+        // latency-bound single workgroups whose run time grows from 0.75 s to 1.23 s beside the whole-GPU kernels of the group's stream)
+        int prio_least = 0, prio_greatest = 0;
+        const bool prio = getenv("BZ3_HIP_AUX_PRIO") != nullptr && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess &&
+                          prio_greatest != prio_least;
         for (int k = 0; k < AUX; k++) {
-            HIP_CHECK(hipStreamCreateWithFlags(&aux[k], hipStreamNonBlocking));
+            if (prio) HIP_CHECK(hipStreamCreateWithPriority(&aux[k], hipStreamNonBlocking, prio_greatest));
+            else HIP_CHECK(hipStreamCreateWithFlags(&aux[k], hipStreamNonBlocking));
             HIP_CHECK(hipEventCreate(&ev_d0[k]));
             HIP_CHECK(hipEventCreate(&ev_d1[k]));
         }

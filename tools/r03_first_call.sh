@@ -62,3 +62,4 @@ PY
 }
 pipe ring BZ3_PIPE_DUMMY=0 | tee -a "$OUT/summary.txt"
 pipe round2 BZ3_HIP_LZP_PIPE=6,2 BZ3_HIP_TAIL_PIPE=32,2 | tee -a "$OUT/summary.txt"
+pipe ring_prio BZ3_HIP_AUX_PRIO=1 | tee -a "$OUT/summary.txt"   # side streams at the highest stream priority (opt-in)
