@@ -18,6 +18,11 @@ for d in cases:
     idx, u = o.bwt(d)
     assert g.unbwt(u, idx) == (0, d), len(d)
 print("stages ok", flush=True)
+os.environ["BZ3_BWT_FUSED"] = "1"  # the opt-in two-pass regrouping of the suffix sorter (read per call)
+for d in cases + [t[777:777 + n] for n in (2047, 2048, 2049, 4097)] + [b"a" * 2049]:
+    assert g.bwt(d) == o.bwt(d), len(d)
+del os.environ["BZ3_BWT_FUSED"]
+print("fused regrouping ok", flush=True)
 bs = 65 * 1024
 def batch(n, pipe):
     for var in ("BZ3_HIP_LZP_PIPE", "BZ3_HIP_TAIL_PIPE"):
