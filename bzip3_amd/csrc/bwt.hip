@@ -474,7 +474,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
         u32 * vcur = val[cur], * vfree = val[cur ^ 1];  // suffixes of the sorted list / a free buffer of the same size
         const u32 max_tiles = (u32)(((u64)n + BG_TILE - 1) / BG_TILE);
         u32 * tile_head = scanA;  // the flag / scan buffer of the seven-launch form is free here
-        u32 * tile_keep = scanA + (((size_t)max_tiles + 63) & ~(size_t)63);
+        u32 * tile_keep = scanA + max_tiles;  // 2 * ceil(n / 2048) <= n for every n >= 2
         u32 * grp = headslot;     // ranks of the compacted suffixes
         for (;;) {
             st.rounds++;
