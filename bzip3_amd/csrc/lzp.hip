@@ -110,21 +110,41 @@ __device__ __forceinline__ u64 lz_eqmask48(const u8 * __restrict__ in, u32 p, u3
 // ---- 2. static events: one bit per position whose hash predecessor passes the pre-test ---------------
 __global__ void __launch_bounds__(LZ_BLOCK) k_lzp_static(const u8 * __restrict__ in, u32 n, const u32 * __restrict__ prev, u32 * __restrict__ cand_bits,
                                                         u32 nwords) {
+    // A wave takes 256 consecutive positions per step, four per lane: the four links first, then the sixteen pre-test loads of the
+    // four positions, all in flight together (branch-free: a position without a predecessor compares with position 0 and is
+    // masked) -- per position two dependent round trips, which one position per lane and step exposed in full.
     const u32 main_end = n - (LZ_MIN + 32);
     const u64 wave_global = (u64)blockIdx.x * (LZ_BLOCK / WAVE) + wave_id();
     const u64 stride = (u64)gridDim.x * (LZ_BLOCK / WAVE);
-    for (u64 base = wave_global * WAVE; base < (u64)nwords * 32; base += stride * WAVE) {
-        const u64 p = base + lane_id();
-        bool ev = false;
-        if (p >= 4 && p < main_end) {
-            const u32 v = prev[lz_lk((u32)p)];
-            ev = v > 0 && lz_pretest(in, (u32)p, v);
+    const u64 last = (u64)n - 1;
+    for (u64 base = wave_global * (4 * WAVE); base < (u64)nwords * 32; base += stride * (4 * WAVE)) {
+        u32 v[4];
+        bool live[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u64 p = base + (u64)q * WAVE + lane_id();
+            live[q] = p >= 4 && p < main_end;
+            v[q] = prev[lz_lk((u32)(p < last ? p : last))];
         }
-        const u64 bits = __ballot(ev);
-        if (lane_id() == 0) {
-            const u32 w = (u32)(base >> 5);
-            if (w < nwords) cand_bits[w] = (u32)bits;
-            if (w + 1 < nwords) cand_bits[w + 1] = (u32)(bits >> 32);
+        u32 a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u64 p = base + (u64)q * WAVE + lane_id();
+            const u32 pp = live[q] ? (u32)p : 0u, vv = live[q] ? v[q] : 0u;  // both + LZ_MIN stay inside the block
+            a0[q] = load_u32_any(in + pp);
+            b0[q] = load_u32_any(in + vv);
+            a1[q] = load_u32_any(in + pp + LZ_MIN - 4);
+            b1[q] = load_u32_any(in + vv + LZ_MIN - 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const bool ev = live[q] && v[q] > 0 && ((a0[q] ^ b0[q]) | (a1[q] ^ b1[q])) == 0;  // :143-144, as lz_pretest
+            const u64 bits = __ballot(ev);
+            if (lane_id() == 0) {
+                const u32 w = (u32)((base + (u64)q * WAVE) >> 5);
+                if (w < nwords) cand_bits[w] = (u32)bits;
+                if (w + 1 < nwords) cand_bits[w + 1] = (u32)(bits >> 32);
+            }
         }
     }
 }
@@ -413,7 +433,7 @@ void lzp_encode_prepare(const u8 * d_in, u32 n, LzpEncodeCtx & c, Arena & ctx, A
     }
     HIP_CHECK(hipMemsetAsync(c.skip, 0, (size_t)c.nwords * 4, s));
     HIP_CHECK(hipMemsetAsync(c.mstart, 0, (size_t)c.nwords * 4, s));
-    u32 grid = (c.nwords * 32u / WAVE + (LZ_BLOCK / WAVE) - 1) / (LZ_BLOCK / WAVE);
+    u32 grid = (c.nwords * 32u / (4 * WAVE) + (LZ_BLOCK / WAVE)) / (LZ_BLOCK / WAVE);  // a wave per 256 positions (k_lzp_static)
     if (grid > 8192) grid = 8192;
     launch(k_lzp_static, dim3(grid), dim3(LZ_BLOCK), 0, s, d_in, n, (const u32 *)c.prev, c.cand_bits, c.nwords);
 }
