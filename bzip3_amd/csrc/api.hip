@@ -656,8 +656,8 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
             arena = lead->ctx->arena_for(need + (size_t)ns * (size_t)window * (ctx_bytes + sizeof(LzpDriverJob) + 256) +
                                          (size_t)n * (sizeof(CmEncodeJob) + CM_SIDE_BYTES + 256) + cm_scratch_bytes((size_t)n) + 65536);
             break;
-        } catch (const HipError & e) {
-            if (e.code != hipErrorOutOfMemory || (ns == 2 && window == 1)) throw;
+        } catch (const HipError &) {  // out of memory, or whatever else the runtime answers to a size it does not like
+            if (ns == 2 && window == 1) throw;
             (void)hipGetLastError();
             if (ns > 2) ns = 2;
             else window = (window + 1) / 2;
