@@ -435,7 +435,7 @@ def main():
             lib.bz3_hip_last_bwt_stats(states[0], C.byref(r), C.byref(p), C.byref(e))
             stage["bwt"] = {"rounds": r.value, "radix_passes": p.value, "sorted_elements": e.value}
             ring = lib.bz3_hip_debug_front_end_ring()  # the encoder's front-end pipeline: context slots x blocks per window
-            stage["front_end_ring"] = {"slots": ring >> 16, "window": ring & 0xFFFF}
+            stage["front_end_ring"] = {"slots": (ring >> 16) & 0xFF, "window": ring & 0xFFFF, "workspace_handed_back": bool(ring >> 30)}
             if cpu_block == block_size and not coded_kept:  # a few ms of device-to-device copies inside the timed region, first recorded step only
                 for i in range(cpu_n):
                     coded_kept.append(bufs[i][: sizes[i]].clone())

@@ -730,11 +730,14 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     const float cm_ms = run_cm_jobs(lead->ctx, arena, jobs, d_jobs, lead->stream, lead->ev0, lead->ev1,
                                     [](const CmEncodeJob * j, u32 nj, hipStream_t st, int variant) { cm_encode_batch(j, nj, st, variant); });
     for (s32 i = 0; i < n; i++) encode_finish(sts[i], cm_ms);
-    if (lead->ctx->ws_cap > 2 * need + ((size_t)1 << 30)) {  // mostly LZP contexts of a large batch: hand the memory back (see above)
+    size_t slack = (size_t)1 << 30;
+    if (const char * e = getenv("BZ3_HIP_WS_KEEP_MB")) slack = (size_t)strtoull(e, nullptr, 10) << 20;  // tests / experiments
+    if (lead->ctx->ws_cap > 2 * need + slack) {  // mostly LZP contexts of a large batch: hand the memory back (see above)
         HIP_CHECK(hipStreamSynchronize(s));  // the side streams are idle: every driver launch has been waited for
         (void)hipFree(lead->ctx->ws);
         lead->ctx->ws = nullptr;
         lead->ctx->ws_cap = 0;
+        g_front_end_ring.fetch_or(1 << 30);
     }
 }
 

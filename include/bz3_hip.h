@@ -55,7 +55,7 @@ BZIP3_API int bz3_hip_cm_variant_for(int device, int blocks, int encode);
 BZIP3_API int bz3_hip_debug_peak_concurrent_groups(int reset);
 
 /* Test hook: shape of the ring the last bz3_encode_blocks / bz3_hip_encode_blocks_device group ran its front end through:
- * blocks per window | context slots << 16 (0 before the first call).  The serial LZP drivers of a window run on a side stream
+ * blocks per window | context slots << 16 | (workspace handed back when the call ended) << 30 (0 before the first call).  The serial LZP drivers of a window run on a side stream
  * while the whole-GPU stages of the other slots' windows run on the group's stream; the shape follows the free memory. */
 BZIP3_API int bz3_hip_debug_front_end_ring(void);
 

@@ -628,10 +628,17 @@ def run(n, size=300):
     for s in states:
         lib.bz3_free(s)
     ring = lib.bz3_hip_debug_front_end_ring()
-    return ring & 0xFFFF, ring >> 16
+    released.append(bool(ring >> 30))
+    return ring & 0xFFFF, (ring >> 16) & 0xFF
+released = []
 assert lib.bz3_hip_debug_front_end_ring() == 0
 assert run(5) == (5, 2)            # small batch: one window, two slots
 assert run(13) == (8, 4)           # 16 GiB "free": windows of 8 through four slots
+assert released == [False, False]  # workspaces of this size are kept for the next call
+os.environ["BZ3_HIP_WS_KEEP_MB"] = "0"  # ... unless they grew beyond twice the sorter's needs + this slack (1 GiB by default): the contexts of
+assert run(13, 60000) == (8, 4) and released[-1]    # 4 x 8 blocks of 60 KB did; the workspace is handed back when the call ends,
+assert run(13, 60000) == (8, 4) and released[-1]    # and the next call allocates again
+del os.environ["BZ3_HIP_WS_KEEP_MB"]
 lib.bz3_hip_release_cached_memory()  # drop the workspace: the next call has to allocate again
 os.environ["BZ3_EMU_MALLOC_LIMIT"] = str(16 << 20)
 w, ns = run(13, 60000)             # an LZP context is ~8.6 bytes per input byte: 4 x 8 of them + the sorter's workspace need ~28 MiB

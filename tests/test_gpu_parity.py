@@ -264,7 +264,7 @@ def test_front_end_and_tail_rings_on_gpu(gpu_lib, oracle, text, pipe, monkeypatc
             if pipe:
                 w, q = (int(x) for x in pipe.split(","))
                 ring = gpu_lib.bz3_hip_debug_front_end_ring()
-                assert (ring & 0xFFFF, ring >> 16) == (w, q)
+                assert (ring & 0xFFFF, (ring >> 16) & 0xFF) == (w, q)
             for k in range(n):
                 assert bytes(bufs[k][: sizes[k]]) == want[(7 * k) % 10], (lean, k)
             bsz = (C.c_size_t * n)(*[cap] * n)
