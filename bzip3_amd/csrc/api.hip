@@ -52,8 +52,8 @@ struct DeviceCtx {
     size_t ws_cap = 0;
     int cus = 256;          // compute units: one full-model CM workgroup fits per CU
     // side streams of the device: the serial LZP drivers of a window of blocks run there while the calling thread drives the
-    // whole-GPU stages of the neighbouring windows on the group's stream (encode_group: one side stream per context slot, so
-    // that the drivers of consecutive windows overlap; decode_group: aux[0] for both of its windows)
+    // whole-GPU stages of the neighbouring windows on the group's stream (encode_group and decode_group: one side stream per slot
+    // of their rings, so that the serial kernels of consecutive windows overlap)
     static constexpr int AUX = 4;
     hipStream_t aux[AUX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_prep = nullptr, ev_d0[AUX] = {nullptr, nullptr, nullptr, nullptr}, ev_d1[AUX] = {nullptr, nullptr, nullptr, nullptr};
