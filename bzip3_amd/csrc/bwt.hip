@@ -288,23 +288,46 @@ __device__ __forceinline__ u32 bg_block_excl_max(u32 v, u32 * lds) {  // lds: BL
 constexpr int BG_SPINE = 1024;
 __global__ void __launch_bounds__(BG_SPINE) k_bg_spine(u32 * __restrict__ tile_head, u32 * __restrict__ tile_keep, u32 tiles, u32 * __restrict__ total) {
     __shared__ u32 lds[BG_SPINE / WAVE + 1];
-    const u32 per = (tiles + BG_SPINE - 1) / BG_SPINE;
+    // a thread owns `per` consecutive tiles and walks them eight at a time, the loads of a batch in flight together (up to 256
+    // tiles per thread at 511 MiB: one exposed round trip per tile would cost more than the passes this kernel sits between)
+    const u32 per = (((tiles + BG_SPINE - 1) / BG_SPINE) + 7u) & ~7u;
     const u32 t0 = threadIdx.x * per, t1 = t0 + per < tiles ? t0 + per : tiles;
+    const u32 last = tiles - 1u;
     u32 hp = 0, sum = 0;
-    for (u32 t = t0; t < t1; t++) {
-        const u32 h = tile_head[t];
-        hp = h > hp ? h : hp;
-        sum += tile_keep[t];
+    for (u32 t = t0; t < t1; t += 8) {
+        u32 h[8], c[8];
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) {
+            const u32 i = t + k < last ? t + k : last;
+            h[k] = tile_head[i];
+            c[k] = tile_keep[i];
+        }
+#pragma unroll
+        for (u32 k = 0; k < 8; k++)
+            if (t + k < t1) {
+                hp = h[k] > hp ? h[k] : hp;
+                sum += c[k];
+            }
     }
     u32 run_hp = bg_block_excl_max<BG_SPINE>(hp, lds);
     u32 all;
     u32 run_sum = block_excl_add<BG_SPINE>(sum, lds, all);
-    for (u32 t = t0; t < t1; t++) {
-        const u32 h = tile_head[t], c = tile_keep[t];
-        tile_head[t] = run_hp;
-        tile_keep[t] = run_sum;
-        run_hp = h > run_hp ? h : run_hp;
-        run_sum += c;
+    for (u32 t = t0; t < t1; t += 8) {
+        u32 h[8], c[8];
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) {
+            const u32 i = t + k < last ? t + k : last;
+            h[k] = tile_head[i];
+            c[k] = tile_keep[i];
+        }
+#pragma unroll
+        for (u32 k = 0; k < 8; k++)
+            if (t + k < t1) {  // entries at and beyond t1 belong to the next thread: read (clamped), never written
+                tile_head[t + k] = run_hp;
+                tile_keep[t + k] = run_sum;
+                run_hp = h[k] > run_hp ? h[k] : run_hp;
+                run_sum += c[k];
+            }
     }
     if (threadIdx.x == 0) *total = all;
 }
