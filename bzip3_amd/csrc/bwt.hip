@@ -337,6 +337,7 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bg_apply(const u64 * __restrict__ 
                                                       const u32 * __restrict__ tile_head, const u32 * __restrict__ tile_keep, u32 * __restrict__ sa,
                                                       u32 * __restrict__ isa, u32 * __restrict__ vals_out, u32 * __restrict__ slots_out, u32 * __restrict__ grp_out) {
     __shared__ u32 lds[BW_BLOCK / WAVE + 1];
+    __shared__ u32 st_v[BG_TILE], st_s[BG_TILE], st_g[BG_TILE];  // the tile's part of the compacted list, staged so that it leaves coalesced
     const u64 base = (u64)blockIdx.x * BG_TILE + (u64)threadIdx.x * BG_ITEMS;
     const u64 lbase = base < m ? base : (u64)m - 1;  // threads past the end load something valid and use none of it
     u64 kv[BG_ITEMS + 2];
@@ -363,8 +364,8 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bg_apply(const u64 * __restrict__ 
     }
     u32 run_hp = bg_block_excl_max<BW_BLOCK>(hp, lds);
     run_hp = carry_hp > run_hp ? carry_hp : run_hp;
-    u32 all;
-    u32 out = tile_off + block_excl_add<BW_BLOCK>(keep, lds, all);
+    u32 all;  // elements of this tile that stay active
+    u32 out = block_excl_add<BW_BLOCK>(keep, lds, all);  // this thread's first slot in the tile's part of the compacted list
     // rank of an element = slot of its group's head.  The head of the group that reaches into this thread's elements from the left
     // costs one gather; from the first head on, the slots are in registers (sl[j] = k itself in the first round).
     u32 run_rank = 0;  // run_hp == 0 only where element 0 of the list starts the thread, and that one is a head
@@ -391,12 +392,20 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bg_apply(const u64 * __restrict__ 
             if (uniq) {
                 sa[sl[j]] = v[j];
             } else {
-                vals_out[out] = v[j];
-                slots_out[out] = sl[j];
-                grp_out[out] = rank[j];
+                st_v[out] = v[j];
+                st_s[out] = sl[j];
+                st_g[out] = rank[j];
                 out++;
             }
         }
+    }
+    __syncthreads();
+    // (a thread's kept elements are consecutive slots: written directly, every store instruction of a wave would touch 64 scattered
+    // words; from LDS consecutive lanes write consecutive words)
+    for (u32 idx = threadIdx.x; idx < all; idx += BW_BLOCK) {
+        vals_out[tile_off + idx] = st_v[idx];
+        slots_out[tile_off + idx] = st_s[idx];
+        grp_out[tile_off + idx] = st_g[idx];
     }
 }
 #undef BG_FLAGS
