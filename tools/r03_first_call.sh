@@ -1,6 +1,6 @@
 #!/bin/bash
 # First GPU call of round 3: time everything that went into the source AFTER round 2's GPU budget was spent, each against the
-# configuration the round measured.  About 12 GPU-minutes; every leg writes a small text file under <out>.
+# configuration the round measured.  About 15 GPU-minutes; every leg writes a small text file under <out>.
 #   bash tools/r03_first_call.sh gpurun_out/r03_first
 # Legs:
 #   parity     the stage / block parity tests of the GPU suite (the changed kernels are in every one of them)
