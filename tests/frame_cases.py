@@ -4,7 +4,7 @@ import ctypes as C
 
 import pytest
 
-from oracle_lib import RefLib
+from oracle_lib import RefLib, require_ref
 
 
 def frame_calls(L, bs, data, mutate=None, out_room=None):
@@ -26,9 +26,7 @@ def frame_calls(L, bs, data, mutate=None, out_room=None):
 
 def check(lib, five, bs, only=None):
     """`five`: data that makes 5 chunks at block size bs (the last one short)."""
-    ref = RefLib()
-    if not ref.available:
-        pytest.skip("oracle/_ref not built")
+    ref = require_ref()
     assert 4 * bs < len(five) < 5 * bs
     exact = five[: 2 * bs]  # multiple of the block size: the (sic) empty last chunk of src/libbz3.c:914
     for data in ((five, exact, five[:100], b"") if only is None else (five, exact)):

@@ -214,6 +214,19 @@ class RefLib:
         return self.lib is not None
 
 
+def require_ref():
+    """The real reference for a parity test that must not pass without comparing (every -m gpu test that checks bytes against
+    oracle/_ref): fails -- never skips -- when oracle/_ref/libbz3ref.so did not travel to the box (`make -C oracle` builds it
+    where /root/reference exists; gpurun ships the built file)."""
+    import pytest
+
+    r = RefLib()
+    if not r.available:
+        pytest.fail("oracle/_ref/libbz3ref.so is missing: this test compares with the REAL reference and does not pass without it "
+                    "(run `make -C oracle` in the build container before the snapshot is taken)")
+    return r
+
+
 def bind_libbz3(L):
     """Declare the libbz3.h prototypes (include/libbz3.h) on a loaded library handle."""
     L.bz3_version.restype = C.c_char_p
