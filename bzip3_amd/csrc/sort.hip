@@ -6,7 +6,7 @@
 //                  (digit, tile) bucket
 //   k_rs_scatter : re-reads the tile, ranks each key among equal digits with wave64 ballots
 //                  (match-any over the 8 digit bits + popcount below the lane), adds the per-wave
-//                  running counts kept in LDS, and scatters key+value to its final slot.  The
+//                  running counts kept in LDS, orders the tile by digit in LDS and writes key+value out in runs.  The
 //                  tile is walked wave-striped (wave w owns keys [1024w, 1024w+1024), 16 rounds of
 //                  64 consecutive keys) so the order of equal digits is preserved: the pass is stable.
 // Algorithmic traffic per pass and element: sizeof(K) (hist) + sizeof(K)+4 (read) + sizeof(K)+4 (write).
@@ -164,96 +164,14 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_hist(const K * __restrict__ key
     hist[(u64)threadIdx.x * tiles + tile] = bins[threadIdx.x];
 }
 
+// The tile is first put in digit order in LDS, then written out with consecutive lanes on consecutive destinations -- a digit's ~16
+// keys of a tile leave as one run instead of 16 separate 8-byte stores.  Measured in round 3 on a 256 MiB block (full-n pass of
+// 8-byte keys + 4-byte values): 1.46 ms = 4.4 TB/s of algorithmic traffic against 2.37 ms for the direct scatter
+// (profiles/r03_kernel_stats_stages_256MiB_staged.txt), so the direct scatter is gone.
+// Slot of a key inside the tile = start of its digit + keys of that digit in earlier waves + rank in its own wave, which is the
+// stable order.  LDS: sizeof(K) * 4096 + 16 KiB + 6 KiB (54 KiB for 8-byte keys: two workgroups per CU).
 template <typename K, bool IOTA, bool WKEYS>
 __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const K * __restrict__ kin, K * __restrict__ kout, const u32 * __restrict__ vin,
-                                                        u32 * __restrict__ vout, u64 n, int shift, const u32 * __restrict__ offs, u32 tiles,
-                                                        u32 iota_split, u32 out_base, u32 xcd) {
-    __shared__ u32 cnt[RS_WAVES][RS_RADIX];
-    __shared__ u32 gbase[RS_RADIX];
-    const u32 tile = rs_tile_of_block(blockIdx.x, tiles, xcd != 0u);
-    if (tile >= tiles) return;
-    const int w = wave_id(), l = lane_id();
-#pragma unroll
-    for (int k = 0; k < RS_WAVES; k++) cnt[k][threadIdx.x] = 0;
-    __syncthreads();
-
-    const u64 tile_base = (u64)tile * RS_TILE;
-    const u64 wbase = tile_base + (u64)w * RS_WAVE_SPAN + l;
-    K key[RS_ROUNDS];
-    u32 local[RS_ROUNDS];
-    const u64 lt = lanemask_lt();
-    const u64 last = n - 1;
-
-    // every key of the tile is requested before the ranking starts (branch-free: clamped index, the lane is masked below)
-#pragma unroll
-    for (int r = 0; r < RS_ROUNDS; r++) {
-        const u64 i = wbase + (u64)r * WAVE;
-        key[r] = kin[i < n ? i : last];
-    }
-#pragma unroll
-    for (int r = 0; r < RS_ROUNDS; r++) {
-        const u64 i = wbase + (u64)r * WAVE;
-        const bool valid = i < n;
-        const u32 d = rs_digit(key[r], shift);
-        u64 peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const bool bit = (d >> b) & 1u;
-            const u64 bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
-        }
-        const u32 below = (u32)__popcll(peers & lt);
-        const u32 pre = valid ? cnt[w][d] : 0u;
-        wave_sync();  // every lane has read the running count before a leader bumps it
-        if (valid && below == 0) cnt[w][d] = pre + (u32)__popcll(peers);
-        wave_sync();
-        local[r] = pre + below;
-    }
-    // the values travel while the per-wave counts are turned into offsets
-    u32 val[RS_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < RS_ROUNDS; r++) {
-        const u64 i = wbase + (u64)r * WAVE;
-        val[r] = IOTA ? (u32)i + ((u32)i >= iota_split ? 1u : 0u) : vin[i < n ? i : last];
-    }
-    __syncthreads();
-    {
-        const u32 d = threadIdx.x;
-        u32 run = 0;
-#pragma unroll
-        for (int k = 0; k < RS_WAVES; k++) {
-            u32 c = cnt[k][d];
-            cnt[k][d] = run;
-            run += c;
-        }
-        gbase[d] = offs[(u64)d * tiles + tile] + out_base;
-    }
-    __syncthreads();
-    // destinations first (32 LDS reads in flight together; a masked lane reads some valid counter and ignores it), stores after.
-    // A destination is < n + out_base, and n < 2^32 by the API (block sizes are int32).
-#pragma unroll
-    for (int r = 0; r < RS_ROUNDS; r++) {
-        const u32 d = rs_digit(key[r], shift);
-        local[r] += gbase[d] + cnt[w][d];
-    }
-#pragma unroll
-    for (int r = 0; r < RS_ROUNDS; r++) {
-        const u64 i = wbase + (u64)r * WAVE;
-        if (i < n) {
-            if (WKEYS) kout[local[r]] = key[r];
-            vout[local[r]] = val[r];
-        }
-    }
-}
-
-// Opt-in variant (BZ3_RS_STAGED=1; NOT the default until it has been measured on the GPU): the tile is first put in digit order in
-// LDS, then written out with consecutive lanes on consecutive destinations -- a digit's ~16 keys of a tile leave as one run instead
-// of 16 separate 8-byte stores (round 1 measured 4.6x write amplification for the direct scatter; an earlier staged version showed
-// "no gain" at a time when the serialised loads above were what bounded the kernel, so the comparison has to be repeated).
-// Same arguments, same result: slot of a key inside the tile = start of its digit + keys of that digit in earlier waves + rank in
-// its own wave, which is the stable order.  LDS: sizeof(K) * 4096 + 16 KiB + 6 KiB (54 KiB for 8-byte keys: two workgroups per CU).
-template <typename K, bool IOTA, bool WKEYS>
-__global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter_staged(const K * __restrict__ kin, K * __restrict__ kout, const u32 * __restrict__ vin,
                                                                u32 * __restrict__ vout, u64 n, int shift, const u32 * __restrict__ offs, u32 tiles,
                                                                u32 iota_split, u32 out_base, u32 xcd) {
     __shared__ u32 cnt[RS_WAVES][RS_RADIX];
@@ -356,12 +274,11 @@ void radix_pass(const K * kin, K * kout, const u32 * vin, u32 * vout, u64 n, int
     const u32 tiles = (u32)((n + RS_TILE - 1) / RS_TILE);
     size_t m = tmp.mark();
     u32 * hist = tmp.take<u32>((size_t)tiles * RS_RADIX);
-    static const u32 xcd = getenv("BZ3_RS_NO_XCD") ? 0u : 1u;  // experiments: BZ3_RS_NO_XCD=1 = tile = blockIdx
+    const u32 xcd = 1u;  // contiguous tiles per XCD (measured round 3: 2.37 against 3.58 ms per full-n pass with tile = blockIdx)
     const dim3 sgrid(rs_grid(tiles, xcd != 0u));
     launch(k_rs_hist<K>, sgrid, dim3(RS_BLOCK), 0, s, kin, n, shift, hist, tiles, xcd);
     exclusive_scan_u32(hist, (u64)tiles * RS_RADIX, nullptr, tmp, s);
     const bool iota = vin == nullptr, wkeys = kout != nullptr;
-    static const bool staged = getenv("BZ3_RS_STAGED") != nullptr;  // experiments: the LDS-staged scatter (see k_rs_scatter_staged)
 #define BZ3_RS_LAUNCH(KERNEL, I, W) \
     launch(KERNEL<K, I, W>, sgrid, dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base, xcd)
 #define BZ3_RS_DISPATCH(KERNEL)                           \
@@ -371,10 +288,7 @@ void radix_pass(const K * kin, K * kout, const u32 * vin, u32 * vout, u64 n, int
         else if (wkeys) BZ3_RS_LAUNCH(KERNEL, false, true);          \
         else BZ3_RS_LAUNCH(KERNEL, false, false);                    \
     } while (0)
-    if (staged)
-        BZ3_RS_DISPATCH(k_rs_scatter_staged);
-    else
-        BZ3_RS_DISPATCH(k_rs_scatter);
+    BZ3_RS_DISPATCH(k_rs_scatter);
 #undef BZ3_RS_DISPATCH
 #undef BZ3_RS_LAUNCH
     tmp.release(m);

@@ -178,3 +178,35 @@ def nasty_cases():
         cases["alpha%d" % sigma] = bytes(np.concatenate([vals, body, vals[::-1]]))
     cases["zerotail"] = b"ab\0ab\0\0ab" * 40 + b"ab\0\0\0\0\0\0\0"
     return cases
+
+
+def _fib_string(n):
+    a, b = b"a", b"ab"
+    while len(b) < n:
+        a, b = b, b + a
+    return b[:n]
+
+
+def suffix_sorter_cases():
+    """Inputs for every path of the round-3 suffix sorter (bwt.hip): groups the resolve kernel finishes in LDS (text, small
+    alphabets: counting for groups <= 64, the bitonic network above), groups of > 512 suffixes that take the big path once or
+    several times (a phrase repeated in random surroundings), lists that overflow it or repeat too deeply and fall back to rank
+    doubling (runs, periods, Fibonacci strings, a passage repeated verbatim), suffixes that end inside a window (zero-coded tails),
+    and sizes around the tile geometry (1536-slot anchors, 2048-slot windows)."""
+    rng = np.random.default_rng(5)
+    t = shakespeare()
+    letters = lambda k: bytes(rng.integers(97, 123, size=k, dtype=np.uint8))
+    c = {
+        "text300k": t[:300000], "two": bytes(rng.integers(0, 2, size=20000, dtype=np.uint8)), "four": bytes(rng.integers(0, 4, size=30000, dtype=np.uint8) + 65),
+        "aaaa": b"a" * 5000, "ab": b"ab" * 4000, "abc": b"abc" * 3000 + b"x", "fib": _fib_string(20000), "zeros+text": b"\0" * 3000 + t[1000:9000] + b"\0" * 2000,
+        "deeprep": t[5000:9000] + t[100000:103000] + t[5000:9000] + b"#" + t[5000:9000], "allbytes": bytes(range(256)) * 40,
+        "tail0": t[2000:6000] + b"\0" * 10, "n2": b"ab", "n2b": b"aa", "n3": b"aba", "n15": b"aaaaaaaaaaaaaab", "n17": t[:17],
+        # 1200 copies of a 22-letter phrase among 150 k random letters: groups of 1200 that one more window resolves
+        "phrase1": b"".join(b"quickbrownfoxjumpsover" + letters(110) for _ in range(1200)),
+        # a 40-letter phrase: its first positions need several big rounds (11 letters per 56-bit window)
+        "phrase3": b"".join(b"thequickbrownfoxjumpsoverthelazydogagain" + letters(400) for _ in range(700)),
+    }
+    for n in (1535, 1536, 1537, 2047, 2048, 2049, 3071, 3072, 3073, 4097):
+        c["text%d" % n] = t[777 : 777 + n]
+        c["pair%d" % n] = (t[9000:9000 + n // 2] * 2)[:n]
+    return c

@@ -736,47 +736,25 @@ def test_pipelined_windows_of_a_large_batch(emu, oracle, pipe, monkeypatch):
         emu.bz3_free(s)
 
 
-def test_opt_in_fused_regrouping_of_the_suffix_sorter(emu, oracle, monkeypatch):
-    """BZ3_BWT_FUSED=1 (bwt.hip k_bg_*: the regrouping of a sorted list as two passes over 2048-element tiles and a one-workgroup
-    spine instead of seven launches; read per call): same primary index and bytes as the oracle on lists that end inside a tile,
-    on a tile boundary and just behind it, on runs (one group that shrinks by one per round), alternations and repeated text."""
-    monkeypatch.setenv("BZ3_BWT_FUSED", "1")
+SORTER_CASES = datagen.suffix_sorter_cases()
+
+
+@pytest.mark.parametrize("name", sorted(SORTER_CASES))
+def test_suffix_sorter_paths(emu, oracle, name):
+    d = SORTER_CASES[name]
     g = bzip3_amd.StageApi(emu)
+    assert g.bwt(d) == oracle.bwt(d), (name, len(d))
+
+
+def test_suffix_sorter_deep_path_for_big_groups(emu, oracle, monkeypatch):
+    """BZ3_BWT_BIG_ROUNDS=0 (tests only, read per call): groups too large for the resolve kernel go straight to rank doubling,
+    so the deep path also runs on inputs that normally finish on the big path; and a block through the whole encoder."""
+    g = bzip3_amd.StageApi(emu)
+    monkeypatch.setenv("BZ3_BWT_BIG_ROUNDS", "0")
+    for name in ("phrase1", "phrase3", "text300k"):
+        d = SORTER_CASES[name][:120000]
+        assert g.bwt(d) == oracle.bwt(d), name
+    monkeypatch.delenv("BZ3_BWT_BIG_ROUNDS")
     t = datagen.shakespeare()
-    cases = [t[777 : 777 + n] for n in (2, 3, 9, 2047, 2048, 2049, 4097, 6143, 20000)]
-    cases += [b"a" * n for n in (2, 2048, 2049, 5000)] + [(b"ab" * 2100)[:n] for n in (2049, 4096)]
-    cases += [t[5000:5600] * 30, datagen.repeats(30000), datagen.low_entropy(20000), datagen.random_bytes(9000), bytes(range(256)) * 20]
-    for d in cases:
-        assert g.bwt(d) == oracle.bwt(d), len(d)
     d = t[40000:70000] + t[40000:52000]
     assert bzip3_amd.encode_block(d, 65 * 1024, emu)[2] == oracle.encode_block(d, 65 * 1024)[2]
-
-
-@pytest.mark.parametrize("env", [{"BZ3_RS_STAGED": "1"}, {"BZ3_RS_STAGED": "1", "BZ3_RS_NO_XCD": "1"}, {"BZ3_RS_NO_XCD": "1"}], ids=["staged", "staged_noxcd", "noxcd"])
-def test_opt_in_radix_scatter_variants(oracle, env):
-    """The experiment switches of the radix sorter (sort.hip: BZ3_RS_STAGED = LDS-staged scatter, BZ3_RS_NO_XCD = tile = blockIdx)
-    are read once per process, so they get a process of their own: the three stages that sort (LZP links: u32 keys, BWT: u64 keys,
-    inverse BWT: u8 keys without key output, destinations shifted by one) give the oracle's bytes on whole tiles, ragged tails and
-    inputs smaller than a tile."""
-    import subprocess
-
-    code = r'''
-import sys, ctypes as C
-sys.path[:0] = [%r, %r, %r]
-import bzip3_amd, datagen
-from build_emu import build
-from oracle_lib import Oracle
-g = bzip3_amd.StageApi(bzip3_amd._declare(C.CDLL(build())))
-o = Oracle()
-t = datagen.shakespeare()
-cases = [t[1000:1000 + 4096 * 3], t[5000:5000 + 4096 * 2 + 17], t[:4095], t[:4097], t[:300], b"ab", datagen.random_bytes(9000),
-         datagen.low_entropy(12000), datagen.repeats(30000), bytes(8192), bytes(range(256)) * 40]
-for d in cases:
-    assert g.lzp_encode(d) == o.lzp_encode(d), len(d)
-    assert g.bwt(d) == o.bwt(d), len(d)
-    idx, u = o.bwt(d)
-    assert g.unbwt(u, idx) == (0, d), len(d)
-print("ok")
-''' % (os.path.dirname(HERE), HERE, os.path.join(HERE, "emu"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-300:], r.stderr[-1200:])
