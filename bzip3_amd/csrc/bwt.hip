@@ -237,7 +237,9 @@ constexpr int TR_WIN = TR_NT * TR_PER;  // 2048
 constexpr int TR_G = 512;
 constexpr int TR_S = TR_WIN - TR_G;     // 1536
 constexpr int TR_SMALL = 64;            // groups up to this size are ranked by counting, larger ones by the bitonic network
-constexpr int TR_CAP = 64;              // steps before a group is left to the deep path (>= 320 symbols, ~570 of text)
+constexpr int TR_STEPS = 3;             // workgroup-wide steps; what is still ambiguous then (a few %, in tiny groups) goes to the tail kernel
+constexpr int TL_MAX = 64;              // largest group the tail kernel takes (one wave sorts it)
+constexpr int TL_CAP = 160;             // tail steps before a group is left to the deep path (>= 800 symbols)
 constexpr u32 TR_FAR = 0xFFFFu;
 
 // V[p] = suffix | head flag, PB[p] = payload byte, tile_last[t] = 1 + slot of the last head in anchor tile t (0: none), pos0, and
@@ -372,8 +374,9 @@ __device__ __forceinline__ void tr_bitonic(u64 * __restrict__ buf, u32 mp) {
 
 __global__ void __launch_bounds__(TR_NT) k_bwt_resolve(const u8 * __restrict__ t, u32 n, u32 * __restrict__ v, u8 * __restrict__ pb,
                                                       const u32 * __restrict__ hbits, const u32 * __restrict__ carry, const u8 * __restrict__ dirty, const u32 * __restrict__ vlc,
-                                                      u32 * __restrict__ big_slot, u32 * __restrict__ big_hp, u32 big_cap, u32 * __restrict__ counters,
-                                                      u32 chain) {
+                                                      u32 * __restrict__ big_slot, u32 * __restrict__ big_hp, u32 big_cap, u32 * __restrict__ chunk_off,
+                                                      u32 * __restrict__ chunk_cnt, u32 * __restrict__ tail_v, u32 * __restrict__ tail_slot,
+                                                      u16 * __restrict__ tail_d, u8 * __restrict__ tail_pb, u32 tail_cap, u32 * __restrict__ counters, u32 chain) {
     __shared__ u64 word[TR_WIN];                      // sort words by active index; the window copy of V / PB lives here during the prologue
     __shared__ u64 sb[TR_WIN + TR_WIN / 8 + 8];       // bitonic buffer of the larger groups
     __shared__ u32 av[TR_WIN];                        // suffix of active element e
@@ -534,6 +537,54 @@ __global__ void __launch_bounds__(TR_NT) k_bwt_resolve(const u8 * __restrict__ t
                 if ((hf >> r) & 1u) gstart[++o] = (u16)(e0 + r);
         }
         if (tid == 0) gstart[groups + 1] = (u16)m;
+        if (iter == (u32)TR_STEPS) {
+            // ---- hand-over: what is still ambiguous sits in tiny groups scattered over all tiles and may need dozens of further
+            // windows; a workgroup-wide step for a handful of suffixes costs as much as one for 2048.  Groups of <= TL_MAX go to the
+            // tail kernel (one wave per tile's leftovers, no workgroup barriers, many waves per CU); larger ones are written back as
+            // they are and left to the deep path.
+            __syncthreads();
+            u32 tf = 0;
+            {
+                u32 o = obase;
+#pragma unroll
+                for (int r = 0; r < TR_PER; r++) {
+                    o += (hf >> r) & 1u;
+                    if (e0 + r < m && (u32)gstart[o + 1] - (u32)gstart[o] <= (u32)TL_MAX) tf |= 1u << r;
+                }
+            }
+            u32 nt;
+            u32 off = block_excl_add<TR_NT>((u32)__popc(tf), red, nt);
+            if (tid == 0) bcast[1] = nt ? atomicAdd(&counters[4], nt) : 0u;
+            __syncthreads();
+            const u32 tb = bcast[1];
+            const bool fits = tb + nt <= tail_cap;
+            if (tid == 0) {
+                if (!fits) counters[3] = 1u;
+                chunk_off[tile] = tb;
+                chunk_cnt[tile] = fits ? nt : 0u;
+                if (m - (fits ? nt : 0u)) atomicAdd(&counters[1], m - (fits ? nt : 0u));
+            }
+#pragma unroll
+            for (int r = 0; r < TR_PER; r++) {
+                const u32 e = e0 + r;
+                if (e < m) {
+                    const u32 sv_ = av[e] | ((u32)ahead[e] << 31);
+                    const u64 p = a + aslot[e];
+                    if (((tf >> r) & 1u) && fits) {
+                        tail_v[tb + off] = sv_;
+                        tail_slot[tb + off] = (u32)p;
+                        tail_d[tb + off] = ad[e];
+                        tail_pb[tb + off] = apb[e];
+                        off++;
+                    } else {
+                        v[p] = sv_;
+                        pb[p] = apb[e];
+                        if ((sv_ & V_MASK) == 0) counters[2] = (u32)p;
+                    }
+                }
+            }
+            break;
+        }
         // ---- next code bits of every active suffix
         u64 wd[TR_PER];
         {
@@ -695,7 +746,6 @@ __global__ void __launch_bounds__(TR_NT) k_bwt_resolve(const u8 * __restrict__ t
         if (tid == 0) ahead[m] = 1;
         __syncthreads();
         // ---- suffixes that are alone now are final: out they go; the others move up
-        const bool last_iter = iter + 1 == (u32)TR_CAP;
         u32 keepf = 0;
         u32 kv[TR_PER];
         u16 kd[TR_PER], ks[TR_PER];
@@ -711,23 +761,20 @@ __global__ void __launch_bounds__(TR_NT) k_bwt_resolve(const u8 * __restrict__ t
                 ks[r] = aslot[e];
                 kp[r] = apb[e];
                 kh[r] = (u8)h;
-                if (uniq || last_iter) {
+                if (uniq) {
                     const u64 p = a + ks[r];
-                    v[p] = kv[r] | (h ? V_HEAD : 0u);
+                    v[p] = kv[r] | V_HEAD;
                     pb[p] = kp[r];
                     if (kv[r] == 0) counters[2] = (u32)p;
+                } else {
+                    keepf |= 1u << r;
                 }
-                if (!uniq) keepf |= 1u << r;
             }
         }
         u32 mnext;
         {
             const u32 nk = (u32)__popc(keepf);
             u32 d = block_excl_add<TR_NT>(nk, red, mnext);  // ends with a barrier: every read above is done
-            if (last_iter) {
-                if (tid == 0 && mnext) atomicAdd(&counters[1], mnext);
-                break;
-            }
 #pragma unroll
             for (int r = 0; r < TR_PER; r++)
                 if ((keepf >> r) & 1u) {
@@ -741,6 +788,100 @@ __global__ void __launch_bounds__(TR_NT) k_bwt_resolve(const u8 * __restrict__ t
         }
         m = mnext;
         __syncthreads();
+    }
+}
+
+// ---- the tail: tiny groups that need many more windows ---------------------------------------------------------------------------
+// One wave per tile's leftovers (chunk_off / chunk_cnt), a lane per suffix, as many whole groups at a time as fit the 64 lanes.  A step
+// costs one gather from the text and a handful of cross-lane operations; nothing in it waits for another wave, and the kernel's small
+// footprint puts dozens of waves on a CU, so the gather latency of one is covered by the others.
+__global__ void __launch_bounds__(WAVE) k_bwt_tail(const u8 * __restrict__ t, u32 n, u32 * __restrict__ v, u8 * __restrict__ pb, const u32 * __restrict__ vlc,
+                                                  const u32 * __restrict__ chunk_off, const u32 * __restrict__ chunk_cnt, const u32 * __restrict__ tail_v,
+                                                  const u32 * __restrict__ tail_slot, const u16 * __restrict__ tail_d, const u8 * __restrict__ tail_pb,
+                                                  u32 * __restrict__ counters) {
+    __shared__ u32 tab[256];
+    __shared__ u64 s_word[WAVE];
+    __shared__ u32 s_v[WAVE];
+    __shared__ u16 s_d[WAVE];
+    __shared__ u8 s_pb[WAVE];
+    const u32 cnt = chunk_cnt[blockIdx.x];
+    if (cnt == 0) return;
+    const u32 off = chunk_off[blockIdx.x];
+    const u32 lane = (u32)lane_id();
+#pragma unroll
+    for (int k = 0; k < 4; k++) tab[lane + 64u * k] = vlc[lane + 64u * k];
+    __syncthreads();
+    u32 cursor = 0;
+    while (cursor < cnt) {
+        const u32 i = cursor + lane;
+        const bool have = i < cnt;
+        const u32 x = have ? tail_v[off + i] : V_HEAD;
+        // the batch: whole groups only.  If the entry behind the 64 loaded ones continues a group, that group waits for the next batch.
+        const u64 hm = __ballot((x >> 31) != 0u);
+        u32 e;
+        if (cursor + WAVE >= cnt) e = cnt - cursor;
+        else if (tail_v[off + cursor + WAVE] >> 31) e = WAVE;
+        else e = 63u - (u32)__clzll((unsigned long long)hm);  // >= 1: no group here is larger than 64
+        const bool act = lane < e;
+        u32 sv = x & V_MASK;
+        u32 sd = have ? (u32)tail_d[off + i] : 0u;
+        const u32 slot = have ? tail_slot[off + i] : 0u;
+        u32 sp = have ? (u32)tail_pb[off + i] : 0u;
+        bool headf = !act || (x >> 31);
+        bool resolved = false;
+        for (u32 step = 0; step < (u32)TL_CAP; step++) {
+            const u64 H = __ballot(headf);  // bit 0 is set: the batch starts with a head
+            const u32 gs = 63u - (u32)__clzll((unsigned long long)(H & ((2ull << lane) - 1ull)));
+            const u64 above = lane == 63u ? 0ull : (H >> (lane + 1u));
+            const u32 ge = above ? lane + (u32)__ffsll((unsigned long long)above) : (u32)WAVE;
+            const u32 sz = act ? (ge < e ? ge : e) - gs : 1u;
+            const u32 maxsz = wave_max(sz);
+            if (maxsz <= 1u) {
+                resolved = true;
+                break;
+            }
+            u64 wa, wb, key;
+            u32 avl, c;
+            load_window(t, (u64)sv + sd, n, wa, wb, avl);
+            vlc_pack<40>(tab, wa, wb, avl, key, c);
+            const bool live = (u64)sv + sd < n;
+            if (!live) {
+                key = (u64)(n - sv);
+                c = 0;
+            }
+            const u64 w = ((live ? 1ull : 0ull) << 40) | key;
+            u32 below = 0;
+            for (u32 k = 0; k < maxsz; k++) {
+                const u32 q = gs + k;
+                const u64 wq = __shfl(w, (int)(q & 63u));
+                if (k < sz) below += (wq < w || (wq == w && q < lane)) ? 1u : 0u;
+            }
+            const u32 np = act ? gs + below : lane;
+            s_word[np] = w;
+            s_v[np] = sv;
+            s_d[np] = (u16)(sd + c);
+            s_pb[np] = (u8)sp;
+            __syncthreads();
+            const u64 w2 = s_word[lane];
+            const u64 wl = s_word[lane ? lane - 1u : 0u];
+            sv = s_v[lane];
+            sd = s_d[lane];
+            sp = s_pb[lane];
+            __syncthreads();
+            headf = headf || w2 != wl;  // (a lane alone in its group only ever compares its own word: it stays a head)
+        }
+        if (act) {
+            v[slot] = sv | (headf ? V_HEAD : 0u);
+            pb[slot] = (u8)sp;
+            if (sv == 0) counters[2] = slot;
+        }
+        if (!resolved) {
+            const u64 H = __ballot(headf);
+            const u64 nxt = (H >> 1) | (1ull << 63);
+            const u64 amb = ~(H & nxt) & (e == 64u ? ~0ull : ((1ull << e) - 1ull));  // lanes not alone in their group
+            if (lane == 0 && amb) atomicAdd(&counters[1], (u32)__popcll((unsigned long long)amb));
+        }
+        cursor += e;
     }
 }
 
@@ -1126,7 +1267,9 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     u32 * carry = tmp.take<u32>(tiles + 1);
     u8 * dirty = tmp.take<u8>(tiles + 2);
     u32 * hbits = tmp.take<u32>(((size_t)n + 63) / 64 * 2 + (size_t)TR_S / 32 + 8);  // snapshot of the head flags, whole 64-slot words of every anchor tile
-    u32 * d_words = tmp.take<u32>(8);   // counters [0] big elements, [1] left ambiguous by the resolve kernel, [2] slot of suffix 0, [3] big list overflow; [4] scan total, [5] primary index
+    u32 * d_words = tmp.take<u32>(8);   // counters [0] big elements, [1] left ambiguous by the resolve / tail kernels, [2] slot of suffix 0, [3] a list overflowed, [4] tail elements; [6] scan total, [7] primary index
+    u32 * chunk_off = tmp.take<u32>(tiles + 1);
+    u32 * chunk_cnt = tmp.take<u32>(tiles + 1);
     u32 * d_vlc = tmp.take<u32>(256);
     u32 * d_hist = tmp.take<u32>(256);
     BwtStats st;
@@ -1166,23 +1309,32 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     u64 * bkey[2] = {bkey0 + big_cap, bkey0 + 2 * (size_t)big_cap};    // 4 n, 6 n
     u64 * gkey = bkey0 + 3 * (size_t)big_cap;                          // 8 n: end of key[1]
     u8 * gpb = reinterpret_cast<u8 *>(val[cur ^ 1]);                   // the other suffix buffer is free as well
+    // the tail kernel's input (written by the resolve kernel, dead before the big round of the same pass starts): key[1] again
+    const u32 tail_cap = n / 4;
+    u32 * tail_v = reinterpret_cast<u32 *>(key[1]);
+    u32 * tail_slot = tail_v + tail_cap;
+    u16 * tail_d = reinterpret_cast<u16 *>(tail_slot + tail_cap);
+    u8 * tail_pb = reinterpret_cast<u8 *>(tail_d + tail_cap);
 
     u32 g = 7;            // symbols every group is known to share at least (7 per 56-bit window)
     bool deep = false;    // fall back to rank doubling
     u32 h_words[8];
     for (int pass = 0;; pass++) {
+        HIP_CHECK(hipMemsetAsync(chunk_cnt, 0, ((size_t)tiles + 1) * sizeof(u32), s));
         launch(k_bwt_resolve, dim3(tiles), dim3(TR_NT), 0, s, d_in, n, V, pb, (const u32 *)hbits, (const u32 *)carry, (const u8 *)(pass ? dirty : nullptr),
-               (const u32 *)d_vlc, big_slot, big_hp, big_cap, d_words, (u32)pass + 1u);
+               (const u32 *)d_vlc, big_slot, big_hp, big_cap, chunk_off, chunk_cnt, tail_v, tail_slot, tail_d, tail_pb, tail_cap, d_words, (u32)pass + 1u);
+        launch(k_bwt_tail, dim3(tiles), dim3(WAVE), 0, s, d_in, n, V, pb, (const u32 *)d_vlc, (const u32 *)chunk_off, (const u32 *)chunk_cnt, (const u32 *)tail_v,
+               (const u32 *)tail_slot, (const u16 *)tail_d, (const u8 *)tail_pb, d_words);
         HIP_CHECK(hipMemcpyAsync(h_words, d_words, sizeof h_words, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         const u32 nb = h_words[0];
-        if (getenv("BZ3_BWT_TRACE")) fprintf(stderr, "[bwt] n %u pass %d depth %u: %u suffixes in groups > %d, %u given up by the resolve kernel, overflow %u\n", n, pass, g, nb, TR_G, h_words[1], h_words[3]);
+        if (getenv("BZ3_BWT_TRACE")) fprintf(stderr, "[bwt] n %u pass %d depth %u: %u suffixes in groups > %d, %u through the tail kernel, %u given up, overflow %u\n", n, pass, g, nb, TR_G, h_words[4], h_words[1], h_words[3]);
         if (nb == 0) {  // no group left that is too large: done, unless the resolve kernel gave some up (counted over all passes)
             deep = h_words[1] != 0;
             break;
         }
         const char * env_rounds = getenv("BZ3_BWT_BIG_ROUNDS");  // tests only: 0 = big groups go straight to the deep path
-        const int max_big = env_rounds ? atoi(env_rounds) : 3;
+        const int max_big = env_rounds ? atoi(env_rounds) : 8;
         if (h_words[3] || pass >= max_big || nb > n / 4) {  // groups too many / too deep for windows of code bits
             deep = true;
             break;
@@ -1218,14 +1370,15 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
                    dirty, d_words);
         }
         g += 7;
-        HIP_CHECK(hipMemsetAsync(d_words, 0, sizeof(u32), s));  // the big list is rebuilt by the next pass
+        HIP_CHECK(hipMemsetAsync(d_words, 0, sizeof(u32), s));      // the big list and the tail list are rebuilt by the next pass
+        HIP_CHECK(hipMemsetAsync(d_words + 4, 0, sizeof(u32), s));
         launch(k_bwt_reduce_heads, dim3(tiles), dim3(BW_BLOCK), 0, s, (const u32 *)V, n, tile_last, hbits);
         launch(k_bwt_spine_max, dim3(1), dim3(SP_BLOCK), 0, s, (const u32 *)tile_last, tiles, carry);
     }
 
     u32 idx = 0;
     if (!deep) {
-        launch(k_bwt_finish, grid(n), dim3(BW_BLOCK), 0, s, d_in, (const u8 *)pb, n, (const u32 *)d_words, d_out, d_words + 5);
+        launch(k_bwt_finish, grid(n), dim3(BW_BLOCK), 0, s, d_in, (const u8 *)pb, n, (const u32 *)d_words, d_out, d_words + 7);
     } else {
         // ---- deep path: ISA from the flags, then prefix doubling on (rank, rank of the suffix h further on)
         u32 * sa = V;  // in place: a slot holds its final suffix (without flag) once the suffix is alone in its group
@@ -1241,7 +1394,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
         {
             const u32 tl = (u32)(((u64)m + BG_TILE - 1) / BG_TILE);
             launch(k_bg_reduce<true>, dim3(tl), dim3(BW_BLOCK), 0, s, (const u64 *)nullptr, (const u32 *)V, m, tile_head, tile_keep);
-            launch(k_bg_spine, dim3(1), dim3(BG_SPINE), 0, s, tile_head, tile_keep, tl, d_words + 4);
+            launch(k_bg_spine, dim3(1), dim3(BG_SPINE), 0, s, tile_head, tile_keep, tl, d_words + 6);
             launch(k_bg_apply<true, false>, dim3(tl), dim3(BW_BLOCK), 0, s, (const u64 *)nullptr, (const u32 *)V, (const u32 *)nullptr, m, (const u32 *)tile_head,
                    (const u32 *)tile_keep, sa, isa, vv[0], slot[0], grp);
         }
@@ -1249,7 +1402,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
         u32 * vact = vv[0], * vfree = vv[1];
         for (;;) {
             u32 m_next = 0;
-            HIP_CHECK(hipMemcpyAsync(&m_next, d_words + 4, 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(&m_next, d_words + 6, 4, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
             if (m_next == 0) break;
             m = m_next;
@@ -1267,7 +1420,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
             st.sorted_elements += m;
             const u32 tl = (u32)(((u64)m + BG_TILE - 1) / BG_TILE);
             launch(k_bg_reduce<false>, dim3(tl), dim3(BW_BLOCK), 0, s, (const u64 *)key[c], (const u32 *)nullptr, m, tile_head, tile_keep);
-            launch(k_bg_spine, dim3(1), dim3(BG_SPINE), 0, s, tile_head, tile_keep, tl, d_words + 4);
+            launch(k_bg_spine, dim3(1), dim3(BG_SPINE), 0, s, tile_head, tile_keep, tl, d_words + 6);
             launch(k_bg_apply<false, true>, dim3(tl), dim3(BW_BLOCK), 0, s, (const u64 *)key[c], (const u32 *)vsorted, (const u32 *)slot[scur], m,
                    (const u32 *)tile_head, (const u32 *)tile_keep, sa, isa, vfree, slot[scur ^ 1], grp);
             scur ^= 1;
@@ -1276,9 +1429,9 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
             if (h >= 0x40000000u) throw HipError{hipErrorUnknown, "suffix sort did not converge", __FILE__, __LINE__};
             h *= 2;
         }
-        launch(k_bwt_emit, grid(n), dim3(BW_BLOCK), 0, s, d_in, (const u32 *)sa, (const u32 *)isa, n, d_out, d_words + 5);
+        launch(k_bwt_emit, grid(n), dim3(BW_BLOCK), 0, s, d_in, (const u32 *)sa, (const u32 *)isa, n, d_out, d_words + 7);
     }
-    HIP_CHECK(hipMemcpyAsync(&idx, d_words + 5, 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(&idx, d_words + 7, 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     tmp.release(mk);
     if (stats) *stats = st;
