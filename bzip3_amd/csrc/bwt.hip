@@ -645,9 +645,17 @@ __global__ void __launch_bounds__(TR_NT) k_bwt_resolve(const u8 * __restrict__ t
                 if (e0 + r < m) {
                     const u32 gs = gstart[o], ge = gstart[o + 1];
                     if (ge - gs <= (u32)TR_SMALL) {
+                        // rank by counting; eight words of the group in flight per round trip (one at a time, the loop is a chain
+                        // of LDS latencies: measured 3x the whole rest of the step)
                         u32 below = 0;
                         const u64 mineW = wd[r];
-                        for (u32 q = gs; q < ge; q++) below += word[q] < mineW ? 1u : 0u;
+                        for (u32 q = gs; q < ge; q += 8u) {
+                            u64 x[8];
+#pragma unroll
+                            for (u32 k = 0; k < 8u; k++) x[k] = word[q + k < ge ? q + k : ge - 1u];
+#pragma unroll
+                            for (u32 k = 0; k < 8u; k++) below += (q + k < ge && x[k] < mineW) ? 1u : 0u;
+                        }
                         newpos[r] = gs + below;
                     } else {
                         medf |= 1u << r;
@@ -1334,7 +1342,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
             break;
         }
         const char * env_rounds = getenv("BZ3_BWT_BIG_ROUNDS");  // tests only: 0 = big groups go straight to the deep path
-        const int max_big = env_rounds ? atoi(env_rounds) : 8;
+        const int max_big = env_rounds ? atoi(env_rounds) : 1;  // one more window takes text from ~12 % of its suffixes in big groups to ~1 %; what is left is deep and goes to rank doubling
         if (h_words[3] || pass >= max_big || nb > n / 4) {  // groups too many / too deep for windows of code bits
             deep = true;
             break;
@@ -1389,7 +1397,9 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
         const u32 max_tiles = (u32)(((u64)n + BG_TILE - 1) / BG_TILE);
         u32 * tile_head = tmp.take<u32>(2 * (size_t)max_tiles + 16);
         u32 * tile_keep = tile_head + max_tiles + 8;
-        u32 m = n, h = g;
+        // every group still ambiguous shares at least h symbols: 7 per window of the big rounds, but a group the resolve kernel
+        // handed back early (more than 64 members after its three steps) is only known to share the first window's 7 + 3 x 5.
+        u32 m = n, h = h_words[1] ? (g < 22u ? g : 22u) : g;
         if (getenv("BZ3_BWT_TRACE")) fprintf(stderr, "[bwt] n %u deep path from depth %u\n", n, h);
         {
             const u32 tl = (u32)(((u64)m + BG_TILE - 1) / BG_TILE);

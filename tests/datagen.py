@@ -206,6 +206,11 @@ def suffix_sorter_cases():
         # a 40-letter phrase: its first positions need several big rounds (11 letters per 56-bit window)
         "phrase3": b"".join(b"thequickbrownfoxjumpsoverthelazydogagain" + letters(400) for _ in range(700)),
     }
+    # groups of 100 that share up to 45 letters (the resolve kernel hands them back after its three steps: more than 64 members)
+    # beside groups of 700 that go through big rounds: the deep path must start from the SHALLOWER of the two depths
+    long_phrase = b"thequickbrownfoxjumpsoverthelazydogagainandagainuntilthecowscomehomeandthenoncemorewithfeelingforgoodmeasure"
+    c["mixdeep"] = (b"".join(long_phrase + letters(500) for _ in range(600)) +
+                    b"".join(b"3141592653589793238462643383279502884197169399375" + letters(300) for _ in range(100)))  # digits: these groups sort far from the big ones
     for n in (1535, 1536, 1537, 2047, 2048, 2049, 3071, 3072, 3073, 4097):
         c["text%d" % n] = t[777 : 777 + n]
         c["pair%d" % n] = (t[9000:9000 + n // 2] * 2)[:n]

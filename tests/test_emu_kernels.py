@@ -754,6 +754,9 @@ def test_suffix_sorter_deep_path_for_big_groups(emu, oracle, monkeypatch):
     for name in ("phrase1", "phrase3", "text300k"):
         d = SORTER_CASES[name][:120000]
         assert g.bwt(d) == oracle.bwt(d), name
+    monkeypatch.setenv("BZ3_BWT_BIG_ROUNDS", "8")  # several windows for the big groups, then the deep path for what the resolve kernel handed back
+    for name in ("mixdeep", "phrase3"):
+        assert g.bwt(SORTER_CASES[name]) == oracle.bwt(SORTER_CASES[name]), name
     monkeypatch.delenv("BZ3_BWT_BIG_ROUNDS")
     t = datagen.shakespeare()
     d = t[40000:70000] + t[40000:52000]
