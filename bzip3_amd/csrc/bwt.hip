@@ -140,13 +140,13 @@ static void vlc_build(const u32 * cnt, u32 * table) {
 
 // The first B code bits of the symbols in the window (wa, wb: 16 bytes, little endian; avail <= 16 of them exist), zero padded;
 // cnt = symbols that lie entirely inside those bits.
-template <int B>
+template <int B, int SYMS = VLC_WINDOW>
 __device__ __forceinline__ void vlc_pack(const u32 * __restrict__ tab, u64 wa, u64 wb, u32 avail, u64 & key, u32 & cnt) {
     u64 acc = 0;
     u32 bits = 0;
     cnt = 0;
 #pragma unroll
-    for (u32 k = 0; k < (u32)VLC_WINDOW; k++) {
+    for (u32 k = 0; k < (u32)SYMS; k++) {
         const u32 e = tab[(u8)(k < 8 ? wa >> (8 * k) : wb >> (8 * (k - 8)))];
         const u32 len = e & 15u;
         const bool take = k < avail && bits < (u32)B;
@@ -231,16 +231,14 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bwt_vlc_keys(const u8 * __restrict
 // ---- groups of the sorted list ----------------------------------------------------------------------------------------------
 // Resolve-kernel geometry: a workgroup owns the groups whose head lies in its RS_S anchor slots; such a group of <= TR_G suffixes
 // ends inside the TR_WIN-slot window.
-constexpr int TR_NT = 256;
-constexpr int TR_PER = 8;
-constexpr int TR_WIN = TR_NT * TR_PER;  // 2048
-constexpr int TR_G = 512;
-constexpr int TR_S = TR_WIN - TR_G;     // 1536
-constexpr int TR_SMALL = 64;            // groups up to this size are ranked by counting, larger ones by the bitonic network
-constexpr int TR_STEPS = 3;             // workgroup-wide steps; what is still ambiguous then (a few %, in tiny groups) goes to the tail kernel
-constexpr int TL_MAX = 64;              // largest group the tail kernel takes (one wave sorts it)
-constexpr int TL_CAP = 160;             // tail steps before a group is left to the deep path (>= 800 symbols)
-constexpr u32 TR_FAR = 0xFFFFu;
+constexpr int WR_A = 512;     // anchor slots per wave
+constexpr int WR_G = 512;     // largest group a wave resolves (8 suffixes per lane)
+constexpr int WR_WAVES = 4;   // waves per workgroup (independent of each other after the code table is loaded)
+constexpr int WR_CAP = 160;   // resolve steps before a group is left to the deep path
+constexpr int TL_CAP = 160;   // tail steps before a group is left to the deep path (>= 800 symbols)
+constexpr u32 WR_FAR = 0xFFFFu;
+constexpr int TR_S = WR_A;    // granularity of tile_last / carry / dirty
+constexpr int TR_G = WR_G;
 
 // V[p] = suffix | head flag, PB[p] = payload byte, tile_last[t] = 1 + slot of the last head in anchor tile t (0: none), pos0, and
 // the SNAPSHOT of the head flags as a bitmap: the resolve kernel takes the group boundaries from the snapshot, because the flags in V
@@ -298,12 +296,18 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bwt_reduce_heads(const u32 * __res
 constexpr int SP_BLOCK = 1024;
 __global__ void __launch_bounds__(SP_BLOCK) k_bwt_spine_max(const u32 * __restrict__ tile_last, u32 tiles, u32 * __restrict__ carry) {
     __shared__ u32 lds[SP_BLOCK / WAVE + 1];
-    const u32 per = (tiles + SP_BLOCK - 1) / SP_BLOCK;
+    // a thread owns `per` consecutive tiles and walks them eight at a time, the loads of a batch in flight together (500 tiles per
+    // thread at 256 MiB: one exposed round trip per tile made this kernel as slow as a radix pass)
+    const u32 per = (((tiles + SP_BLOCK - 1) / SP_BLOCK) + 7u) & ~7u;
     const u32 t0 = threadIdx.x * per, t1 = t0 + per < tiles ? t0 + per : tiles;
     u32 hp = 0;
-    for (u32 t = t0; t < t1; t++) {
-        const u32 h = tile_last[t];
-        hp = h > hp ? h : hp;
+    for (u32 t = t0; t < t1; t += 8) {
+        u32 h[8];
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) h[k] = tile_last[t + k < t1 ? t + k : t1 - 1u];
+#pragma unroll
+        for (u32 k = 0; k < 8; k++)
+            if (t + k < t1) hp = h[k] > hp ? h[k] : hp;
     }
     // exclusive running maximum over the threads
     const u32 incl = wave_incl_max(hp);
@@ -314,512 +318,486 @@ __global__ void __launch_bounds__(SP_BLOCK) k_bwt_spine_max(const u32 * __restri
     u32 run = 0;
     for (int w = 0; w < wave_id(); w++) run = lds[w] > run ? lds[w] : run;
     run = up > run ? up : run;
-    for (u32 t = t0; t < t1; t++) {
-        carry[t] = run ? run - 1u : 0u;
-        const u32 h = tile_last[t];
-        run = h > run ? h : run;
+    for (u32 t = t0; t < t1; t += 8) {
+        u32 h[8];
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) h[k] = tile_last[t + k < t1 ? t + k : t1 - 1u];
+#pragma unroll
+        for (u32 k = 0; k < 8; k++)
+            if (t + k < t1) {
+                carry[t + k] = run ? run - 1u : 0u;
+                run = h[k] > run ? h[k] : run;
+            }
     }
 }
 
 // ---- the resolve kernel ------------------------------------------------------------------------------------------------------
-// Sort word of an ambiguous suffix: [group start : 11][live : 1][next 40 code bits, or the suffix length when it has ended][index : 12].
-__device__ __forceinline__ u32 tr_pad(u32 i) { return i + (i >> 3); }  // LDS index of element i of the bitonic buffer (bank spread)
+// One WAVE per 512 anchor slots, no workgroup barriers.  The wave owns the groups whose head lies in its anchor slots; it takes them
+// in batches of whole groups that are neighbours in the slot order, at most 512 slots per batch (8 per lane, blocked: position
+// j = lane * E + r), and resolves a batch completely before it goes on:
+//   step  : every suffix that still shares its group fetches the next 40 code bits at its depth straight from the text (16 bytes, all
+//           loads of a lane in flight together) -- no inverse suffix array, no rank table: groups are independent of each other;
+//           sort word = [group start : 9][live : 1][40 code bits, or the length of a suffix that has ended][position : 9];
+//           a bitonic network over the wave's registers (strides below E inside a lane, the others by cross-lane exchange) sorts all
+//           groups of the batch at once; the payloads (suffix, depth, BWT symbol) follow through a per-wave LDS buffer; positions
+//           whose word differs from their left neighbour's become group heads.
+//   shrink: once the suffixes still ambiguous fit half the lanes' capacity, the final ones are written out and the rest move up
+//           (E halves: a 64-element network costs a tenth of a 512-element one), so long tails of tiny deep groups stay cheap.
+// Round 3 measured the first, workgroup-wide version of this kernel (2048-slot windows, block scans and barriers between the phases
+// of a step) at 40 ms per 256 MiB block, nearly all of it waiting at barriers with 16 waves per CU; a wave-level step is the same
+// work without a single barrier, and the small footprint (~5 KB of LDS per wave) lets many waves cover each other's gathers.
+__device__ __forceinline__ u32 bw_readlane(u32 v, int lane) {
+#ifdef BZ3_EMU
+    return __shfl(v, lane);
+#else
+    return (u32)__builtin_amdgcn_readlane((int)v, lane);
+#endif
+}
+// Sort word layout
+constexpr int WW_IDX = 9, WW_KEY = 40;
+__device__ __forceinline__ u64 ww_make(u32 gs, bool live, u64 key, u32 idx) {
+    return ((u64)gs << (WW_IDX + WW_KEY + 1)) | ((live ? 1ull : 0ull) << (WW_IDX + WW_KEY)) | (key << WW_IDX) | (u64)idx;
+}
+// payload: [suffix : 30][depth : 16][BWT symbol : 8]
+__device__ __forceinline__ u64 pl_make(u32 v, u32 d, u32 p) { return ((u64)v << 24) | ((u64)(d & 0xFFFFu) << 8) | (u64)(p & 0xFFu); }
+__device__ __forceinline__ u32 pl_v(u64 x) { return (u32)(x >> 24); }
+__device__ __forceinline__ u32 pl_d(u64 x) { return (u32)(x >> 8) & 0xFFFFu; }
+__device__ __forceinline__ u32 pl_p(u64 x) { return (u32)x & 0xFFu; }
 
-// Bitonic sort of buf[0 .. mp) (mp a power of two <= TR_WIN, padded indices), ascending; every thread of the workgroup calls it.
-// Strides are taken three at a time: a thread loads the 8 elements whose indices differ in those three bits, runs the three
-// compare-exchange stages in registers and stores them back -- one LDS round trip per three stages.
-__device__ __forceinline__ void tr_bitonic(u64 * __restrict__ buf, u32 mp) {
-    for (u32 k = 2; k <= mp; k <<= 1) {
-        u32 j = k >> 1;  // largest stride of this merge
-        while (j >= 1) {
-            // strides j, j/2, .. down to jl: as many as three, and so that what remains below is a multiple of three stages
-            u32 lj = 0;
-            while ((1u << lj) < j) lj++;  // log2(j)
-            const u32 take = (lj % 3u) + 1u;  // lj+1 stages remain: take ((lj+1) mod 3, or 3) first
-            const u32 c = take > lj + 1u ? lj + 1u : take;
-            const u32 lq = lj + 1u - c;  // lowest owned bit
-            const u32 sets = mp >> c;
-            for (u32 sidx = threadIdx.x; sidx < sets; sidx += TR_NT) {
-                const u32 base = ((sidx >> lq) << (lq + c)) | (sidx & ((1u << lq) - 1u));
-                const bool asc = (base & k) == 0u;
-                u64 x[8];
+// Bitonic sort of the 64 * E words held by the wave (position j = lane * E + r), ascending.
+template <int E>
+__device__ __forceinline__ void wave_bitonic(u64 (&w)[E]) {
+    const u32 lane = (u32)lane_id();
 #pragma unroll
-                for (u32 r = 0; r < 8; r++)
-                    if (r < (1u << c)) x[r] = buf[tr_pad(base + (r << lq))];
+    for (u32 k = 2; k <= 64u * E; k <<= 1) {
 #pragma unroll
-                for (u32 b = 3; b-- > 0;) {
-                    if (b < c) {
+        for (u32 j = k >> 1; j >= 1; j >>= 1) {
+            if (j >= (u32)E) {  // partner in another lane
+                const u32 lj = j / E;
+                const bool upper = (lane & lj) != 0u;
+                const bool asc = ((lane * E) & k) == 0u;  // k >= 2 E here: the bit lies in the lane number
 #pragma unroll
-                        for (u32 r = 0; r < 8; r++) {
-                            if (r < (1u << c) && !(r & (1u << b))) {
-                                const u32 r2 = r | (1u << b);
-                                const u64 lo = x[r] < x[r2] ? x[r] : x[r2];
-                                const u64 hi = x[r] < x[r2] ? x[r2] : x[r];
-                                x[r] = asc ? lo : hi;
-                                x[r2] = asc ? hi : lo;
-                            }
-                        }
+                for (int r = 0; r < E; r++) {
+                    const u64 y = __shfl_xor(w[r], (int)lj);
+                    const u64 lo = w[r] < y ? w[r] : y, hi = w[r] < y ? y : w[r];
+                    w[r] = (upper == asc) ? hi : lo;
+                }
+            } else {  // partner in the same lane
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    if (!(r & j)) {
+                        const bool asc = ((lane * E + r) & k) == 0u;
+                        const u64 x = w[r], y = w[r | j];
+                        const u64 lo = x < y ? x : y, hi = x < y ? y : x;
+                        w[r] = asc ? lo : hi;
+                        w[r | j] = asc ? hi : lo;
                     }
                 }
-#pragma unroll
-                for (u32 r = 0; r < 8; r++)
-                    if (r < (1u << c)) buf[tr_pad(base + (r << lq))] = x[r];
             }
-            __syncthreads();
-            j = lq ? (1u << (lq - 1u)) : 0u;
-            if (lq == 0) break;
         }
     }
 }
 
-__global__ void __launch_bounds__(TR_NT) k_bwt_resolve(const u8 * __restrict__ t, u32 n, u32 * __restrict__ v, u8 * __restrict__ pb,
-                                                      const u32 * __restrict__ hbits, const u32 * __restrict__ carry, const u8 * __restrict__ dirty, const u32 * __restrict__ vlc,
-                                                      u32 * __restrict__ big_slot, u32 * __restrict__ big_hp, u32 big_cap, u32 * __restrict__ chunk_off,
-                                                      u32 * __restrict__ chunk_cnt, u32 * __restrict__ tail_v, u32 * __restrict__ tail_slot,
-                                                      u16 * __restrict__ tail_d, u8 * __restrict__ tail_pb, u32 tail_cap, u32 * __restrict__ counters, u32 chain) {
-    __shared__ u64 word[TR_WIN];                      // sort words by active index; the window copy of V / PB lives here during the prologue
-    __shared__ u64 sb[TR_WIN + TR_WIN / 8 + 8];       // bitonic buffer of the larger groups
-    __shared__ u32 av[TR_WIN];                        // suffix of active element e
-    __shared__ u16 ad[TR_WIN + 8];                    // its depth (symbols known equal inside its group); head positions during the prologue
-    __shared__ u16 aslot[TR_WIN];                     // its slot inside the window (slots never move, suffixes do)
-    __shared__ u16 gstart[TR_WIN / 2 + 8];            // first active index of group number o (1-based), [groups + 1] = m
-    __shared__ u16 mact[TR_WIN];                      // active index of compact "larger group" element q
-    __shared__ u8 apb[TR_WIN];                        // payload byte
-    __shared__ u8 ahead[TR_WIN + 8];                  // 1: active element e starts a group
-    __shared__ u32 tab[256];
-    __shared__ u32 red[TR_NT / WAVE + 1];
-    __shared__ u32 bcast[4];
+// per-wave LDS
+struct WrLds {
+    u64 pl[WR_G];       // payloads by position (permutation / compaction buffer)
+    u16 aux[WR_G];      // slot of a position (offset from the window start)
+    u8 hd[WR_G];        // compaction: head flags of the positions
+    u32 hb[36];         // head bits of the window [a, a + 1024]
+};
 
-    const u32 tile = blockIdx.x;
-    const u64 a = (u64)tile * TR_S;
-    if (a >= n) return;
-    if (dirty && !(dirty[tile] | dirty[tile + 1])) return;
-    const u32 tid = threadIdx.x;
-    u32 * vw = reinterpret_cast<u32 *>(word);                 // TR_WIN + 1 words
-    u8 * pbw = reinterpret_cast<u8 *>(vw + TR_WIN + 8);       // TR_WIN bytes (16 KB region: 8 KB + 32 + 2 KB)
-    u16 * hpos = ad;                                          // head positions by ordinal (prologue only)
-    tab[tid] = vlc[tid];
-    {
-        u32 x[TR_PER], hb[TR_PER];
-        u8 y[TR_PER];
-#pragma unroll
-        for (int r = 0; r < TR_PER; r++) {  // coalesced: consecutive threads, consecutive slots
-            const u32 w = (u32)r * TR_NT + tid;
-            const u64 p = a + w;
-            const u64 pc = p < n ? p : (u64)n - 1;
-            x[r] = v[pc];
-            y[r] = pb[pc];
-            hb[r] = hbits[pc >> 5];
-        }
-#pragma unroll
-        for (int r = 0; r < TR_PER; r++) {
-            const u32 w = (u32)r * TR_NT + tid;
-            const u64 p = a + w;
-            // group boundaries from the snapshot; past the end: a head, so that the last group ends there
-            vw[w] = p < n ? ((x[r] & V_MASK) | (((hb[r] >> (p & 31u)) & 1u) << 31)) : V_HEAD;
-            pbw[w] = y[r];
-        }
-        if (tid == 0) {
-            const u64 p = a + TR_WIN;
-            vw[TR_WIN] = p < n ? (((hbits[p >> 5] >> (p & 31u)) & 1u) << 31) : V_HEAD;
-        }
-    }
-    __syncthreads();
-    // head ordinals: thread owns window positions tid*8 .. tid*8+7
-    const u32 w0 = tid * TR_PER;
-    u32 hflag = 0;  // bit r: position w0 + r is a head
-    u32 nheads = 0;
-#pragma unroll
-    for (int r = 0; r < TR_PER; r++) {
-        const u32 h = vw[w0 + r] >> 31;
-        hflag |= h << r;
-        nheads += h;
-    }
-    u32 total_heads;
-    u32 ord = block_excl_add<TR_NT>(nheads, red, total_heads);  // heads before w0
-    {
-        u32 o = ord;
-#pragma unroll
-        for (int r = 0; r < TR_PER; r++)
-            if ((hflag >> r) & 1u) hpos[++o] = (u16)(w0 + r);
-    }
-    if (tid == 0) hpos[total_heads + 1] = (vw[TR_WIN] >> 31) ? (u16)TR_WIN : (u16)TR_FAR;
-    __syncthreads();
-    // classification
-    u32 mine = 0, bigf = 0;  // bit r
-    u32 bighp[TR_PER];
-    const u32 carry_hp = carry[tile];
-    {
-        u32 o = ord;
-#pragma unroll
-        for (int r = 0; r < TR_PER; r++) {
-            const u32 w = w0 + r;
-            o += (hflag >> r) & 1u;
-            const u32 hl = o ? hpos[o] : 0u;
-            const u32 nh = hpos[o + 1];  // o + 1 <= total_heads + 1
-            const bool known = nh != TR_FAR;
-            bighp[r] = 0;
-            if (o && hl < (u32)TR_S && known && nh - hl >= 2u && nh - hl <= (u32)TR_G) mine |= 1u << r;
-            if (w < (u32)TR_S && a + w < n) {
-                const u32 hg = o ? (u32)a + hl : carry_hp;
-                const bool big = !known || ((u32)a + nh - hg) > (u32)TR_G;
-                if (big) {
-                    bigf |= 1u << r;
-                    bighp[r] = hg;
-                }
-            }
-        }
-    }
-    // the groups too large for this kernel: (slot, head slot) to the global list
-    {
-        u32 tot;
-        const u32 nb = (u32)__popc(bigf);
-        u32 off = block_excl_add<TR_NT>(nb, red, tot);
-        if (tot) {
-            if (tid == 0) bcast[0] = atomicAdd(&counters[0], tot);
-            __syncthreads();
-            const u32 gb = bcast[0];
-            if (gb + tot > big_cap) {
-                if (tid == 0) counters[3] = 1u;
-            } else {
-#pragma unroll
-                for (int r = 0; r < TR_PER; r++)
-                    if ((bigf >> r) & 1u) {
-                        big_slot[gb + off] = (u32)a + w0 + r;
-                        big_hp[gb + off] = bighp[r];
-                        off++;
-                    }
-            }
-        }
-    }
-    // the active list
-    u32 m;
-    {
-        const u32 nm = (u32)__popc(mine);
-        u32 e = block_excl_add<TR_NT>(nm, red, m);
-        u32 sv[TR_PER];
-        u8 sp[TR_PER];
-#pragma unroll
-        for (int r = 0; r < TR_PER; r++) {
-            sv[r] = vw[w0 + r];
-            sp[r] = pbw[w0 + r];
-        }
-        __syncthreads();  // the window copy (inside `word`) and hpos (inside `ad`) are dead from here on
-#pragma unroll
-        for (int r = 0; r < TR_PER; r++)
-            if ((mine >> r) & 1u) {
-                av[e] = sv[r] & V_MASK;
-                apb[e] = sp[r];
-                aslot[e] = (u16)(w0 + r);
-                ahead[e] = (u8)(sv[r] >> 31);
-                ad[e] = 0;
-                e++;
-            }
-    }
-    __syncthreads();
+// smallest set bit position >= p in the wave's window bitmap (33 words), WR_FAR if none
+__device__ __forceinline__ u32 wr_next_head(const u32 * hb, u32 p) {
+    const u32 lane = (u32)lane_id();
+    u32 word = lane < 33u ? hb[lane] : 0u;
+    const u32 wp = p >> 5;
+    if (lane < wp) word = 0;
+    else if (lane == wp) word &= 0xFFFFFFFFu << (p & 31u);
+    const u64 any = __ballot(word != 0u);
+    if (!any) return WR_FAR;
+    const int l = __ffsll((unsigned long long)any) - 1;
+    const u32 wv = bw_readlane(word, l);
+    return (u32)l * 32u + (u32)(__ffs(wv) - 1);
+}
+// largest set bit position <= t
+__device__ __forceinline__ u32 wr_prev_head(const u32 * hb, u32 t) {
+    const u32 lane = (u32)lane_id();
+    u32 word = lane < 33u ? hb[lane] : 0u;
+    const u32 wp = t >> 5;
+    if (lane > wp) word = 0;
+    else if (lane == wp) word &= 0xFFFFFFFFu >> (31u - (t & 31u));
+    const u64 any = __ballot(word != 0u);
+    if (!any) return WR_FAR;
+    const int l = 63 - __clzll((unsigned long long)any);
+    const u32 wv = bw_readlane(word, l);
+    return (u32)l * 32u + (31u - (u32)__clz(wv));
+}
 
-    for (u32 iter = 0; m > 0; iter++) {
-        const u32 e0 = tid * TR_PER;  // this thread owns active indices e0 .. e0+7
-        // ---- group structure of the active list
-        u32 hf = 0, nh_ = 0;
+struct WrCtx {
+    const u8 * t;
+    u32 n;
+    u32 * v;
+    u8 * pb;
+    const u32 * tab;
+    u32 * counters;
+    u32 chain;
+    u64 slot0;  // global slot of window position 0
+    u32 * tail_v;
+    u32 * tail_slot;
+    u16 * tail_d;
+    u8 * tail_pb;
+    u32 tail_cap;
+};
+
+// One batch: window positions [c, c + L) (whole groups, L <= 512), E = suffixes per lane.  Returns when every group is resolved (or the
+// step cap is reached: the groups are written back as they are and counted as given up).
+template <int E>
+__device__ __forceinline__ void wr_run(const WrCtx & cx, WrLds & lds, u64 (&pl)[E], u32 hm, u32 L, u32 step);
+
+// the `total` ambiguous suffixes a shrink left in the wave's LDS buffer, E2 per lane
+template <int E2>
+__device__ __forceinline__ void wr_reload(const WrCtx & cx, WrLds & lds, u32 total, u32 step) {
+    const u32 lane = (u32)lane_id();
+    u64 q[E2];
+    u32 h2 = 0;
 #pragma unroll
-        for (int r = 0; r < TR_PER; r++) {
-            const u32 h = e0 + r < m ? (u32)ahead[e0 + r] : 0u;
-            hf |= h << r;
-            nh_ += h;
-        }
-        u32 groups;
-        const u32 obase = block_excl_add<TR_NT>(nh_, red, groups);
-        {
-            u32 o = obase;
+    for (int r = 0; r < E2; r++) {
+        const u32 j = lane * E2 + r;
+        const bool in = j < total;
+        q[r] = in ? lds.pl[j] : 0ull;
+        h2 |= (in ? (u32)lds.hd[j] : 1u) << r;
+    }
+    wave_sync();
+    wr_run<E2>(cx, lds, q, h2, total, step);
+}
+
+template <int E>
+__device__ __forceinline__ void wr_run(const WrCtx & cx, WrLds & lds, u64 (&pl)[E], u32 hm, u32 L, u32 step) {
+    // pl[r] / bit r of hm: payload and head flag of position j = lane * E + r; lds.aux[j] = the position's slot (offset from cx.slot0);
+    // positions >= L are heads without content
+    const u32 lane = (u32)lane_id();
+    for (;; step++) {
+        // ---- which positions still share a group: not (head and followed by a head)
+        const u32 nxt0 = __shfl_down(hm & 1u, 1u);
+        const u32 hnext = (hm >> 1) | ((lane == 63u ? 1u : nxt0) << (E - 1));
+        u32 amb = ~(hm & hnext) & ((1u << E) - 1u);
 #pragma unroll
-            for (int r = 0; r < TR_PER; r++)
-                if ((hf >> r) & 1u) gstart[++o] = (u16)(e0 + r);
-        }
-        if (tid == 0) gstart[groups + 1] = (u16)m;
-        if (iter == (u32)TR_STEPS) {
-            // ---- hand-over: what is still ambiguous sits in tiny groups scattered over all tiles and may need dozens of further
-            // windows; a workgroup-wide step for a handful of suffixes costs as much as one for 2048.  Groups of <= TL_MAX go to the
-            // tail kernel (one wave per tile's leftovers, no workgroup barriers, many waves per CU); larger ones are written back as
-            // they are and left to the deep path.
-            __syncthreads();
-            u32 tf = 0;
-            {
-                u32 o = obase;
+        for (int r = 0; r < E; r++)
+            if (lane * E + r >= L) amb &= ~(1u << r);
+        const u32 ambs = (u32)__popc(amb);
+        const u32 total = wave_sum(ambs);
+        if (total == 0u || step >= (u32)WR_CAP) {
+            // ---- out: every position of the batch (a suffix alone in its group is final)
 #pragma unroll
-                for (int r = 0; r < TR_PER; r++) {
-                    o += (hf >> r) & 1u;
-                    if (e0 + r < m && (u32)gstart[o + 1] - (u32)gstart[o] <= (u32)TL_MAX) tf |= 1u << r;
+            for (int r = 0; r < E; r++)
+                if (lane * E + r < L) {
+                    const u64 p = cx.slot0 + lds.aux[lane * E + r];
+                    const u32 sv = pl_v(pl[r]);
+                    cx.v[p] = sv | (((hm >> r) & 1u) ? V_HEAD : 0u);
+                    cx.pb[p] = (u8)pl_p(pl[r]);
+                    if (sv == 0u) cx.counters[2] = (u32)p;
                 }
-            }
-            u32 nt;
-            u32 off = block_excl_add<TR_NT>((u32)__popc(tf), red, nt);
-            if (tid == 0) bcast[1] = nt ? atomicAdd(&counters[4], nt) : 0u;
-            __syncthreads();
-            const u32 tb = bcast[1];
-            const bool fits = tb + nt <= tail_cap;
-            if (tid == 0) {
-                if (!fits) counters[3] = 1u;
-                chunk_off[tile] = tb;
-                chunk_cnt[tile] = fits ? nt : 0u;
-                if (m - (fits ? nt : 0u)) atomicAdd(&counters[1], m - (fits ? nt : 0u));
-            }
+            if (total && lane == 0) atomicAdd(&cx.counters[1], total);
+            return;
+        }
+        if (total <= 32u * E) {
+            // ---- shrink: the final ones out, the others move up into half (or less) of the lanes' capacity
+            const u32 before = wave_incl_add(ambs) - ambs;
+            u32 so[E];
 #pragma unroll
-            for (int r = 0; r < TR_PER; r++) {
-                const u32 e = e0 + r;
-                if (e < m) {
-                    const u32 sv_ = av[e] | ((u32)ahead[e] << 31);
-                    const u64 p = a + aslot[e];
-                    if (((tf >> r) & 1u) && fits) {
-                        tail_v[tb + off] = sv_;
-                        tail_slot[tb + off] = (u32)p;
-                        tail_d[tb + off] = ad[e];
-                        tail_pb[tb + off] = apb[e];
-                        off++;
+            for (int r = 0; r < E; r++) so[r] = lane * E + r < L ? (u32)lds.aux[lane * E + r] : 0u;
+            wave_sync();  // every lane has read the slots of its positions before any is overwritten
+            u32 d = before;
+#pragma unroll
+            for (int r = 0; r < E; r++) {
+                if (lane * E + r < L) {
+                    if ((amb >> r) & 1u) {
+                        lds.pl[d] = pl[r];
+                        lds.aux[d] = (u16)so[r];
+                        lds.hd[d] = (u8)((hm >> r) & 1u);
+                        d++;
                     } else {
-                        v[p] = sv_;
-                        pb[p] = apb[e];
-                        if ((sv_ & V_MASK) == 0) counters[2] = (u32)p;
+                        const u64 p = cx.slot0 + so[r];
+                        const u32 sv = pl_v(pl[r]);
+                        cx.v[p] = sv | V_HEAD;
+                        cx.pb[p] = (u8)pl_p(pl[r]);
+                        if (sv == 0u) cx.counters[2] = (u32)p;
                     }
                 }
             }
-            break;
-        }
-        // ---- next code bits of every active suffix
-        u64 wd[TR_PER];
-        {
-            u32 sv[TR_PER], sd[TR_PER];
-#pragma unroll
-            for (int r = 0; r < TR_PER; r++) {
-                const u32 e = e0 + r < m ? e0 + r : (m - 1);
-                sv[r] = av[e];
-                sd[r] = ad[e];
+            wave_sync();
+            // continue with the smallest capacity that holds them
+            if (total <= 64u) {  // the rest is the tail kernel's (one suffix per lane, many waves per CU)
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(&cx.counters[4], total);
+                base = __shfl(base, 0);
+                if (base + total > cx.tail_cap) {
+                    if (lane == 0) {
+                        cx.counters[3] = 1u;
+                        atomicMin(&cx.counters[5], base);  // the list is valid up to the first append that did not fit
+                        atomicAdd(&cx.counters[1], total);
+                    }
+                    if (lane < total) {  // back where they are
+                        const u64 p = cx.slot0 + lds.aux[lane];
+                        cx.v[p] = pl_v(lds.pl[lane]) | (lds.hd[lane] ? V_HEAD : 0u);
+                        cx.pb[p] = (u8)pl_p(lds.pl[lane]);
+                    }
+                } else if (lane < total) {
+                    const u64 x = lds.pl[lane];
+                    cx.tail_v[base + lane] = pl_v(x) | (lds.hd[lane] ? V_HEAD : 0u);
+                    cx.tail_slot[base + lane] = (u32)(cx.slot0 + lds.aux[lane]);
+                    cx.tail_d[base + lane] = (u16)pl_d(x);
+                    cx.tail_pb[base + lane] = (u8)pl_p(x);
+                }
+                wave_sync();
+                return;
             }
-            u64 wa[TR_PER], wb[TR_PER];
-            u32 avl[TR_PER];
-            if (iter == 0) {
-                // depth = the symbols inside the 56-bit windows the group was formed on: one from the sort of all suffixes, one more
-                // per big round its members went through.  Every member walks the same symbols, so all arrive at the same depth
-                // (a member whose text ends on the way arrives at the end and sorts first).
-                for (u32 hop = 0; hop < chain; hop++) {
+            if constexpr (E == 8) {
+                if (total > 128u) return wr_reload<4>(cx, lds, total, step);
+                return wr_reload<2>(cx, lds, total, step);
+            }
+            if constexpr (E == 4) return wr_reload<2>(cx, lds, total, step);
+        }
+        // ---- group starts (running maximum of the head positions)
+        u32 lasth = 0;  // 1 + position of this lane's last head
 #pragma unroll
-                    for (int r = 0; r < TR_PER; r++) load_window(t, (u64)sv[r] + sd[r], n, wa[r], wb[r], avl[r]);
+        for (int r = 0; r < E; r++)
+            if ((hm >> r) & 1u) lasth = lane * E + r + 1u;
+        u32 run = wave_incl_max(lasth);
+        run = __shfl_up(run, 1u);
+        if (lane == 0) run = 0;  // (position 0 is a head)
+        // ---- next code bits of the ambiguous suffixes, four suffixes of a lane at a time (their windows in flight together: with all eight
+        // the kernel needs every register a wave can have, and one wave per SIMD hides no latency at all)
+        constexpr int CH = E < 4 ? E : 4;
+        u64 w[E];
 #pragma unroll
-                    for (int r = 0; r < TR_PER; r++) {
+        for (int r0 = 0; r0 < E; r0 += CH) {
+            u64 wa[CH], wb[CH];
+            u32 avl[CH], dep[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++) dep[k] = pl_d(pl[r0 + k]);
+            if (step == 0) {
+                // depth = the symbols inside the 56-bit windows the group was formed on: one from the sort of all suffixes, one more per
+                // big round its members went through.  Every member walks the same symbols, so all arrive at the same depth (a member
+                // whose text ends on the way arrives at the end and sorts first).
+                for (u32 hop = 0; hop < cx.chain; hop++) {
+#pragma unroll
+                    for (int k = 0; k < CH; k++) load_window(cx.t, (u64)pl_v(pl[r0 + k]) + dep[k], cx.n, wa[k], wb[k], avl[k]);
+#pragma unroll
+                    for (int k = 0; k < CH; k++) {
                         u64 k56;
                         u32 cnt;
-                        vlc_pack<56>(tab, wa[r], wb[r], avl[r], k56, cnt);
-                        sd[r] += cnt;
+                        vlc_pack<56>(cx.tab, wa[k], wb[k], avl[k], k56, cnt);
+                        dep[k] += ((amb >> (r0 + k)) & 1u) ? cnt : 0u;
                     }
                 }
             }
 #pragma unroll
-            for (int r = 0; r < TR_PER; r++) load_window(t, (u64)sv[r] + sd[r], n, wa[r], wb[r], avl[r]);
+            for (int k = 0; k < CH; k++) load_window(cx.t, (u64)pl_v(pl[r0 + k]) + dep[k], cx.n, wa[k], wb[k], avl[k]);
 #pragma unroll
-            for (int r = 0; r < TR_PER; r++) {
+            for (int k = 0; k < CH; k++) {
+                const int r = r0 + k;
+                const u32 j = lane * E + r;
+                if ((hm >> r) & 1u) run = j + 1u;
+                const u32 gs = run - 1u;
                 u64 key;
                 u32 cnt;
-                vlc_pack<40>(tab, wa[r], wb[r], avl[r], key, cnt);
-                const bool live = (u64)sv[r] + sd[r] < n;
+                vlc_pack<WW_KEY, 12>(cx.tab, wa[k], wb[k], avl[k], key, cnt);
+                const u32 sv = pl_v(pl[r]);
+                const bool live = (u64)sv + dep[k] < cx.n;
                 if (!live) {
-                    key = (u64)(n - sv[r]);  // ended: shorter first
+                    key = (u64)(cx.n - sv);  // ended: shorter first
                     cnt = 0;
                 }
-                wd[r] = ((live ? 1ull : 0ull) << 52) | (key << 12) | (u64)(e0 + r);
-                if (e0 + r < m) {
-                    word[e0 + r] = wd[r];
-                    ad[e0 + r] = (u16)(sd[r] + cnt);
-                }
+                const bool am = (amb >> r) & 1u;
+                w[r] = am ? ww_make(gs, live, key, j) : ww_make(j < L ? j : (u32)(64 * E - 1), false, 0ull, j);  // a final suffix stays where it is
+                if (am) pl[r] = pl_make(sv, dep[k] + cnt, pl_p(pl[r]));
             }
         }
-        __syncthreads();
-        // ---- new position of every active element inside its group
-        u32 newpos[TR_PER];
-        u32 medf = 0;
-        {
-            u32 o = obase;
+        // ---- sort; the payloads follow
 #pragma unroll
-            for (int r = 0; r < TR_PER; r++) {
-                o += (hf >> r) & 1u;
-                newpos[r] = e0 + r;
-                if (e0 + r < m) {
-                    const u32 gs = gstart[o], ge = gstart[o + 1];
-                    if (ge - gs <= (u32)TR_SMALL) {
-                        // rank by counting; eight words of the group in flight per round trip (one at a time, the loop is a chain
-                        // of LDS latencies: measured 3x the whole rest of the step)
-                        u32 below = 0;
-                        const u64 mineW = wd[r];
-                        for (u32 q = gs; q < ge; q += 8u) {
-                            u64 x[8];
+        for (int r = 0; r < E; r++) lds.pl[lane * E + r] = pl[r];
+        wave_bitonic<E>(w);
+        wave_sync();
 #pragma unroll
-                            for (u32 k = 0; k < 8u; k++) x[k] = word[q + k < ge ? q + k : ge - 1u];
+        for (int r = 0; r < E; r++) pl[r] = lds.pl[(u32)w[r] & ((1u << WW_IDX) - 1u)];
+        wave_sync();
+        // ---- new heads: where the word (without the position) differs from the left neighbour's
+        const u64 left = __shfl_up(w[E - 1], 1u);
 #pragma unroll
-                            for (u32 k = 0; k < 8u; k++) below += (q + k < ge && x[k] < mineW) ? 1u : 0u;
-                        }
-                        newpos[r] = gs + below;
-                    } else {
-                        medf |= 1u << r;
-                    }
-                }
-            }
+        for (int r = 0; r < E; r++) {
+            const u64 prev = r ? w[r - 1] : left;
+            if ((w[r] >> WW_IDX) != (prev >> WW_IDX)) hm |= 1u << r;  // (lane 0, r = 0 compares with its own last word: it is a head already)
         }
-        u32 M;
-        {
-            const u32 nm = (u32)__popc(medf);
-            u32 q = block_excl_add<TR_NT>(nm, red, M);
-            if (M) {
-                u32 o = obase;
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void wr_batch(const WrCtx & cx, WrLds & lds, u32 c, u32 L) {
+    const u32 lane = (u32)lane_id();
+    u64 pl[E];
+    u32 hm = 0;
+    u32 xv[E];
+    u8 xp[E];
 #pragma unroll
-                for (int r = 0; r < TR_PER; r++) {
-                    o += (hf >> r) & 1u;
-                    if ((medf >> r) & 1u) {
-                        const u64 gs = gstart[o];
-                        sb[tr_pad(q)] = (gs << 53) | (wd[r] & ~0xFFFull) | (u64)q;
-                        mact[q] = (u16)(e0 + r);
-                        q++;
-                    }
-                }
-            }
-        }
-        u32 mp = 0;
-        if (M) {
-            mp = 2;
-            while (mp < M) mp <<= 1;
-            for (u32 q = M + tid; q < mp; q += TR_NT) sb[tr_pad(q)] = ~0ull;
-            __syncthreads();
-            tr_bitonic(sb, mp);  // ends with a barrier
-        }
-        // ---- move: read everything that moves into registers, then write it to its new place
-        u32 mv_v[TR_PER], mv_dst[TR_PER];
-        u16 mv_d[TR_PER];
-        u8 mv_p[TR_PER];
-        u64 mv_w[TR_PER];
-        u32 sm_v[TR_PER];
-        u16 sm_d[TR_PER];
-        u8 sm_p[TR_PER];
+    for (int r = 0; r < E; r++) {
+        const u32 j = lane * E + r;
+        const u64 p = cx.slot0 + c + (j < L ? j : L - 1u);
+        xv[r] = cx.v[p];
+        xp[r] = cx.pb[p];
+    }
 #pragma unroll
-        for (int r = 0; r < TR_PER; r++) {
-            const u32 e = e0 + r;
-            if (e < m && !((medf >> r) & 1u)) {
-                sm_v[r] = av[e];
-                sm_d[r] = ad[e];
-                sm_p[r] = apb[e];
-            }
-            const u32 j = e0 + r;  // sorted position among the larger groups' elements
-            mv_dst[r] = 0xFFFFFFFFu;
-            if (j < M) {
-                const u64 x = sb[tr_pad(j)];
-                const u32 src = mact[(u32)(x & 0xFFFu)];
-                mv_dst[r] = mact[j];
-                mv_v[r] = av[src];
-                mv_d[r] = ad[src];
-                mv_p[r] = apb[src];
-                mv_w[r] = word[src];
-            }
+    for (int r = 0; r < E; r++) {
+        const u32 j = lane * E + r;
+        const u32 wpos = c + j;
+        const bool in = j < L;
+        const u32 h = in ? ((lds.hb[wpos >> 5] >> (wpos & 31u)) & 1u) : 1u;
+        hm |= h << r;
+        pl[r] = in ? pl_make(xv[r] & V_MASK, 0u, xp[r]) : 0ull;
+        lds.aux[j] = (u16)(c + (in ? j : 0u));
+    }
+    wave_sync();
+    wr_run<E>(cx, lds, pl, hm, L, 0u);
+    wave_sync();  // the next batch reuses the buffers
+}
+
+// A batch of <= 64 slots goes to the tail kernel as it is (depth 0: the tail kernel walks the windows its groups were formed on);
+// suffixes alone in their group stay where they are.
+__device__ __forceinline__ void wr_hand_over(const WrCtx & cx, WrLds & lds, u32 c, u32 L) {
+    const u32 lane = (u32)lane_id();
+    const bool in = lane < L;
+    const u32 wpos = c + lane;
+    const u32 h = in ? ((lds.hb[wpos >> 5] >> (wpos & 31u)) & 1u) : 1u;
+    const u32 wn = wpos + 1u;
+    const u32 hn = lane + 1u < L ? ((lds.hb[wn >> 5] >> (wn & 31u)) & 1u) : 1u;
+    const bool amb = in && !(h && hn);
+    const u64 am = __ballot(amb);
+    const u32 total = (u32)__popcll((unsigned long long)am);
+    if (total == 0u) return;
+    u32 base = 0;
+    if (lane == 0) base = atomicAdd(&cx.counters[4], total);
+    base = __shfl(base, 0);
+    if (base + total > cx.tail_cap) {
+        if (lane == 0) {
+            cx.counters[3] = 1u;
+            atomicMin(&cx.counters[5], base);
+            atomicAdd(&cx.counters[1], total);
         }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < TR_PER; r++) {
-            const u32 e = e0 + r;
-            if (e < m && !((medf >> r) & 1u)) {
-                const u32 d = newpos[r];
-                av[d] = sm_v[r];
-                ad[d] = sm_d[r];
-                apb[d] = sm_p[r];
-                word[d] = wd[r];
-            }
-            if (mv_dst[r] != 0xFFFFFFFFu) {
-                const u32 d = mv_dst[r];
-                av[d] = mv_v[r];
-                ad[d] = mv_d[r];
-                apb[d] = mv_p[r];
-                word[d] = mv_w[r];
-            }
+        return;
+    }
+    if (amb) {
+        const u32 d = base + (u32)__popcll((unsigned long long)(am & (((u64)1 << lane) - 1ull)));
+        const u64 p = cx.slot0 + wpos;
+        cx.tail_v[d] = (cx.v[p] & V_MASK) | (h ? V_HEAD : 0u);
+        cx.tail_slot[d] = (u32)p;
+        cx.tail_d[d] = 0;
+        cx.tail_pb[d] = cx.pb[p];
+    }
+}
+
+__device__ __forceinline__ void wr_emit_big(u32 * __restrict__ big_slot, u32 * __restrict__ big_hp, u32 big_cap, u32 * __restrict__ counters, u64 slot0, u32 p0, u32 p1,
+                                            u32 hp) {
+    if (p1 <= p0) return;
+    const u32 lane = (u32)lane_id();
+    const u32 cnt = p1 - p0;
+    u32 base = 0;
+    if (lane == 0) base = atomicAdd(&counters[0], cnt);
+    base = __shfl(base, 0);
+    if (base + cnt > big_cap) {
+        if (lane == 0) counters[3] = 1u;
+        return;
+    }
+    for (u32 q = lane; q < cnt; q += WAVE) {
+        big_slot[base + q] = (u32)slot0 + p0 + q;
+        big_hp[base + q] = hp;
+    }
+}
+
+__global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_resolve(const u8 * __restrict__ t, u32 n, u32 * __restrict__ v, u8 * __restrict__ pb,
+                                                                const u32 * __restrict__ hbits, const u32 * __restrict__ carry, const u8 * __restrict__ dirty,
+                                                                const u32 * __restrict__ vlc, u32 * __restrict__ big_slot, u32 * __restrict__ big_hp, u32 big_cap,
+                                                                u32 * __restrict__ tail_v, u32 * __restrict__ tail_slot, u16 * __restrict__ tail_d,
+                                                                u8 * __restrict__ tail_pb, u32 tail_cap, u32 * __restrict__ counters, u32 chain) {
+    __shared__ u32 tab[256];
+    __shared__ WrLds wl[WR_WAVES];
+    tab[threadIdx.x] = vlc[threadIdx.x];
+    __syncthreads();  // the only workgroup barrier: from here on the waves do not know of each other
+    const u32 lane = (u32)lane_id();
+    const u32 tile = blockIdx.x * WR_WAVES + (u32)wave_id();
+    const u64 a = (u64)tile * WR_A;
+    if (a >= n) return;
+    if (dirty && !(dirty[tile] | dirty[tile + 1])) return;
+    WrLds & lds = wl[wave_id()];
+    // head bits of [a, a + 1024] from the snapshot; slots past the end are heads
+    if (lane < 33u) {
+        const u64 first = a + 32ull * lane;
+        const u64 limit = ((u64)n + 63u) & ~63ull;  // the snapshot is written in whole 64-slot words
+        lds.hb[lane] = first < limit ? hbits[first >> 5] : 0xFFFFFFFFu;
+    }
+    wave_sync();
+    WrCtx cx{t, n, v, pb, tab, counters, chain, a, tail_v, tail_slot, tail_d, tail_pb, tail_cap};
+    const u32 headA = wr_next_head(lds.hb, (u32)WR_A);  // first head that belongs to the next wave (<= 1024, or none in sight)
+    u32 c = wr_next_head(lds.hb, 0u);
+    if (c > 0u) {  // the slots before the first head continue a group headed before this window (tile > 0: slot 0 is always a head)
+        const u32 hp = carry[tile];
+        const bool big = c == WR_FAR || (u32)a + c - hp > (u32)WR_G;
+        const u32 stop = c < (u32)WR_A ? c : (u32)WR_A;
+        const u64 left = (u64)n - a;
+        if (big) wr_emit_big(big_slot, big_hp, big_cap, counters, a, 0u, (u64)stop < left ? stop : (u32)left, hp);
+    }
+    while (c < (u32)WR_A && a + c < n) {
+        u32 e = wr_prev_head(lds.hb, c + (u32)WR_G);  // >= c
+        if (e == c) {  // no other head within 512 slots: too large for a wave
+            const u32 nh = wr_next_head(lds.hb, c + 1u);
+            const u32 stop = nh < (u32)WR_A ? nh : (u32)WR_A;
+            const u64 left = (u64)n - a;
+            wr_emit_big(big_slot, big_hp, big_cap, counters, a, c, (u64)stop < left ? stop : (u32)left, (u32)a + c);
+            c = nh;
+            continue;
         }
-        __syncthreads();
-        // ---- new heads: where the bits just compared differ from the left neighbour's
-        u32 nhf = 0;
-#pragma unroll
-        for (int r = 0; r < TR_PER; r++) {
-            const u32 e = e0 + r;
-            if (e < m) {
-                const bool h = ((hf >> r) & 1u) || (word[e] >> 12) != (word[e - 1] >> 12);  // e > 0 here: element 0 is a head
-                nhf |= (h ? 1u : 0u) << r;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < TR_PER; r++)
-            if (e0 + r < m) ahead[e0 + r] = (u8)((nhf >> r) & 1u);
-        if (tid == 0) ahead[m] = 1;
-        __syncthreads();
-        // ---- suffixes that are alone now are final: out they go; the others move up
-        u32 keepf = 0;
-        u32 kv[TR_PER];
-        u16 kd[TR_PER], ks[TR_PER];
-        u8 kp[TR_PER], kh[TR_PER];
-#pragma unroll
-        for (int r = 0; r < TR_PER; r++) {
-            const u32 e = e0 + r;
-            if (e < m) {
-                const bool h = (nhf >> r) & 1u;
-                const bool uniq = h && ahead[e + 1];
-                kv[r] = av[e];
-                kd[r] = ad[e];
-                ks[r] = aslot[e];
-                kp[r] = apb[e];
-                kh[r] = (u8)h;
-                if (uniq) {
-                    const u64 p = a + ks[r];
-                    v[p] = kv[r] | V_HEAD;
-                    pb[p] = kp[r];
-                    if (kv[r] == 0) counters[2] = (u32)p;
-                } else {
-                    keepf |= 1u << r;
-                }
-            }
-        }
-        u32 mnext;
-        {
-            const u32 nk = (u32)__popc(keepf);
-            u32 d = block_excl_add<TR_NT>(nk, red, mnext);  // ends with a barrier: every read above is done
-#pragma unroll
-            for (int r = 0; r < TR_PER; r++)
-                if ((keepf >> r) & 1u) {
-                    av[d] = kv[r];
-                    ad[d] = kd[r];
-                    aslot[d] = ks[r];
-                    apb[d] = kp[r];
-                    ahead[d] = kh[r];
-                    d++;
-                }
-        }
-        m = mnext;
-        __syncthreads();
+        if (headA != WR_FAR && e > headA) e = headA;  // groups headed at or beyond the next anchor are the next wave's
+        if ((u64)e > (u64)n - a) e = (u32)((u64)n - a);  // (the first slot past the end is a head)
+        const u32 L = e - c;
+        // singletons only? then there is nothing to do: a batch of L heads
+        if (L <= 64u) wr_hand_over(cx, lds, c, L);
+        else if (L <= 128u) wr_batch<2>(cx, lds, c, L);
+        else if (L <= 256u) wr_batch<4>(cx, lds, c, L);
+        else wr_batch<8>(cx, lds, c, L);
+        c = e;
     }
 }
 
 // ---- the tail: tiny groups that need many more windows ---------------------------------------------------------------------------
-// One wave per tile's leftovers (chunk_off / chunk_cnt), a lane per suffix, as many whole groups at a time as fit the 64 lanes.  A step
-// costs one gather from the text and a handful of cross-lane operations; nothing in it waits for another wave, and the kernel's small
-// footprint puts dozens of waves on a CU, so the gather latency of one is covered by the others.
+// What the resolve kernel hands over: batches that are down to <= 64 ambiguous suffixes (and batches that never had more).  They sit
+// in one global list, every batch a run of whole groups that starts with a head.  One wave per 64 list entries takes the groups
+// whose head lies in its entries (a group has at most 64 members: they end within the next 64 entries), a lane per suffix, as many
+// whole groups at a time as fit the 64 lanes.  A step costs one gather from the text and a handful of cross-lane operations; nothing
+// in it waits for another wave, and with ~50 registers and 2 KB of LDS dozens of these waves share a CU, so the gather latency of
+// one is covered by the others -- which the resolve kernel, with eight suffixes per lane in registers, cannot offer.
 __global__ void __launch_bounds__(WAVE) k_bwt_tail(const u8 * __restrict__ t, u32 n, u32 * __restrict__ v, u8 * __restrict__ pb, const u32 * __restrict__ vlc,
-                                                  const u32 * __restrict__ chunk_off, const u32 * __restrict__ chunk_cnt, const u32 * __restrict__ tail_v,
-                                                  const u32 * __restrict__ tail_slot, const u16 * __restrict__ tail_d, const u8 * __restrict__ tail_pb,
-                                                  u32 * __restrict__ counters) {
+                                                  const u32 * __restrict__ tail_v, const u32 * __restrict__ tail_slot, const u16 * __restrict__ tail_d,
+                                                  const u8 * __restrict__ tail_pb, u32 * __restrict__ counters, u32 total_entries, u32 chain) {
     __shared__ u32 tab[256];
     __shared__ u64 s_word[WAVE];
     __shared__ u32 s_v[WAVE];
     __shared__ u16 s_d[WAVE];
     __shared__ u8 s_pb[WAVE];
-    const u32 cnt = chunk_cnt[blockIdx.x];
-    if (cnt == 0) return;
-    const u32 off = chunk_off[blockIdx.x];
     const u32 lane = (u32)lane_id();
+    const u32 off = blockIdx.x * WAVE;  // this wave's 64 entries; its groups end before off + 128
+    if (off >= total_entries) return;
+    u32 cursor, cnt;
+    {
+        const u32 i0 = off + lane, i1 = off + WAVE + lane;
+        const u64 h0 = __ballot(i0 >= total_entries || (tail_v[i0 < total_entries ? i0 : 0u] >> 31) != 0u);
+        const u64 h1 = __ballot(i1 >= total_entries || (tail_v[i1 < total_entries ? i1 : 0u] >> 31) != 0u);
+        if (!h0) return;  // these 64 entries continue a group headed in the previous wave's entries
+        cursor = (u32)__ffsll((unsigned long long)h0) - 1u;
+        cnt = h1 ? (u32)WAVE + (u32)__ffsll((unsigned long long)h1) - 1u : 2u * WAVE;
+        if (off + cnt > total_entries) cnt = total_entries - off;
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) tab[lane + 64u * k] = vlc[lane + 64u * k];
     __syncthreads();
-    u32 cursor = 0;
     while (cursor < cnt) {
         const u32 i = cursor + lane;
         const bool have = i < cnt;
@@ -837,6 +815,16 @@ __global__ void __launch_bounds__(WAVE) k_bwt_tail(const u8 * __restrict__ t, u3
         u32 sp = have ? (u32)tail_pb[off + i] : 0u;
         bool headf = !act || (x >> 31);
         bool resolved = false;
+        const bool fresh = act && sd == 0u;  // came straight from the slot array: depth = the windows its group was formed on
+        if (__ballot(fresh)) {
+            for (u32 hop = 0; hop < chain; hop++) {
+                u64 wa, wb, k56;
+                u32 avl, c56;
+                load_window(t, (u64)sv + sd, n, wa, wb, avl);
+                vlc_pack<56>(tab, wa, wb, avl, k56, c56);
+                sd += fresh ? c56 : 0u;
+            }
+        }
         for (u32 step = 0; step < (u32)TL_CAP; step++) {
             const u64 H = __ballot(headf);  // bit 0 is set: the batch starts with a head
             const u32 gs = 63u - (u32)__clzll((unsigned long long)(H & ((2ull << lane) - 1ull)));
@@ -949,11 +937,11 @@ __global__ void __launch_bounds__(BW_BLOCK) k_big_apply(const u32 * __restrict__
 }
 
 // U from the payload bytes: U[0] = T[n-1], slot i0 (suffix 0) is skipped.
-__global__ void __launch_bounds__(BW_BLOCK) k_bwt_finish(const u8 * __restrict__ t, const u8 * __restrict__ pb, u32 n, const u32 * __restrict__ counters,
+__global__ void __launch_bounds__(BW_BLOCK) k_bwt_finish(const u8 * __restrict__ t, const u8 * __restrict__ pb, u32 n, const u32 * __restrict__ slot_of_suffix0,
                                                         u8 * __restrict__ out, u32 * __restrict__ idx_out) {
     const u32 i = blockIdx.x * BW_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const u32 i0 = counters[2];
+    const u32 i0 = *slot_of_suffix0;
     if (i == 0) {
         out[0] = t[n - 1];
         *idx_out = i0 + 1;
@@ -1128,7 +1116,8 @@ __global__ void __launch_bounds__(BG_SPINE) k_bg_spine(u32 * __restrict__ tile_h
 template <bool VF, bool DOUBLING>
 __global__ void __launch_bounds__(BW_BLOCK) k_bg_apply(const u64 * __restrict__ keys, const u32 * __restrict__ vals, const u32 * __restrict__ slots, u32 m,
                                                       const u32 * __restrict__ tile_head, const u32 * __restrict__ tile_keep, u32 * __restrict__ sa,
-                                                      u32 * __restrict__ isa, u32 * __restrict__ vals_out, u32 * __restrict__ slots_out, u32 * __restrict__ grp_out) {
+                                                      u32 * __restrict__ isa, u32 * __restrict__ vals_out, u32 * __restrict__ slots_out, u32 * __restrict__ grp_out,
+                                                      const u8 * __restrict__ t, u8 * __restrict__ pb, u32 * __restrict__ rank_out) {
     __shared__ u32 lds[BW_BLOCK / WAVE + 1];
     __shared__ u32 st_v[BG_TILE], st_s[BG_TILE], st_g[BG_TILE];  // the tile's part of the compacted list, staged so that it leaves coalesced
     const u64 base = (u64)blockIdx.x * BG_TILE + (u64)threadIdx.x * BG_ITEMS;
@@ -1186,9 +1175,13 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bg_apply(const u64 * __restrict__ 
     for (int j = 0; j < BG_ITEMS; j++) {
         const u64 k = base + j;
         if (k < m) {
-            if (!DOUBLING || rank[j] != hi[j]) isa[v[j]] = rank[j];
+            if (VF) rank_out[k] = rank[j];  // in slot order; the inverse suffix array is filled from these by isa_from_ranks (bucketed, not n random stores)
+            else if (!DOUBLING || rank[j] != hi[j]) isa[v[j]] = rank[j];
             if ((uniqs >> j) & 1u) {
-                if (!VF) sa[sl[j]] = v[j];  // VF: the list IS the array, the suffix is in its slot already (and neighbours still read its flag)
+                if (!VF) {  // (VF: the list IS the array, the suffix is in its slot already -- and neighbours still read its flag)
+                    sa[sl[j]] = v[j];
+                    pb[sl[j]] = v[j] ? t[v[j] - 1u] : (u8)0;  // the slot's BWT symbol: the output is assembled from these bytes
+                }
             } else {
                 st_v[out] = v[j];
                 st_s[out] = sl[j];
@@ -1219,16 +1212,25 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bwt_doubling_keys_grp(const u32 * 
     keys[k] = ((u64)grp[k] << 32) | lo;
 }
 
-__global__ void __launch_bounds__(BW_BLOCK) k_bwt_emit(const u8 * __restrict__ t, const u32 * __restrict__ sa, const u32 * __restrict__ isa, u32 n,
-                                                      u8 * __restrict__ out, u32 * __restrict__ idx_out) {
-    const u32 i = blockIdx.x * BW_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const u32 i0 = isa[0];
-    if (i == 0) {
-        out[0] = t[n - 1];
-        *idx_out = i0 + 1;
+// isa[suffix] = rank for pairs that a radix pass has bucketed by the top 8 bits of the suffix number: a bucket's destinations lie in
+// a window of n / 256 words (4 MB at 256 MiB), and with a contiguous range of tiles per XCD (cf. sort.hip) the XCD's L2 absorbs the
+// random stores of the bucket it is working on -- measured against n stores all over the 1 GB array: see DESIGN.md.
+constexpr int IS_ITEMS = 8;
+__global__ void __launch_bounds__(BW_BLOCK) k_isa_scatter(const u32 * __restrict__ suf, const u32 * __restrict__ rank, u32 n, u32 tiles, u32 * __restrict__ isa) {
+    const u32 per = (tiles + 7u) / 8u;
+    const u32 tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (tile >= tiles) return;
+    const u64 base = (u64)tile * (BW_BLOCK * IS_ITEMS) + threadIdx.x;
+    u32 x[IS_ITEMS], r[IS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < IS_ITEMS; k++) {
+        const u64 i = base + (u64)k * BW_BLOCK;
+        x[k] = suf[i < n ? i : (u64)n - 1];
+        r[k] = rank[i < n ? i : (u64)n - 1];
     }
-    if (i != i0) out[i < i0 ? i + 1 : i] = t[(sa[i] & V_MASK) - 1];  // (slots that were final before the deep path still carry their flag)
+#pragma unroll
+    for (int k = 0; k < IS_ITEMS; k++)
+        if (base + (u64)k * BW_BLOCK < n) isa[x[k] & V_MASK] = r[k];
 }
 
 static int bits_for(u64 x) {
@@ -1275,9 +1277,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     u32 * carry = tmp.take<u32>(tiles + 1);
     u8 * dirty = tmp.take<u8>(tiles + 2);
     u32 * hbits = tmp.take<u32>(((size_t)n + 63) / 64 * 2 + (size_t)TR_S / 32 + 8);  // snapshot of the head flags, whole 64-slot words of every anchor tile
-    u32 * d_words = tmp.take<u32>(8);   // counters [0] big elements, [1] left ambiguous by the resolve / tail kernels, [2] slot of suffix 0, [3] a list overflowed, [4] tail elements; [6] scan total, [7] primary index
-    u32 * chunk_off = tmp.take<u32>(tiles + 1);
-    u32 * chunk_cnt = tmp.take<u32>(tiles + 1);
+    u32 * d_words = tmp.take<u32>(8);   // counters [0] big elements, [1] left ambiguous by the resolve / tail kernels, [2] slot of suffix 0, [3] a list overflowed, [4] tail entries, [5] start of the first tail append that did not fit; [6] scan total, [7] primary index
     u32 * d_vlc = tmp.take<u32>(256);
     u32 * d_hist = tmp.take<u32>(256);
     BwtStats st;
@@ -1288,6 +1288,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     u32 h_hist[256], h_vlc[256];
     HIP_CHECK(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), s));
     HIP_CHECK(hipMemsetAsync(d_words, 0, 8 * sizeof(u32), s));
+    HIP_CHECK(hipMemsetAsync(d_words + 5, 0xFF, sizeof(u32), s));
     launch(k_bwt_sym_hist, grid(((u64)n + 63) / 64), dim3(BW_BLOCK), 0, s, d_in, n, d_hist);
     HIP_CHECK(hipMemcpyAsync(h_hist, d_hist, sizeof h_hist, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -1323,16 +1324,19 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     u32 * tail_slot = tail_v + tail_cap;
     u16 * tail_d = reinterpret_cast<u16 *>(tail_slot + tail_cap);
     u8 * tail_pb = reinterpret_cast<u8 *>(tail_d + tail_cap);
-
     u32 g = 7;            // symbols every group is known to share at least (7 per 56-bit window)
     bool deep = false;    // fall back to rank doubling
     u32 h_words[8];
     for (int pass = 0;; pass++) {
-        HIP_CHECK(hipMemsetAsync(chunk_cnt, 0, ((size_t)tiles + 1) * sizeof(u32), s));
-        launch(k_bwt_resolve, dim3(tiles), dim3(TR_NT), 0, s, d_in, n, V, pb, (const u32 *)hbits, (const u32 *)carry, (const u8 *)(pass ? dirty : nullptr),
-               (const u32 *)d_vlc, big_slot, big_hp, big_cap, chunk_off, chunk_cnt, tail_v, tail_slot, tail_d, tail_pb, tail_cap, d_words, (u32)pass + 1u);
-        launch(k_bwt_tail, dim3(tiles), dim3(WAVE), 0, s, d_in, n, V, pb, (const u32 *)d_vlc, (const u32 *)chunk_off, (const u32 *)chunk_cnt, (const u32 *)tail_v,
-               (const u32 *)tail_slot, (const u16 *)tail_d, (const u8 *)tail_pb, d_words);
+        launch(k_bwt_resolve, dim3((tiles + WR_WAVES - 1) / WR_WAVES), dim3(WR_WAVES * WAVE), 0, s, d_in, n, V, pb, (const u32 *)hbits, (const u32 *)carry,
+               (const u8 *)(pass ? dirty : nullptr), (const u32 *)d_vlc, big_slot, big_hp, big_cap, tail_v, tail_slot, tail_d, tail_pb, tail_cap, d_words,
+               (u32)pass + 1u);
+        HIP_CHECK(hipMemcpyAsync(h_words, d_words, sizeof h_words, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        const u32 ntail = h_words[4] < h_words[5] ? h_words[4] : h_words[5];  // ([5]: where the first append that did not fit would have started)
+        if (ntail)
+            launch(k_bwt_tail, dim3((ntail + WAVE - 1) / WAVE), dim3(WAVE), 0, s, d_in, n, V, pb, (const u32 *)d_vlc, (const u32 *)tail_v, (const u32 *)tail_slot,
+                   (const u16 *)tail_d, (const u8 *)tail_pb, d_words, ntail, (u32)pass + 1u);
         HIP_CHECK(hipMemcpyAsync(h_words, d_words, sizeof h_words, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         const u32 nb = h_words[0];
@@ -1380,13 +1384,14 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
         g += 7;
         HIP_CHECK(hipMemsetAsync(d_words, 0, sizeof(u32), s));      // the big list and the tail list are rebuilt by the next pass
         HIP_CHECK(hipMemsetAsync(d_words + 4, 0, sizeof(u32), s));
+        HIP_CHECK(hipMemsetAsync(d_words + 5, 0xFF, sizeof(u32), s));
         launch(k_bwt_reduce_heads, dim3(tiles), dim3(BW_BLOCK), 0, s, (const u32 *)V, n, tile_last, hbits);
         launch(k_bwt_spine_max, dim3(1), dim3(SP_BLOCK), 0, s, (const u32 *)tile_last, tiles, carry);
     }
 
     u32 idx = 0;
     if (!deep) {
-        launch(k_bwt_finish, grid(n), dim3(BW_BLOCK), 0, s, d_in, (const u8 *)pb, n, (const u32 *)d_words, d_out, d_words + 7);
+        launch(k_bwt_finish, grid(n), dim3(BW_BLOCK), 0, s, d_in, (const u8 *)pb, n, (const u32 *)(d_words + 2), d_out, d_words + 7);
     } else {
         // ---- deep path: ISA from the flags, then prefix doubling on (rank, rank of the suffix h further on)
         u32 * sa = V;  // in place: a slot holds its final suffix (without flag) once the suffix is alone in its group
@@ -1397,16 +1402,26 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
         const u32 max_tiles = (u32)(((u64)n + BG_TILE - 1) / BG_TILE);
         u32 * tile_head = tmp.take<u32>(2 * (size_t)max_tiles + 16);
         u32 * tile_keep = tile_head + max_tiles + 8;
-        // every group still ambiguous shares at least h symbols: 7 per window of the big rounds, but a group the resolve kernel
-        // handed back early (more than 64 members after its three steps) is only known to share the first window's 7 + 3 x 5.
-        u32 m = n, h = h_words[1] ? (g < 22u ? g : 22u) : g;
+        // every group still ambiguous shares at least h symbols: 7 per window of the big rounds; a group the resolve kernel gave up
+        // shares the first window's 7 and 5 more per step it took (WR_CAP steps): never the shallower of the two.
+        u32 m = n, h = g < 7u + 5u * (u32)TL_CAP ? g : 7u + 5u * (u32)TL_CAP;
         if (getenv("BZ3_BWT_TRACE")) fprintf(stderr, "[bwt] n %u deep path from depth %u\n", n, h);
         {
+            // ranks in slot order, then the inverse suffix array from (suffix, rank) pairs bucketed by the top bits of the suffix
+            u32 * rk = reinterpret_cast<u32 *>(key[0]);
+            u32 * kb = rk + n;                            // key[0] holds 2 n words
+            u32 * rb = reinterpret_cast<u32 *>(key[1]);
             const u32 tl = (u32)(((u64)m + BG_TILE - 1) / BG_TILE);
             launch(k_bg_reduce<true>, dim3(tl), dim3(BW_BLOCK), 0, s, (const u64 *)nullptr, (const u32 *)V, m, tile_head, tile_keep);
             launch(k_bg_spine, dim3(1), dim3(BG_SPINE), 0, s, tile_head, tile_keep, tl, d_words + 6);
             launch(k_bg_apply<true, false>, dim3(tl), dim3(BW_BLOCK), 0, s, (const u64 *)nullptr, (const u32 *)V, (const u32 *)nullptr, m, (const u32 *)tile_head,
-                   (const u32 *)tile_keep, sa, isa, vv[0], slot[0], grp);
+                   (const u32 *)tile_keep, sa, isa, vv[0], slot[0], grp, d_in, pb, rk);
+            const int nbits = bits_for((u64)n - 1);
+            const int shift = nbits > 8 ? nbits - 8 : 0;
+            radix_pass<u32>((const u32 *)V, kb, (const u32 *)rk, rb, n, shift, 0xFFFFFFFFu, 0u, tmp, s);
+            st.radix_passes++;
+            const u32 itiles = (u32)(((u64)n + BW_BLOCK * IS_ITEMS - 1) / (BW_BLOCK * IS_ITEMS));
+            launch(k_isa_scatter, dim3(8u * ((itiles + 7u) / 8u)), dim3(BW_BLOCK), 0, s, (const u32 *)kb, (const u32 *)rb, n, itiles, isa);
         }
         int scur = 0;
         u32 * vact = vv[0], * vfree = vv[1];
@@ -1432,14 +1447,15 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
             launch(k_bg_reduce<false>, dim3(tl), dim3(BW_BLOCK), 0, s, (const u64 *)key[c], (const u32 *)nullptr, m, tile_head, tile_keep);
             launch(k_bg_spine, dim3(1), dim3(BG_SPINE), 0, s, tile_head, tile_keep, tl, d_words + 6);
             launch(k_bg_apply<false, true>, dim3(tl), dim3(BW_BLOCK), 0, s, (const u64 *)key[c], (const u32 *)vsorted, (const u32 *)slot[scur], m,
-                   (const u32 *)tile_head, (const u32 *)tile_keep, sa, isa, vfree, slot[scur ^ 1], grp);
+                   (const u32 *)tile_head, (const u32 *)tile_keep, sa, isa, vfree, slot[scur ^ 1], grp, d_in, pb, (u32 *)nullptr);
             scur ^= 1;
             vact = vfree;
             vfree = vsorted;
             if (h >= 0x40000000u) throw HipError{hipErrorUnknown, "suffix sort did not converge", __FILE__, __LINE__};
             h *= 2;
         }
-        launch(k_bwt_emit, grid(n), dim3(BW_BLOCK), 0, s, d_in, (const u32 *)sa, (const u32 *)isa, n, d_out, d_words + 7);
+        // isa[0] = the slot of suffix 0
+        launch(k_bwt_finish, grid(n), dim3(BW_BLOCK), 0, s, d_in, (const u8 *)pb, n, (const u32 *)isa, d_out, d_words + 7);
     }
     HIP_CHECK(hipMemcpyAsync(&idx, d_words + 7, 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
