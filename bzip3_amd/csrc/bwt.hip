@@ -745,23 +745,27 @@ __global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_resolve(const u8 * __re
         const u64 left = (u64)n - a;
         if (big) wr_emit_big(big_slot, big_hp, big_cap, counters, a, 0u, (u64)stop < left ? stop : (u32)left, hp);
     }
-    while (c < (u32)WR_A && a + c < n) {
-        u32 e = wr_prev_head(lds.hb, c + (u32)WR_G);  // >= c
-        if (e == c) {  // no other head within 512 slots: too large for a wave
-            const u32 nh = wr_next_head(lds.hb, c + 1u);
+    const u32 wend = (u64)n - a < 1025ull ? (u32)((u64)n - a) : 1025u;  // window positions that exist (the first slot past the end is a head)
+    while (c < (u32)WR_A && c < wend) {
+        const u32 nh = wr_next_head(lds.hb, c + 1u);  // end of the group that starts at c
+        if (nh == WR_FAR || nh - c > (u32)WR_G) {     // too large for a wave
             const u32 stop = nh < (u32)WR_A ? nh : (u32)WR_A;
-            const u64 left = (u64)n - a;
-            wr_emit_big(big_slot, big_hp, big_cap, counters, a, c, (u64)stop < left ? stop : (u32)left, (u32)a + c);
+            wr_emit_big(big_slot, big_hp, big_cap, counters, a, c, stop < wend ? stop : wend, (u32)a + c);
             c = nh;
             continue;
         }
+        // Batches are kept as small as their first group allows: up to 64 slots go straight to the tail kernel (one suffix per lane,
+        // ~50 registers, dozens of waves per CU: measured four times the throughput per suffix of the wide path below), and only a
+        // group of more than 64 members takes the wide path, with as many lanes' worth of capacity as it needs.
+        const u32 size = nh - c;
+        const u32 room = size <= 64u ? 64u : size <= 128u ? 128u : size <= 256u ? 256u : 512u;
+        u32 e = wr_prev_head(lds.hb, c + room);  // >= nh: whole groups that fit beside it come along
         if (headA != WR_FAR && e > headA) e = headA;  // groups headed at or beyond the next anchor are the next wave's
-        if ((u64)e > (u64)n - a) e = (u32)((u64)n - a);  // (the first slot past the end is a head)
+        if (e > wend) e = wend;
         const u32 L = e - c;
-        // singletons only? then there is nothing to do: a batch of L heads
-        if (L <= 64u) wr_hand_over(cx, lds, c, L);
-        else if (L <= 128u) wr_batch<2>(cx, lds, c, L);
-        else if (L <= 256u) wr_batch<4>(cx, lds, c, L);
+        if (room == 64u) wr_hand_over(cx, lds, c, L);
+        else if (room == 128u) wr_batch<2>(cx, lds, c, L);
+        else if (room == 256u) wr_batch<4>(cx, lds, c, L);
         else wr_batch<8>(cx, lds, c, L);
         c = e;
     }
