@@ -67,6 +67,7 @@ def _declare(L):
         "bz3_hip_stage_lzp_decode": (i32, [vp, i32, vp, i32]),
         "bz3_hip_stage_bwt": (i32, [vp, vp, i32]),
         "bz3_hip_stage_unbwt": (i32, [vp, vp, i32, i32]),
+        "bz3_hip_stage_last_ms": (C.c_float, []),
         "bz3_hip_stage_cm_encode": (i32, [vp, i32, vp]),
         "bz3_hip_stage_cm_decode": (None, [vp, i32, vp, i32]),
         "bz3_hip_stage_cm_decode_many": (C.c_float, [vp, i32, vp, i32, i32, vp]),

@@ -1706,13 +1706,21 @@ BZIP3_API int32_t bz3_hip_stage_lzp_decode(const uint8_t * in, int32_t n, uint8_
     });
 }
 
+// Wall time of the last bz3_hip_stage_bwt / bz3_hip_stage_unbwt call's transform alone (both are synchronous: from the first launch to
+// the last result on the host; the hook's own allocations and PCIe copies are outside).  Profiling only.
+static std::atomic<float> g_stage_ms{0.f};
+BZIP3_API float bz3_hip_stage_last_ms(void) { return g_stage_ms.load(); }
+
 BZIP3_API int32_t bz3_hip_stage_bwt(const uint8_t * in, uint8_t * out, int32_t n) {
     return stage_guard([&]() -> s32 {
         StageEnv e;
         u8 * d = e.dev((size_t)n + 64, in, (size_t)n);
         u8 * o = e.dev((size_t)n + 64);
         Arena a = e.ctx->arena_for(workspace_bytes_for((u64)n + 64));
+        HIP_CHECK(hipStreamSynchronize(e.s));
+        const auto t0 = std::chrono::steady_clock::now();
         const s32 idx = bwt_forward(d, (u32)n, o, a, e.s, nullptr);
+        g_stage_ms.store(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count());
         e.down(out, o, (size_t)n);
         return idx;
     });
@@ -1731,7 +1739,11 @@ BZIP3_API int32_t bz3_hip_stage_unbwt(const uint8_t * in, uint8_t * out, int32_t
         u8 * d = e.dev((size_t)n + 64, in, (size_t)n);
         u8 * o = e.dev((size_t)n + 64);
         Arena a = e.ctx->arena_for(workspace_bytes_for((u64)n + 64));
+        HIP_CHECK(hipStreamSynchronize(e.s));
+        const auto t0 = std::chrono::steady_clock::now();
         bwt_inverse(d, (u32)n, (u32)idx, o, a, e.s);
+        HIP_CHECK(hipStreamSynchronize(e.s));
+        g_stage_ms.store(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count());
         e.down(out, o, (size_t)n);
         return 0;
     });

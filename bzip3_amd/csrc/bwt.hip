@@ -661,40 +661,6 @@ __device__ __forceinline__ void wr_batch(const WrCtx & cx, WrLds & lds, u32 c, u
     wave_sync();  // the next batch reuses the buffers
 }
 
-// A batch of <= 64 slots goes to the tail kernel as it is (depth 0: the tail kernel walks the windows its groups were formed on);
-// suffixes alone in their group stay where they are.
-__device__ __forceinline__ void wr_hand_over(const WrCtx & cx, WrLds & lds, u32 c, u32 L) {
-    const u32 lane = (u32)lane_id();
-    const bool in = lane < L;
-    const u32 wpos = c + lane;
-    const u32 h = in ? ((lds.hb[wpos >> 5] >> (wpos & 31u)) & 1u) : 1u;
-    const u32 wn = wpos + 1u;
-    const u32 hn = lane + 1u < L ? ((lds.hb[wn >> 5] >> (wn & 31u)) & 1u) : 1u;
-    const bool amb = in && !(h && hn);
-    const u64 am = __ballot(amb);
-    const u32 total = (u32)__popcll((unsigned long long)am);
-    if (total == 0u) return;
-    u32 base = 0;
-    if (lane == 0) base = atomicAdd(&cx.counters[4], total);
-    base = __shfl(base, 0);
-    if (base + total > cx.tail_cap) {
-        if (lane == 0) {
-            cx.counters[3] = 1u;
-            atomicMin(&cx.counters[5], base);
-            atomicAdd(&cx.counters[1], total);
-        }
-        return;
-    }
-    if (amb) {
-        const u32 d = base + (u32)__popcll((unsigned long long)(am & (((u64)1 << lane) - 1ull)));
-        const u64 p = cx.slot0 + wpos;
-        cx.tail_v[d] = (cx.v[p] & V_MASK) | (h ? V_HEAD : 0u);
-        cx.tail_slot[d] = (u32)p;
-        cx.tail_d[d] = 0;
-        cx.tail_pb[d] = cx.pb[p];
-    }
-}
-
 __device__ __forceinline__ void wr_emit_big(u32 * __restrict__ big_slot, u32 * __restrict__ big_hp, u32 big_cap, u32 * __restrict__ counters, u64 slot0, u32 p0, u32 p1,
                                             u32 hp) {
     if (p1 <= p0) return;
@@ -736,38 +702,97 @@ __global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_resolve(const u8 * __re
     }
     wave_sync();
     WrCtx cx{t, n, v, pb, tab, counters, chain, a, tail_v, tail_slot, tail_d, tail_pb, tail_cap};
-    const u32 headA = wr_next_head(lds.hb, (u32)WR_A);  // first head that belongs to the next wave (<= 1024, or none in sight)
-    u32 c = wr_next_head(lds.hb, 0u);
-    if (c > 0u) {  // the slots before the first head continue a group headed before this window (tile > 0: slot 0 is always a head)
-        const u32 hp = carry[tile];
-        const bool big = c == WR_FAR || (u32)a + c - hp > (u32)WR_G;
-        const u32 stop = c < (u32)WR_A ? c : (u32)WR_A;
-        const u64 left = (u64)n - a;
-        if (big) wr_emit_big(big_slot, big_hp, big_cap, counters, a, 0u, (u64)stop < left ? stop : (u32)left, hp);
-    }
     const u32 wend = (u64)n - a < 1025ull ? (u32)((u64)n - a) : 1025u;  // window positions that exist (the first slot past the end is a head)
-    while (c < (u32)WR_A && c < wend) {
-        const u32 nh = wr_next_head(lds.hb, c + 1u);  // end of the group that starts at c
-        if (nh == WR_FAR || nh - c > (u32)WR_G) {     // too large for a wave
-            const u32 stop = nh < (u32)WR_A ? nh : (u32)WR_A;
-            wr_emit_big(big_slot, big_hp, big_cap, counters, a, c, stop < wend ? stop : wend, (u32)a + c);
-            c = nh;
-            continue;
+    // 64 head bits starting at window position `start` (may be negative: nothing is known before the window)
+    auto bits64 = [&](int start) -> u64 {
+        const int s0 = start < 0 ? 0 : start;
+        const u32 wi = (u32)s0 >> 5, sh = (u32)s0 & 31u;
+        const u64 lo = ((u64)lds.hb[wi + 1 < 33u ? wi + 1 : 32u] << 32) | lds.hb[wi < 33u ? wi : 32u];
+        const u64 hi = lds.hb[wi + 2 < 33u ? wi + 2 : 32u];
+        u64 x = sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+        if (wi + 1 >= 33u) x &= 0xFFFFFFFFull >> sh;  // (beyond the window: unknown, read as no head)
+        if (start < 0) x = start > -64 ? x << (u32)(-start) : 0ull;
+        return x;
+    };
+    // ---- groups of up to 64 suffixes go to the tail kernel (one suffix per lane, ~50 registers, dozens of waves per CU: measured four
+    // times the throughput per suffix of the wide path below).  Every slot decides for itself from the head bits around it: its group's
+    // head h (within 63 slots before it) and end e (within 64 after it); it goes if h lies in this wave's anchor slots, 2 <= e - h <= 64.
+    // One append per wave (an append per group made the list's counter the bottleneck: 200 ms).
+    {
+        u32 flags = 0, cnt = 0;  // bit k: position lane + 64 k goes
+        u64 row_ballot[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const u32 p = lane + 64u * k;
+            const u64 w1 = bits64((int)p - 63), w2 = bits64((int)p + 1);
+            bool go = false;
+            if (w1 && w2 && p < wend) {
+                const u32 h = p - (u32)__clzll((unsigned long long)w1);
+                const u32 e = p + (u32)__ffsll((unsigned long long)w2);
+                go = h < (u32)WR_A && e - h >= 2u && e - h <= 64u;
+            }
+            row_ballot[k] = __ballot(go);
+            flags |= (go ? 1u : 0u) << k;
         }
-        // Batches are kept as small as their first group allows: up to 64 slots go straight to the tail kernel (one suffix per lane,
-        // ~50 registers, dozens of waves per CU: measured four times the throughput per suffix of the wide path below), and only a
-        // group of more than 64 members takes the wide path, with as many lanes' worth of capacity as it needs.
-        const u32 size = nh - c;
-        const u32 room = size <= 64u ? 64u : size <= 128u ? 128u : size <= 256u ? 256u : 512u;
-        u32 e = wr_prev_head(lds.hb, c + room);  // >= nh: whole groups that fit beside it come along
-        if (headA != WR_FAR && e > headA) e = headA;  // groups headed at or beyond the next anchor are the next wave's
-        if (e > wend) e = wend;
-        const u32 L = e - c;
-        if (room == 64u) wr_hand_over(cx, lds, c, L);
-        else if (room == 128u) wr_batch<2>(cx, lds, c, L);
-        else if (room == 256u) wr_batch<4>(cx, lds, c, L);
-        else wr_batch<8>(cx, lds, c, L);
-        c = e;
+        u32 row_base[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            row_base[k] = cnt;
+            cnt += (u32)__popcll((unsigned long long)row_ballot[k]);
+        }
+        if (cnt) {
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&counters[4], cnt);
+            base = __shfl(base, 0);
+            if (base + cnt > tail_cap) {
+                if (lane == 0) {
+                    counters[3] = 1u;
+                    atomicMin(&counters[5], base);  // the list is valid up to the first append that did not fit
+                    atomicAdd(&counters[1], cnt);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; k++)
+                    if ((flags >> k) & 1u) {
+                        const u32 p = lane + 64u * k;
+                        const u32 d = base + row_base[k] + (u32)__popcll((unsigned long long)(row_ballot[k] & (((u64)1 << lane) - 1ull)));
+                        const u64 slot = a + p;
+                        tail_v[d] = (v[slot] & V_MASK) | (((lds.hb[p >> 5] >> (p & 31u)) & 1u) ? V_HEAD : 0u);
+                        tail_slot[d] = (u32)slot;
+                        tail_d[d] = 0;  // the tail kernel walks the windows the group was formed on
+                        tail_pb[d] = pb[slot];
+                    }
+            }
+        }
+    }
+    // ---- the slots before the first head continue a group headed before this window (tile > 0: slot 0 is always a head)
+    const u32 c0 = wr_next_head(lds.hb, 0u);
+    if (c0 > 0u) {
+        const u32 hp = carry[tile];
+        const bool big = c0 == WR_FAR || (u32)a + c0 - hp > (u32)WR_G;
+        const u32 stop = c0 < (u32)WR_A ? c0 : (u32)WR_A;
+        if (big) wr_emit_big(big_slot, big_hp, big_cap, counters, a, 0u, stop < wend ? stop : wend, hp);
+    }
+    // ---- groups of more than 64 headed here: the wide path (up to 512 members, 2 / 4 / 8 suffixes per lane), or the big list
+    for (u32 k = 0; k < 8u; k++) {
+        const u32 p = lane + 64u * k;
+        const bool head = (lds.hb[p >> 5] >> (p & 31u)) & 1u;
+        u64 large = __ballot(head && p < wend && bits64((int)p + 1) == 0ull);  // no other head within the next 64 slots
+        while (large) {
+            const u32 l = (u32)__ffsll((unsigned long long)large) - 1u;
+            large &= large - 1ull;
+            const u32 c = l + 64u * k;
+            const u32 nh = wr_next_head(lds.hb, c + 1u);  // end of the group
+            if (nh == WR_FAR || nh - c > (u32)WR_G) {     // too large for a wave
+                const u32 stop = nh < (u32)WR_A ? nh : (u32)WR_A;
+                wr_emit_big(big_slot, big_hp, big_cap, counters, a, c, stop < wend ? stop : wend, (u32)a + c);
+                continue;
+            }
+            const u32 L = (nh < wend ? nh : wend) - c;
+            if (L <= 128u) wr_batch<2>(cx, lds, c, L);
+            else if (L <= 256u) wr_batch<4>(cx, lds, c, L);
+            else wr_batch<8>(cx, lds, c, L);
+        }
     }
 }
 
@@ -1244,8 +1269,8 @@ static int bits_for(u64 x) {
 }
 
 size_t bwt_workspace_bytes(u64 n) {
-    // 2 keys (16) + 2 suffix arrays (8) + payload (1) + ISA (4) + 2 slot lists (8) + ranks (4) + tile words (4) + a third suffix list (4)
-    return n * (16 + 8 + 1 + 4 + 8 + 4 + 4 + 4) + radix_temp_bytes(n) + scan_temp_words(n) * 4 + (1u << 20) + 16384;
+    // 2 keys (16) + 2 suffix arrays (8) + payload (1) + tail list (11) + ISA (4) + 2 slot lists (8) + ranks (4) + tile words (4) + a third suffix list (4)
+    return n * (16 + 8 + 1 + 11 + 4 + 8 + 4 + 4 + 4) + radix_temp_bytes(n) + scan_temp_words(n) * 4 + (1u << 20) + 16384;
 }
 
 // full LSD sort of (keys, iota) over key bits [bit_lo, bit_hi): the first pass generates the values.  Returns the buffer index of the result.
@@ -1322,12 +1347,12 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     u64 * bkey[2] = {bkey0 + big_cap, bkey0 + 2 * (size_t)big_cap};    // 4 n, 6 n
     u64 * gkey = bkey0 + 3 * (size_t)big_cap;                          // 8 n: end of key[1]
     u8 * gpb = reinterpret_cast<u8 *>(val[cur ^ 1]);                   // the other suffix buffer is free as well
-    // the tail kernel's input (written by the resolve kernel, dead before the big round of the same pass starts): key[1] again
-    const u32 tail_cap = n / 4;
-    u32 * tail_v = reinterpret_cast<u32 *>(key[1]);
-    u32 * tail_slot = tail_v + tail_cap;
-    u16 * tail_d = reinterpret_cast<u16 *>(tail_slot + tail_cap);
-    u8 * tail_pb = reinterpret_cast<u8 *>(tail_d + tail_cap);
+    // the tail kernel's input: every suffix that shares a group of up to 64 may be in it
+    const u32 tail_cap = n;
+    u32 * tail_v = tmp.take<u32>(tail_cap);
+    u32 * tail_slot = tmp.take<u32>(tail_cap);
+    u16 * tail_d = tmp.take<u16>(tail_cap);
+    u8 * tail_pb = tmp.take<u8>(tail_cap);
     u32 g = 7;            // symbols every group is known to share at least (7 per 56-bit window)
     bool deep = false;    // fall back to rank doubling
     u32 h_words[8];

@@ -101,6 +101,7 @@ BZIP3_API int32_t bz3_hip_stage_lzp_encode(const uint8_t * in, int32_t n, uint8_
 BZIP3_API int32_t bz3_hip_stage_lzp_decode(const uint8_t * in, int32_t n, uint8_t * out, int32_t max); /* lzp_decompress */
 BZIP3_API int32_t bz3_hip_stage_bwt(const uint8_t * in, uint8_t * out, int32_t n);                  /* libsais_bwt     */
 BZIP3_API int32_t bz3_hip_stage_unbwt(const uint8_t * in, uint8_t * out, int32_t n, int32_t idx);   /* libsais_unbwt   */
+BZIP3_API float bz3_hip_stage_last_ms(void); /* wall ms of the transform inside the last bz3_hip_stage_bwt / _unbwt call (allocations and PCIe copies excluded) */
 BZIP3_API int32_t bz3_hip_stage_cm_encode(const uint8_t * in, int32_t n, uint8_t * out);            /* encode_bytes    */
 BZIP3_API void bz3_hip_stage_cm_decode(const uint8_t * in, int32_t in_size, uint8_t * out, int32_t n); /* decode_bytes  */
 

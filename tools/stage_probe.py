@@ -22,15 +22,15 @@ def main():
         t = time.time(); rle = g.mrle_encode(d); t_rle = time.time() - t
         t = time.time(); nl, lz = g.lzp_encode(d); t_lzp = time.time() - t
         src = lz if nl > 0 else d
-        t = time.time(); idx, u = g.bwt(src); t_bwt = time.time() - t
-        t = time.time(); rc, back = g.unbwt(u, idx); t_unbwt = time.time() - t
+        t = time.time(); idx, u = g.bwt(src); t_bwt = time.time() - t; ms_bwt = g.lib.bz3_hip_stage_last_ms()
+        t = time.time(); rc, back = g.unbwt(u, idx); t_unbwt = time.time() - t; ms_unbwt = g.lib.bz3_hip_stage_last_ms()
         assert rc == 0 and back == src
         t_unlzp = 0.0
         if nl > 0:
             t = time.time(); k, back2 = g.lzp_decode(lz, n + 100); t_unlzp = time.time() - t
             assert k == n and back2 == d
         print(f"[{mib:g} MiB rep{rep}] crc {t_crc*1e3:.0f} ms  rle {t_rle*1e3:.0f} ms (-> {len(rle)})  lzp {t_lzp*1e3:.0f} ms (-> {nl})  "
-              f"bwt {t_bwt*1e3:.0f} ms  unbwt {t_unbwt*1e3:.0f} ms  unlzp {t_unlzp*1e3:.0f} ms   [hook times include ~{n/25e9*2e3:.0f} ms of PCIe copies]")
+              f"bwt {t_bwt*1e3:.0f} ms (transform alone {ms_bwt:.1f})  unbwt {t_unbwt*1e3:.0f} ms (transform alone {ms_unbwt:.1f})  unlzp {t_unlzp*1e3:.0f} ms   [hook times include ~{n/25e9*2e3:.0f} ms of PCIe copies]")
         sys.stdout.flush()
 
 
