@@ -10,18 +10,27 @@ input bytes of all ranks / 2^20 / (t_encode + t_decode).
 
 Wall budget.  One step over a GPU-filling batch of 256 MiB blocks takes minutes (the CM coder is a serial
 recurrence per block), so the requested --steps / --warmup are CLAMPED to what fits the wall budget
-(--budget-s, default 1300 s of the driver's 1800 s): at least one timed step always runs; a warmup step is
+(--budget-s, default 1500 s of the driver's 1800 s): at least one timed step always runs; a warmup step is
 only spent when a second step still fits.  The JSON line carries the steps / warmup actually run and the
 requested ones.  A watchdog thread prints the line with whatever has been measured so far if the hard
 deadline (--deadline-s) is reached while an optional extra leg is still running.
 
+Two timed steps when the budget allows (both reported, with their spread; the first includes the first-call effects:
+workspace allocation).  "cpu_baseline": the REAL reference (oracle/_ref) through its own bz3_encode_blocks /
+bz3_decode_blocks on min(cores, 64) host threads x 256 MiB blocks -- the same blocks the GPU coded, and the reference's
+coded bytes are compared with the GPU's (bit-exact parity at the metric's block size).  It runs on the host WHILE the GPU
+runs its second timed step (a step is one blocking C call that leaves the host's cores idle).  64 threads because the
+reference's own CLI caps -j at 64 (src/main.c:213) and its batch API is documented for 2-16 blocks (libbz3.h:202).
+
 Extra legs after the timed region (rank 0, N=1 only, each only while the budget lasts), all in "configs":
-  cfg3      BASELINE.json configs[2]: 1,000,000,000 B of text at -b 256 = 4 blocks on one GPU, with the
-            reference's -j 4 path timed on the host beside it;
-  random    incompressible blocks (LZP and RLE decline, the coder emits ~1 byte per byte).
-and "cpu_baseline": the REAL reference (oracle/_ref/libbz3ref.so) through its own bz3_encode_blocks /
-bz3_decode_blocks on min(cores, 64) host threads x 256 MiB blocks -- the same blocks the GPU coded, and the
-reference's coded bytes are compared with the GPU's (bit-exact parity at the metric's block size).
+  cfg3        BASELINE.json configs[2]: 1,000,000,000 B of text at -b 256 = 4 blocks on one GPU, with the
+              reference's -j 4 path timed on the host beside it;
+  cfg2        BASELINE.json configs[1]: 100,000,000 B at -b 32 = 3 blocks, with -j 3 beside it;
+  cfg5_unbwt  BASELINE.json configs[4]'s stage: the inverse BWT of one 511 MiB block (the maximum block size) of a
+              skewed order-1 Markov source over 16 symbols, GB/s against the stage's 11 B per byte;
+  mixed       text, binary and incompressible blocks in ONE batch (the single CM launch lasts as long as its slowest
+              block, and blocks the row-cache kernels give up are coded again: cm_blocks_given_up is reported);
+  random      incompressible blocks (LZP and RLE decline, the coder emits ~1 byte per byte).
 
 Multi-GPU: blocks are independent, so each rank owns `--blocks` blocks on its own GPU (weak
 scaling), there is NO data-path collective; torch.distributed (RCCL) is used only for the barrier and the
@@ -73,7 +82,7 @@ def parse():
                          "rows / rows3 / lock2 / lock3 = row-cache kernels, two / three blocks per CU")
     ap.add_argument("--lean", type=int, default=int(os.environ.get("BZ3_BENCH_LEAN", "-1")),
                     help="lean states (bz3_hip_set_lean_states): 1 = no per-state swap buffer, in-place CM encode (room for 3x256 blocks of 256 MiB); -1 = by block count")
-    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("BZ3_BENCH_BUDGET_S", "1300")),
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("BZ3_BENCH_BUDGET_S", "1500")),
                     help="wall budget from process start: steps/warmup are clamped and the extra legs skipped so that the run ends before it")
     ap.add_argument("--deadline-s", type=float, default=float(os.environ.get("BZ3_BENCH_DEADLINE_S", "1690")),
                     help="hard deadline: the watchdog prints the JSON line as measured so far and exits")
@@ -262,13 +271,54 @@ def host_mem_available():
     return 8 << 30
 
 
-def reference_round_trip(sample_blocks, block_size, keep_encoded=False):
+REF_VARIANTS = (("gcc -O2", "libbz3ref.so"), ("gcc -O2 -march=x86-64-v3", "libbz3ref_v3.so"), ("clang -O3 -march=x86-64-v3", "libbz3ref_clang.so"))
+
+
+def fastest_reference(sample):
+    """(label, path, probe record) of the reference build that round-trips an 8 MiB sample fastest on ONE thread of this host.
+    SURVEY.md 8d asks for gcc -O2 and clang -O3 with -march=native; the reference tree is not on the GPU box, so the variants are
+    compiled in the build container (oracle/Makefile) for x86-64-v3, the closest level both machines run."""
+    from oracle_lib import ORACLE_DIR, Bz3, RefLib
+
+    flags = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("flags"):
+                    flags = ln
+                    break
+    except OSError:
+        pass
+    v3_ok = all(f" {x}" in flags for x in ("avx2", "bmi2", "fma"))
+    probe, best = {}, None
+    for label, name in REF_VARIANTS:
+        path = os.path.join(ORACLE_DIR, "_ref", name)
+        if not os.path.exists(path) or ("v3" in label and not v3_ok):
+            continue
+        r = RefLib(path)
+        if not r.available:
+            continue
+        b = Bz3(r.lib)
+        bs = max(len(sample), 65 * 1024)
+        t0 = time.perf_counter()
+        n_enc, err, blk = b.encode_block(sample, bs)
+        k, err2, back = b.decode_block(blk, len(sample), bs)
+        dt = time.perf_counter() - t0
+        if err or err2 or back != sample:
+            continue
+        probe[label] = round(len(sample) / 2 ** 20 / dt, 3)
+        if best is None or dt < best[2]:
+            best = (label, path, dt)
+    return (best[0], best[1], probe) if best else (None, None, probe)
+
+
+def reference_round_trip(sample_blocks, block_size, keep_encoded=False, lib_path=None, label="gcc -O2"):
     """The REAL reference (oracle/_ref/libbz3ref.so, kind 'reference') through its own batch API, one pthread per block
     (src/libbz3.c:845-870), on this host.  Returns (record, encoded blocks or None).  Falls back to the plain-C oracle
     (kind 'port', 1 core, 4 MiB) only if oracle/_ref did not travel."""
     from oracle_lib import Oracle, RefLib
 
-    ref = RefLib()
+    ref = RefLib(lib_path)
     n = len(sample_blocks)
     total = sum(len(b) for b in sample_blocks)
     model, ncpu = cpu_info()
@@ -301,7 +351,7 @@ def reference_round_trip(sample_blocks, block_size, keep_encoded=False):
         t_enc, t_dec = t1 - t0, t2 - t1b
         rec = {"value": round(total / 2 ** 20 / (t_enc + t_dec), 3), "unit": "MiB/s", "cores": n, "kind": "reference",
                "sample": f"{n} x {len(sample_blocks[0]) / 2 ** 20:.0f} MiB blocks (the GPU's blocks 0..{n - 1}), one pass of bz3_encode_blocks + "
-                         f"bz3_decode_blocks of the gcc -O2 reference, one thread per block",
+                         f"bz3_decode_blocks of the {label} reference, one thread per block",
                "t_enc_s": round(t_enc, 2), "t_dec_s": round(t_dec, 2), "host_cpu": model, "host_cores": ncpu}
         return rec, enc
     o = Oracle()
@@ -436,7 +486,7 @@ def main():
             stage["bwt"] = {"rounds": r.value, "radix_passes": p.value, "sorted_elements": e.value}
             ring = lib.bz3_hip_debug_front_end_ring()  # the encoder's front-end pipeline: context slots x blocks per window
             stage["front_end_ring"] = {"slots": (ring >> 16) & 0xFF, "window": ring & 0xFFFF, "workspace_handed_back": bool(ring >> 30)}
-            if cpu_block == block_size and not coded_kept:  # a few ms of device-to-device copies inside the timed region, first recorded step only
+            if cpu_block == block_size and not coded_kept and not step_s:  # a few ms of device-to-device copies inside the timed region, first step only
                 for i in range(cpu_n):
                     coded_kept.append(bufs[i][: sizes[i]].clone())
         t2 = time.perf_counter()
@@ -454,32 +504,22 @@ def main():
 
     # ---- steps under the wall budget ---------------------------------------------------------------------------------
     extras_wanted = rank == 0 and world == 1 and not a.no_extras
-    reserve = (240.0 if want_cpu else 0.0) + (360.0 if extras_wanted else 0.0) + 30.0  # cpu_baseline, cfg3 + random, verification
+    reserve = (40.0 if want_cpu else 0.0) + (420.0 if extras_wanted else 0.0) + 30.0  # host copies, extra legs, verification
+    step_s = []
     barrier()
     t0 = time.perf_counter()
     one_step(record=True)
     barrier()
-    t_first = max_over_ranks(time.perf_counter() - t0)
-    left = agree(a.budget_s - elapsed()) - reserve
-    warmup_run, more = plan_steps(left, t_first, a.steps, a.warmup)
-    steps_run, timed = (0, 0.0) if warmup_run else (1, t_first)  # with a warmup the step just run does not count
-    for _ in range(max(0, warmup_run - 1)):
-        one_step()
-    if more:
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(more):
-            one_step(record=(k == more - 1))
-        barrier()
-        timed += max_over_ranks(time.perf_counter() - t0)
-        steps_run += more
-    progress(f"timed {steps_run} step(s) in {timed:.1f}s after {warmup_run} warmup step(s) (requested {a.steps} / {a.warmup}; budget {a.budget_s:.0f}s)")
+    step_s.append(max_over_ranks(time.perf_counter() - t0))
 
-    # ---- the round trip must be the identity (decode is in place: the buffers hold the plaintext again) ----
-    for k in range(nblk):
-        assert fingerprint(torch, bufs[k][:block_size]) == prints[k], f"block {k}: round trip changed the data"
-    for k in range(n_keep):
-        assert torch.equal(bufs[k][:block_size], kept[k]), f"block {k}: round trip changed the data"
+    def verify_round_trip():
+        # the round trip must be the identity (decode is in place: the buffers hold the plaintext again)
+        for k in range(nblk):
+            assert fingerprint(torch, bufs[k][:block_size]) == prints[k], f"block {k}: round trip changed the data"
+        for k in range(n_keep):
+            assert torch.equal(bufs[k][:block_size], kept[k]), f"block {k}: round trip changed the data"
+
+    verify_round_trip()
     # host copies for the reference legs: plaintext of blocks 0..cpu_n-1 (verified above) and the GPU's coded bytes of the same blocks
     host_plain, host_coded = [], []
     if want_cpu:
@@ -487,6 +527,44 @@ def main():
                      [bufs[0][:cpu_block].cpu().numpy()] * cpu_n
         host_coded = [c.cpu().numpy().tobytes() for c in coded_kept]
         coded_kept.clear()
+        progress(f"host copies of {cpu_n} blocks for the reference legs")
+    ref_choice = {"label": "gcc -O2", "path": None, "probe": {}}
+    cpu_result = {}
+    cpu_need = 2.6 * cpu_block / (4.5 * (1 << 20)) if want_cpu else 0.0  # ~4.5 MiB/s per thread and direction at 256 MiB blocks (BASELINE.md), with margin
+
+    def cpu_baseline_leg():
+        """The reference on the host's cores -- runs in a thread of its own while the GPU does its second timed step."""
+        try:
+            label, path, probe = fastest_reference(host_plain[0][: 8 << 20].tobytes())
+            if label is not None:
+                ref_choice.update(label=label, path=path, probe=probe)
+            progress(f"cpu_baseline: {cpu_n} threads x {cpu_block >> 20} MiB blocks, {ref_choice['label']} (one-thread probe, MiB/s: {probe}; estimated {cpu_need:.0f}s)")
+            rec, enc = reference_round_trip(host_plain, max(cpu_block, 65 * 1024), keep_encoded=bool(host_coded), lib_path=ref_choice["path"], label=ref_choice["label"])
+            rec["build_probe_1_thread_8MiB_MiBps"] = probe
+            rec["threads_note"] = "64 threads: the reference's CLI caps -j at 64 (src/main.c:213); one thread per block as in bz3_encode_blocks (src/libbz3.c:845-856)"
+            if enc is not None and host_coded:
+                same = sum(1 for x, y in zip(enc, host_coded) if x == y)
+                rec["parity"] = f"{same} of {len(enc)} blocks of {cpu_block >> 20} MiB: the GPU's coded bytes are identical to the reference's"
+                cpu_result["parity_ok"] = same == len(enc)
+            cpu_result["rec"] = rec
+        except Exception as e:  # the baseline is reported, never required
+            cpu_result["err"] = str(e)
+
+    left = agree(a.budget_s - elapsed()) - reserve
+    second = (a.steps >= 2 or a.warmup > 0) and left > step_s[0] * 1.03
+    cpu_thread = None
+    if want_cpu and a.deadline_s - 20.0 - elapsed() > cpu_need:
+        cpu_thread = threading.Thread(target=cpu_baseline_leg)
+        cpu_thread.start()
+    if second:
+        barrier()
+        t0 = time.perf_counter()
+        one_step(record=True)
+        barrier()
+        step_s.append(max_over_ranks(time.perf_counter() - t0))
+        verify_round_trip()
+    steps_run, timed, warmup_run = len(step_s), sum(step_s), 0
+    progress(f"timed {steps_run} step(s): {[round(x, 1) for x in step_s]} s (requested {a.steps} / {a.warmup}; budget {a.budget_s:.0f}s)")
 
     total_bytes = world * nblk * block_size
     value = total_bytes * steps_run / 2 ** 20 / timed
@@ -539,13 +617,16 @@ def main():
             "steps": steps_run,
             "warmup": warmup_run,
             "ms_per_step": round(timed / steps_run * 1e3, 1),
+            "step_s": [round(x, 2) for x in step_s],
+            "step_spread": round((max(step_s) - min(step_s)) / (timed / steps_run), 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "requested": {"steps": a.steps, "warmup": a.warmup, "budget_s": a.budget_s,
-                          "note": "steps/warmup clamped to the wall budget: one step codes and decodes a GPU-filling batch of 256 MiB blocks"},
+                          "note": "steps/warmup clamped to the wall budget: one step codes and decodes a GPU-filling batch of 256 MiB blocks; both steps are timed, "
+                                  "the first one includes the first-call effects (workspace allocation)"},
             "config": {
                 "workload": f"{nblk} x {a.block_mib:g} MiB synthetic enwik-style {a.kind} blocks per GPU (word-bigram Markov over shakespeare.txt tokens; "
                             f"blocks 2.. are 64 KiB-piece permutations of block 1), resident in HBM, "
@@ -614,82 +695,167 @@ def main():
         assert all(lib.bz3_last_error(S[i]) == 0 for i in range(n)), "decode failed"
         return t1 - t0, t2 - t1, coded
 
-    cpu_need = 2.6 * cpu_block / (4.5 * (1 << 20)) if want_cpu else 0.0  # ~4.5 MiB/s per thread and direction at 256 MiB blocks (BASELINE.md), with margin
+    # ---- cpu_baseline: started before the second step, collected here
+    if want_cpu:
+        if cpu_thread is not None:
+            cpu_thread.join()
+        if "rec" in cpu_result:
+            rec = cpu_result["rec"]
+            rec["gpu_over_cpu"] = round(RESULT["line"]["value"] / rec["value"], 3) if rec.get("value") else None
+            rec["timed_while"] = "the GPU ran its second timed step" if second else "the GPU was idle"
+            RESULT["line"]["cpu_baseline"] = rec
+            progress(f"cpu_baseline: {rec['value']} MiB/s on {rec['cores']} threads ({ref_choice['label']}); {rec.get('parity', '')}")
+            assert cpu_result.get("parity_ok", True), "GPU output differs from the reference: " + rec.get("parity", "")
+        else:
+            why = cpu_result.get("err", f"needs ~{cpu_need:.0f}s, {a.deadline_s - elapsed():.0f}s to the deadline")
+            RESULT["line"]["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": f"not run: {why}"}
+
+    def ref_beside(blocks, bs, tag):
+        """the reference's -j N on the same blocks, on the host, in a thread of its own while the GPU codes them"""
+        box = {}
+
+        def run():
+            try:
+                box["rec"], _ = reference_round_trip(blocks, bs, lib_path=ref_choice["path"], label=ref_choice["label"])
+            except Exception as e:
+                box["err"] = str(e)
+
+        th = threading.Thread(target=run)
+        th.start()
+        return th, box
+
+    def small_config(name, total_bytes_, bs, what):
+        """BASELINE configs of a few blocks: `total_bytes_` of the batch's text at block size bs on one GPU, the reference's -j N beside it."""
+        nb = (total_bytes_ + bs - 1) // bs
+        sizes_ = [bs] * (nb - 1) + [total_bytes_ - (nb - 1) * bs]
+        sel = list(range(nb))
+        fp = [fingerprint(torch, bufs[k][: sizes_[k]]) for k in sel]
+        th, box = (None, {})
+        if want_cpu and cpu_n >= nb and cpu_block == block_size:
+            th, box = ref_beside([host_plain[k][: sizes_[k]] for k in sel], max(bs, 65 * 1024), name)
+        te, td, coded = round_trip(sel, sizes_)
+        assert all(fingerprint(torch, bufs[k][: sizes_[k]]) == fp[k] for k in sel), f"{name}: round trip changed the data"
+        rec = {"workload": f"{what}: {total_bytes_} B of synthetic text, -b {bs / 2 ** 20:g} -> {nb} blocks ({nb - 1} x {bs} + {sizes_[-1]}) on one GPU",
+               "value": round(total_bytes_ / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
+               "compressed_ratio": round(total_bytes_ / sum(coded), 3)}
+        RESULT["line"]["configs"][name] = rec
+        progress(f"{name}: {rec['value']} MiB/s (enc {te:.1f}s dec {td:.1f}s)")
+        if th is not None:
+            th.join()
+            if "rec" in box:
+                r = box["rec"]
+                r["sample"] = f"reference -j {nb} ({ref_choice['label']}): bz3_encode_blocks + bz3_decode_blocks on the same {nb} blocks, {nb} host threads, timed while the GPU coded them"
+                rec[f"cpu_j{nb}"] = r
+                rec[f"vs_cpu_j{nb}"] = round(rec["value"] / r["value"], 3)
+                progress(f"{name}: reference -j {nb} on the host: {r['value']} MiB/s")
+            else:
+                rec[f"cpu_j{nb}"] = {"value": None, "sample": "failed: " + box.get("err", "?")}
 
     n3 = (a.cfg3_bytes + block_size - 1) // block_size  # blocks of the cfg3 leg: full blocks + one partial
     if extras_wanted and a.kind == "text" and nblk >= n3:
         # cfg3 (BASELINE.json configs[2]): 1,000,000,000 B at -b 256 = 3 full blocks + 194,693,632 B, on one GPU
         cm_s = (stage["enc"]["cm"] + stage["dec"]["cm"]) * 1e-3
         est = cm_s * (1.0 if per_cu == 1 else 0.7) + 15.0
-        if left_s() - cpu_need > est:
+        if left_s() > est:
             progress(f"cfg3: {n3} blocks (estimated {est:.0f}s)")
-            sizes3 = [block_size] * (n3 - 1) + [a.cfg3_bytes - (n3 - 1) * block_size]
-            sel3 = list(range(n3))
-            fp3 = [fingerprint(torch, bufs[k][: sizes3[k]]) for k in sel3]
-            host_j4 = {}
-            th = None
-            if want_cpu and cpu_n >= n3 and cpu_block == block_size:
-                blocks3 = [host_plain[k][: sizes3[k]] for k in sel3]
-
-                def ref_j4():  # the reference's -j N on the same blocks, on the host, while the GPU codes them
-                    try:
-                        host_j4["rec"], _ = reference_round_trip(blocks3, block_size)
-                    except Exception as e:
-                        host_j4["err"] = str(e)
-
-                th = threading.Thread(target=ref_j4)
-                th.start()
-            te, td, coded = round_trip(sel3, sizes3)
-            assert all(fingerprint(torch, bufs[k][: sizes3[k]]) == fp3[k] for k in sel3), "cfg3: round trip changed the data"
             is_cfg3 = a.cfg3_bytes == CFG3_BYTES and block_size == 256 << 20
-            rec = {"workload": ("BASELINE.json configs[2] stand-in: " if is_cfg3 else "(not BASELINE's size) ") +
-                               f"{a.cfg3_bytes} B of synthetic text, -b {a.block_mib:g} -> {n3} blocks ({n3 - 1} x {block_size} + {sizes3[-1]}) on one GPU",
-                   "value": round(a.cfg3_bytes / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
-                   "compressed_ratio": round(a.cfg3_bytes / sum(coded), 3)}
-            RESULT["line"]["configs"]["cfg3"] = rec
-            progress(f"cfg3: {rec['value']} MiB/s (enc {te:.1f}s dec {td:.1f}s)")
-            if th is not None:
-                th.join()
-                if "rec" in host_j4:
-                    r = host_j4["rec"]
-                    r["sample"] = f"reference -j {n3}: bz3_encode_blocks + bz3_decode_blocks on the same {n3} blocks, {n3} host threads, timed while the GPU coded them"
-                    rec["cpu_j4"] = r
-                    rec["vs_cpu_j4"] = round(rec["value"] / r["value"], 3)
-                    progress(f"cfg3: reference -j {n3} on the host: {r['value']} MiB/s")
-                else:
-                    rec["cpu_j4"] = {"value": None, "sample": "failed: " + host_j4.get("err", "?")}
+            small_config("cfg3", a.cfg3_bytes, block_size, "BASELINE.json configs[2] stand-in" if is_cfg3 else "(not BASELINE's size)")
         else:
             RESULT["line"]["configs"]["cfg3"] = {"skipped": f"needs ~{est:.0f}s, {left_s():.0f}s of the budget left"}
+    if extras_wanted and a.kind == "text" and block_size >= (32 << 20) and nblk >= 3:
+        # cfg2 (BASELINE.json configs[1]): 100,000,000 B at -b 32 = 2 full blocks + 32,891,136 B
+        if left_s() > 60.0:
+            small_config("cfg2", 100_000_000, 32 << 20, "BASELINE.json configs[1] stand-in")
+        else:
+            RESULT["line"]["configs"]["cfg2"] = {"skipped": f"{left_s():.0f}s of the budget left"}
+    host_plain, host_coded = [], []
 
-    if want_cpu:
+    if extras_wanted and a.kind == "text" and nblk > 160 and left_s() > 60.0:
+        # ---- room for the legs below: most of the batch's buffers and the big workspace are not needed any more
+        keep_n = 160
+        for s_ in states[keep_n:]:
+            lib.bz3_free(s_)
+        live_states = keep_n
+        del bufs[keep_n:]
+        lib.bz3_hip_release_cached_memory()
+        torch.cuda.empty_cache()
+    else:
+        live_states = nblk
+
+    if extras_wanted and a.kind == "text" and left_s() > 60.0:
+        # cfg5's stage (BASELINE.json configs[4]: "-b 511 max block ... decode-path unBWT throughput"): the inverse BWT of one block of the
+        # maximum size.  Verbatim long repeats would be collapsed by LZP (SURVEY.md 8d), so the source is a skewed order-1 Markov chain
+        # over 16 symbols (repeat units < 40 B: LZP / RLE decline, the BWT stage sees all n bytes).
         try:
-            if a.deadline_s - 20.0 - elapsed() < cpu_need:
-                raise RuntimeError(f"needs ~{cpu_need:.0f}s, {a.deadline_s - elapsed():.0f}s to the deadline")
-            progress(f"cpu_baseline: {cpu_n} threads x {cpu_block >> 20} MiB blocks (estimated {cpu_need:.0f}s)")
-            rec, enc = reference_round_trip(host_plain, max(cpu_block, 65 * 1024), keep_encoded=bool(host_coded))
-            if enc is not None and host_coded:
-                same = sum(1 for x, y in zip(enc, host_coded) if x == y)
-                rec["parity"] = f"{same} of {len(enc)} blocks of {cpu_block >> 20} MiB: the GPU's coded bytes are identical to the reference's"
-                assert same == len(enc), "GPU output differs from the reference: " + rec["parity"]
-            rec["gpu_over_cpu"] = round(RESULT["line"]["value"] / rec["value"], 3) if rec.get("value") else None
-            RESULT["line"]["cpu_baseline"] = rec
-            progress(f"cpu_baseline: {rec['value']} MiB/s on {rec['cores']} threads; {rec.get('parity', '')}")
-        except AssertionError:
-            raise
-        except Exception as e:  # the baseline is reported, never required
-            RESULT["line"]["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": f"not run: {e}"}
-        host_plain, host_coded = [], []
+            n5 = 511 << 20
+            g = torch.Generator(device=device)
+            g.manual_seed(5)
+            chains = 1 << 16
+            steps5 = (n5 + chains - 1) // chains
+            probs = 1.0 / torch.arange(1, 17, device=device, dtype=torch.float64) ** 1.6
+            rows = torch.stack([probs[torch.randperm(16, generator=g, device=device)] for _ in range(16)])
+            cdf = torch.cumsum(rows / rows.sum(1, keepdim=True), 1).to(torch.float32)
+            state5 = torch.randint(0, 16, (chains,), generator=g, device=device)
+            out5 = torch.empty((steps5, chains), dtype=torch.uint8, device=device)
+            for t_ in range(steps5):
+                r = torch.rand((chains,), generator=g, device=device)
+                state5 = (cdf[state5] < r[:, None]).sum(1).clamp_(max=15)
+                out5[t_] = (state5 + 97).to(torch.uint8)
+            src5 = out5.t().reshape(-1)[:n5].contiguous().cpu().numpy().tobytes()
+            del out5
+            torch.cuda.empty_cache()
+            gs = bzip3_amd.StageApi(lib)
+            idx5, u5 = gs.bwt(src5)
+            ms_fwd = float(lib.bz3_hip_stage_last_ms())
+            rc5, back5 = gs.unbwt(u5, idx5)
+            ms_inv = float(lib.bz3_hip_stage_last_ms())
+            assert rc5 == 0 and back5 == src5, "cfg5_unbwt: the inverse BWT did not return the block"
+            RESULT["line"]["configs"]["cfg5_unbwt"] = {
+                "workload": "BASELINE.json configs[4]'s stage on one GPU: inverse BWT of ONE 511 MiB block (535,822,336 B, the maximum block size) of a skewed "
+                            "order-1 Markov source over 16 symbols (bz3_hip_stage_unbwt; transform alone, PCIe copies of the hook excluded)",
+                "value": round(ALG_BYTES_BWT * n5 / (ms_inv * 1e-3) / 1e9, 3), "unit": "GB/s (11 algorithmic bytes per byte, SURVEY.md 8d)",
+                "ms": round(ms_inv, 2), "MiBps": round(511.0 / (ms_inv * 1e-3), 1), "frac_of_hbm_peak": round(ALG_BYTES_BWT * n5 / (ms_inv * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                "forward_bwt_ms": round(ms_fwd, 2), "forward_bwt_GBps": round(ALG_BYTES_BWT * n5 / (ms_fwd * 1e-3) / 1e9, 3)}
+            progress(f"cfg5_unbwt: inverse BWT of a 511 MiB block in {ms_inv:.1f} ms (forward {ms_fwd:.1f} ms)")
+            del src5, u5, back5
+            lib.bz3_hip_release_cached_memory()
+        except Exception as e:
+            RESULT["line"]["configs"]["cfg5_unbwt"] = {"skipped": f"failed: {e}"}
+
+    if extras_wanted and a.kind == "text" and live_states >= 96 and block_size >= (32 << 20) and left_s() > 100.0:
+        # mixed batch: text, binary and incompressible blocks through ONE pair of batch calls
+        mb = 32 << 20
+        per = 32
+        g = torch.Generator(device=device)
+        g.manual_seed(7)
+        sel = list(range(3 * per))
+        for j in range(per):  # blocks 0..31 keep their text; 32..63 binary (little-endian words of a random walk); 64..95 random
+            k = per + j
+            walk = torch.cumsum(torch.randint(-3, 4, (mb // 4,), generator=g, device=device, dtype=torch.int32), 0).to(torch.int32)
+            bufs[k][:mb] = walk.view(torch.uint8)
+            bufs[2 * per + j][:mb] = torch.randint(0, 256, (mb,), dtype=torch.uint8, generator=g, device=device)
+        fpm = [fingerprint(torch, bufs[k][:mb]) for k in sel]
+        before = int(lib.bz3_hip_cm_blocks_given_up())
+        te, td, coded = round_trip(sel, [mb] * len(sel))
+        assert all(fingerprint(torch, bufs[k][:mb]) == f for k, f in zip(sel, fpm)), "mixed: round trip changed the data"
+        RESULT["line"]["configs"]["mixed"] = {
+            "workload": f"{3 * per} x 32 MiB blocks in one batch on one GPU: {per} text, {per} binary (32-bit words of a random walk), {per} uniformly random",
+            "value": round(len(sel) * mb / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
+            "compressed_ratio": {"text": round(per * mb / sum(coded[:per]), 3), "binary": round(per * mb / sum(coded[per : 2 * per]), 3),
+                                 "random": round(per * mb / sum(coded[2 * per :]), 4)},
+            "cm_blocks_given_up": int(lib.bz3_hip_cm_blocks_given_up()) - before}
+        progress(f"mixed: {RESULT['line']['configs']['mixed']['value']} MiB/s, {RESULT['line']['configs']['mixed']['cm_blocks_given_up']} blocks given up by the row-cache kernels")
 
     if extras_wanted and a.kind == "text":
         # incompressible blocks: LZP and RLE decline (model 0), the coder emits ~1.004 bytes per byte
         rb = int(a.random_block_mib * (1 << 20))
-        nr = max(1, min(a.random_blocks, nblk, cus))
+        nr = max(1, min(a.random_blocks, live_states, cus))
         if rb <= block_size and left_s() > 90.0:
             progress(f"random: {nr} x {a.random_block_mib:g} MiB")
             g = torch.Generator(device=device)
             g.manual_seed(2)
             fpr = []
-            rsel = list(range(nblk - nr, nblk))  # the last blocks of the batch (their text is not needed any more)
+            rsel = list(range(live_states - nr, live_states))  # the last blocks still alive (their text is not needed any more)
             for k in rsel:
                 bufs[k][:rb] = torch.randint(0, 256, (rb,), dtype=torch.uint8, generator=g, device=device)
                 fpr.append(fingerprint(torch, bufs[k][:rb]))
@@ -705,7 +871,7 @@ def main():
 
     if rank == 0:
         emit_line(final=True)
-    for s in states:
+    for s in states[: (live_states if rank == 0 and world == 1 and not a.no_extras else nblk)]:
         lib.bz3_free(s)
     if world > 1:
         dist.barrier()

@@ -292,42 +292,57 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bwt_reduce_heads(const u32 * __res
     if (threadIdx.x == 0) tile_last[blockIdx.x] = hp;
 }
 
-// One workgroup: carry[t] = slot of the last head before tile t (tile 0: 0, never used: slot 0 is a head).
-constexpr int SP_BLOCK = 1024;
-__global__ void __launch_bounds__(SP_BLOCK) k_bwt_spine_max(const u32 * __restrict__ tile_last, u32 tiles, u32 * __restrict__ carry) {
-    __shared__ u32 lds[SP_BLOCK / WAVE + 1];
-    // a thread owns `per` consecutive tiles and walks them eight at a time, the loads of a batch in flight together (500 tiles per
-    // thread at 256 MiB: one exposed round trip per tile made this kernel as slow as a radix pass)
-    const u32 per = (((tiles + SP_BLOCK - 1) / SP_BLOCK) + 7u) & ~7u;
-    const u32 t0 = threadIdx.x * per, t1 = t0 + per < tiles ? t0 + per : tiles;
-    u32 hp = 0;
-    for (u32 t = t0; t < t1; t += 8) {
-        u32 h[8];
-#pragma unroll
-        for (u32 k = 0; k < 8; k++) h[k] = tile_last[t + k < t1 ? t + k : t1 - 1u];
-#pragma unroll
-        for (u32 k = 0; k < 8; k++)
-            if (t + k < t1) hp = h[k] > hp ? h[k] : hp;
-    }
-    // exclusive running maximum over the threads
-    const u32 incl = wave_incl_max(hp);
+// carry of tile t = 1 + slot of the last head before the tile = max(carry_local[t], group_carry[t / SP_GROUP]) (0: none):
+//   k_bwt_spine_a : one workgroup per SP_GROUP tiles, exclusive running maximum inside the group + the group's maximum
+//   k_bwt_spine_b : one workgroup, exclusive running maximum over the groups (at most ~1000 of them)
+// (one workgroup over all 520 k tiles of a 256 MiB block took as long as a radix pass)
+constexpr int SP_BLOCK = 256;
+constexpr int SP_PER = 4;
+constexpr int SP_GROUP = SP_BLOCK * SP_PER;
+template <int BLOCK>
+__device__ __forceinline__ u32 sp_block_excl_max(u32 v, u32 * lds, u32 & all) {  // lds: BLOCK / 64 + 1 words; ends with a barrier
+    const u32 incl = wave_incl_max(v);
     if (lane_id() == WAVE - 1) lds[wave_id()] = incl;
     u32 up = __shfl_up(incl, 1u);
     if (lane_id() == 0) up = 0u;
     __syncthreads();
-    u32 run = 0;
-    for (int w = 0; w < wave_id(); w++) run = lds[w] > run ? lds[w] : run;
-    run = up > run ? up : run;
-    for (u32 t = t0; t < t1; t += 8) {
-        u32 h[8];
+    u32 carry = 0, tot = 0;
+    for (int w = 0; w < BLOCK / WAVE; w++) {
+        if (w < wave_id()) carry = lds[w] > carry ? lds[w] : carry;
+        tot = lds[w] > tot ? lds[w] : tot;
+    }
+    __syncthreads();
+    all = tot;
+    return up > carry ? up : carry;
+}
+__global__ void __launch_bounds__(SP_BLOCK) k_bwt_spine_a(const u32 * __restrict__ tile_last, u32 tiles, u32 * __restrict__ carry_local, u32 * __restrict__ group_max) {
+    __shared__ u32 lds[SP_BLOCK / WAVE + 1];
+    const u32 t0 = blockIdx.x * SP_GROUP + threadIdx.x * SP_PER;
+    u32 h[SP_PER];
 #pragma unroll
-        for (u32 k = 0; k < 8; k++) h[k] = tile_last[t + k < t1 ? t + k : t1 - 1u];
+    for (int k = 0; k < SP_PER; k++) h[k] = t0 + k < tiles ? tile_last[t0 + k] : 0u;
+    u32 mine = 0;
 #pragma unroll
-        for (u32 k = 0; k < 8; k++)
-            if (t + k < t1) {
-                carry[t + k] = run ? run - 1u : 0u;
-                run = h[k] > run ? h[k] : run;
-            }
+    for (int k = 0; k < SP_PER; k++) mine = h[k] > mine ? h[k] : mine;
+    u32 all;
+    u32 run = sp_block_excl_max<SP_BLOCK>(mine, lds, all);
+#pragma unroll
+    for (int k = 0; k < SP_PER; k++) {
+        if (t0 + k < tiles) carry_local[t0 + k] = run;
+        run = h[k] > run ? h[k] : run;
+    }
+    if (threadIdx.x == 0) group_max[blockIdx.x] = all;
+}
+__global__ void __launch_bounds__(1024) k_bwt_spine_b(const u32 * __restrict__ group_max, u32 groups, u32 * __restrict__ group_carry) {
+    __shared__ u32 lds[1024 / WAVE + 1];
+    u32 run_in = 0;  // maximum over the chunks of 1024 groups before this one (one chunk for every block size the API allows)
+    for (u32 base = 0; base < groups; base += 1024u) {
+        const u32 g = base + threadIdx.x;
+        const u32 x = g < groups ? group_max[g] : 0u;
+        u32 all;
+        const u32 ex = sp_block_excl_max<1024>(x, lds, all);
+        if (g < groups) group_carry[g] = ex > run_in ? ex : run_in;
+        run_in = all > run_in ? all : run_in;
     }
 }
 
@@ -500,7 +515,27 @@ __device__ __forceinline__ void wr_run(const WrCtx & cx, WrLds & lds, u64 (&pl)[
             if (total && lane == 0) atomicAdd(&cx.counters[1], total);
             return;
         }
-        if (total <= 32u * E) {
+        // ---- group starts (running maximum of the head positions) and the largest group
+        u32 lasth = 0;  // 1 + position of this lane's last head
+#pragma unroll
+        for (int r = 0; r < E; r++)
+            if ((hm >> r) & 1u) lasth = lane * E + r + 1u;
+        u32 run0 = wave_incl_max(lasth);
+        run0 = __shfl_up(run0, 1u);
+        if (lane == 0) run0 = 0;  // (position 0 is a head)
+        u32 span = 0;  // largest distance of a position from its group's head
+        {
+            u32 rn = run0;
+#pragma unroll
+            for (int r = 0; r < E; r++) {
+                const u32 j = lane * E + r;
+                if ((hm >> r) & 1u) rn = j + 1u;
+                if (j < L && j + 1u - rn > span) span = j + 1u - rn;
+            }
+        }
+        const bool small_groups = wave_max(span) < 64u && step > 0u;  // every group has at most 64 members: the tail kernel's
+        u32 run = run0;
+        if (small_groups || total <= 32u * E) {
             // ---- shrink: the final ones out, the others move up into half (or less) of the lanes' capacity
             const u32 before = wave_incl_add(ambs) - ambs;
             u32 so[E];
@@ -527,27 +562,28 @@ __device__ __forceinline__ void wr_run(const WrCtx & cx, WrLds & lds, u64 (&pl)[
             }
             wave_sync();
             // continue with the smallest capacity that holds them
-            if (total <= 64u) {  // the rest is the tail kernel's (one suffix per lane, many waves per CU)
+            if (small_groups || total <= 64u) {  // the rest is the tail kernel's (one suffix per lane, many waves per CU)
                 u32 base = 0;
                 if (lane == 0) base = atomicAdd(&cx.counters[4], total);
                 base = __shfl(base, 0);
-                if (base + total > cx.tail_cap) {
-                    if (lane == 0) {
-                        cx.counters[3] = 1u;
-                        atomicMin(&cx.counters[5], base);  // the list is valid up to the first append that did not fit
-                        atomicAdd(&cx.counters[1], total);
+                const bool fits = base + total <= cx.tail_cap;
+                if (!fits && lane == 0) {
+                    cx.counters[3] = 1u;
+                    atomicMin(&cx.counters[5], base);  // the list is valid up to the first append that did not fit
+                    atomicAdd(&cx.counters[1], total);
+                }
+                for (u32 q = lane; q < total; q += WAVE) {
+                    const u64 x = lds.pl[q];
+                    if (fits) {
+                        cx.tail_v[base + q] = pl_v(x) | (lds.hd[q] ? V_HEAD : 0u);
+                        cx.tail_slot[base + q] = (u32)(cx.slot0 + lds.aux[q]);
+                        cx.tail_d[base + q] = (u16)pl_d(x);
+                        cx.tail_pb[base + q] = (u8)pl_p(x);
+                    } else {  // back where they are
+                        const u64 p = cx.slot0 + lds.aux[q];
+                        cx.v[p] = pl_v(x) | (lds.hd[q] ? V_HEAD : 0u);
+                        cx.pb[p] = (u8)pl_p(x);
                     }
-                    if (lane < total) {  // back where they are
-                        const u64 p = cx.slot0 + lds.aux[lane];
-                        cx.v[p] = pl_v(lds.pl[lane]) | (lds.hd[lane] ? V_HEAD : 0u);
-                        cx.pb[p] = (u8)pl_p(lds.pl[lane]);
-                    }
-                } else if (lane < total) {
-                    const u64 x = lds.pl[lane];
-                    cx.tail_v[base + lane] = pl_v(x) | (lds.hd[lane] ? V_HEAD : 0u);
-                    cx.tail_slot[base + lane] = (u32)(cx.slot0 + lds.aux[lane]);
-                    cx.tail_d[base + lane] = (u16)pl_d(x);
-                    cx.tail_pb[base + lane] = (u8)pl_p(x);
                 }
                 wave_sync();
                 return;
@@ -558,14 +594,6 @@ __device__ __forceinline__ void wr_run(const WrCtx & cx, WrLds & lds, u64 (&pl)[
             }
             if constexpr (E == 4) return wr_reload<2>(cx, lds, total, step);
         }
-        // ---- group starts (running maximum of the head positions)
-        u32 lasth = 0;  // 1 + position of this lane's last head
-#pragma unroll
-        for (int r = 0; r < E; r++)
-            if ((hm >> r) & 1u) lasth = lane * E + r + 1u;
-        u32 run = wave_incl_max(lasth);
-        run = __shfl_up(run, 1u);
-        if (lane == 0) run = 0;  // (position 0 is a head)
         // ---- next code bits of the ambiguous suffixes, four suffixes of a lane at a time (their windows in flight together: with all eight
         // the kernel needs every register a wave can have, and one wave per SIMD hides no latency at all)
         constexpr int CH = E < 4 ? E : 4;
@@ -680,7 +708,8 @@ __device__ __forceinline__ void wr_emit_big(u32 * __restrict__ big_slot, u32 * _
 }
 
 __global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_resolve(const u8 * __restrict__ t, u32 n, u32 * __restrict__ v, u8 * __restrict__ pb,
-                                                                const u32 * __restrict__ hbits, const u32 * __restrict__ carry, const u8 * __restrict__ dirty,
+                                                                const u32 * __restrict__ hbits, const u32 * __restrict__ carry_local,
+                                                                const u32 * __restrict__ group_carry, const u8 * __restrict__ dirty,
                                                                 const u32 * __restrict__ vlc, u32 * __restrict__ big_slot, u32 * __restrict__ big_hp, u32 big_cap,
                                                                 u32 * __restrict__ tail_v, u32 * __restrict__ tail_slot, u16 * __restrict__ tail_d,
                                                                 u8 * __restrict__ tail_pb, u32 tail_cap, u32 * __restrict__ counters, u32 chain) {
@@ -768,7 +797,8 @@ __global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_resolve(const u8 * __re
     // ---- the slots before the first head continue a group headed before this window (tile > 0: slot 0 is always a head)
     const u32 c0 = wr_next_head(lds.hb, 0u);
     if (c0 > 0u) {
-        const u32 hp = carry[tile];
+        const u32 cl = carry_local[tile], cg = group_carry[tile / (u32)SP_GROUP];
+        const u32 hp = (cl > cg ? cl : cg) - 1u;  // (tile > 0: slot 0 is a head, so there is one)
         const bool big = c0 == WR_FAR || (u32)a + c0 - hp > (u32)WR_G;
         const u32 stop = c0 < (u32)WR_A ? c0 : (u32)WR_A;
         if (big) wr_emit_big(big_slot, big_hp, big_cap, counters, a, 0u, stop < wend ? stop : wend, hp);
@@ -875,24 +905,45 @@ __global__ void __launch_bounds__(WAVE) k_bwt_tail(const u8 * __restrict__ t, u3
                 c = 0;
             }
             const u64 w = ((live ? 1ull : 0ull) << 40) | key;
-            u32 below = 0;
-            for (u32 k = 0; k < maxsz; k++) {
-                const u32 q = gs + k;
-                const u64 wq = __shfl(w, (int)(q & 63u));
-                if (k < sz) below += (wq < w || (wq == w && q < lane)) ? 1u : 0u;
+            u64 w2, wl;
+            if (maxsz <= 12u) {
+                // small groups: rank by counting (a cross-lane read per member of the largest group)
+                u32 below = 0;
+                for (u32 k = 0; k < maxsz; k++) {
+                    const u32 q = gs + k;
+                    const u64 wq = __shfl(w, (int)(q & 63u));
+                    if (k < sz) below += (wq < w || (wq == w && q < lane)) ? 1u : 0u;
+                }
+                const u32 np = act ? gs + below : lane;
+                s_word[np] = w;
+                s_v[np] = sv;
+                s_d[np] = (u16)(sd + c);
+                s_pb[np] = (u8)sp;
+                __syncthreads();
+                w2 = s_word[lane];
+                wl = s_word[lane ? lane - 1u : 0u];
+                sv = s_v[lane];
+                sd = s_d[lane];
+                sp = s_pb[lane];
+                __syncthreads();
+            } else {
+                // larger groups: one 64-lane bitonic network over [group start : 6][word : 41][lane : 6] sorts all groups at once
+                // (21 stages whatever the group sizes; counting costs a cross-lane read per member: 64 of them for a group of 64)
+                u64 x[1] = {((u64)(act ? gs : lane) << 47) | (w << 6) | (u64)lane};
+                s_v[lane] = sv;
+                s_d[lane] = (u16)(sd + c);
+                s_pb[lane] = (u8)sp;
+                wave_bitonic<1>(x);
+                __syncthreads();
+                const u32 src = (u32)x[0] & 63u;
+                sv = s_v[src];
+                sd = s_d[src];
+                sp = s_pb[src];
+                __syncthreads();
+                w2 = (x[0] >> 6) & ((1ull << 41) - 1ull);
+                const u64 xl = __shfl_up(x[0], 1u);
+                wl = (xl >> 6) & ((1ull << 41) - 1ull);
             }
-            const u32 np = act ? gs + below : lane;
-            s_word[np] = w;
-            s_v[np] = sv;
-            s_d[np] = (u16)(sd + c);
-            s_pb[np] = (u8)sp;
-            __syncthreads();
-            const u64 w2 = s_word[lane];
-            const u64 wl = s_word[lane ? lane - 1u : 0u];
-            sv = s_v[lane];
-            sd = s_d[lane];
-            sp = s_pb[lane];
-            __syncthreads();
             headf = headf || w2 != wl;  // (a lane alone in its group only ever compares its own word: it stays a head)
         }
         if (act) {
@@ -1303,7 +1354,10 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     u8 * pb = tmp.take<u8>(n);
     const u32 tiles = (u32)(((u64)n + TR_S - 1) / TR_S);
     u32 * tile_last = tmp.take<u32>(tiles + 1);
-    u32 * carry = tmp.take<u32>(tiles + 1);
+    u32 * carry = tmp.take<u32>(tiles + 1);  // carry_local
+    const u32 sp_groups = (tiles + SP_GROUP - 1) / SP_GROUP;
+    u32 * group_max = tmp.take<u32>(sp_groups + 1);
+    u32 * group_carry = tmp.take<u32>(sp_groups + 1);
     u8 * dirty = tmp.take<u8>(tiles + 2);
     u32 * hbits = tmp.take<u32>(((size_t)n + 63) / 64 * 2 + (size_t)TR_S / 32 + 8);  // snapshot of the head flags, whole 64-slot words of every anchor tile
     u32 * d_words = tmp.take<u32>(8);   // counters [0] big elements, [1] left ambiguous by the resolve / tail kernels, [2] slot of suffix 0, [3] a list overflowed, [4] tail entries, [5] start of the first tail append that did not fit; [6] scan total, [7] primary index
@@ -1331,7 +1385,8 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     st.rounds++;
     u32 * V = val[cur];
     launch(k_bwt_heads, dim3(tiles), dim3(BW_BLOCK), 0, s, (const u64 *)key[cur], V, pb, n, tile_last, hbits, d_words);
-    launch(k_bwt_spine_max, dim3(1), dim3(SP_BLOCK), 0, s, (const u32 *)tile_last, tiles, carry);
+    launch(k_bwt_spine_a, dim3(sp_groups), dim3(SP_BLOCK), 0, s, (const u32 *)tile_last, tiles, carry, group_max);
+    launch(k_bwt_spine_b, dim3(1), dim3(1024), 0, s, (const u32 *)group_max, sp_groups, group_carry);
 
     // the key buffers are free from here on: the big path's lists live there
     const u32 big_cap = n / 4;
@@ -1357,7 +1412,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     bool deep = false;    // fall back to rank doubling
     u32 h_words[8];
     for (int pass = 0;; pass++) {
-        launch(k_bwt_resolve, dim3((tiles + WR_WAVES - 1) / WR_WAVES), dim3(WR_WAVES * WAVE), 0, s, d_in, n, V, pb, (const u32 *)hbits, (const u32 *)carry,
+        launch(k_bwt_resolve, dim3((tiles + WR_WAVES - 1) / WR_WAVES), dim3(WR_WAVES * WAVE), 0, s, d_in, n, V, pb, (const u32 *)hbits, (const u32 *)carry, (const u32 *)group_carry,
                (const u8 *)(pass ? dirty : nullptr), (const u32 *)d_vlc, big_slot, big_hp, big_cap, tail_v, tail_slot, tail_d, tail_pb, tail_cap, d_words,
                (u32)pass + 1u);
         HIP_CHECK(hipMemcpyAsync(h_words, d_words, sizeof h_words, hipMemcpyDeviceToHost, s));
@@ -1415,7 +1470,8 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
         HIP_CHECK(hipMemsetAsync(d_words + 4, 0, sizeof(u32), s));
         HIP_CHECK(hipMemsetAsync(d_words + 5, 0xFF, sizeof(u32), s));
         launch(k_bwt_reduce_heads, dim3(tiles), dim3(BW_BLOCK), 0, s, (const u32 *)V, n, tile_last, hbits);
-        launch(k_bwt_spine_max, dim3(1), dim3(SP_BLOCK), 0, s, (const u32 *)tile_last, tiles, carry);
+        launch(k_bwt_spine_a, dim3(sp_groups), dim3(SP_BLOCK), 0, s, (const u32 *)tile_last, tiles, carry, group_max);
+    launch(k_bwt_spine_b, dim3(1), dim3(1024), 0, s, (const u32 *)group_max, sp_groups, group_carry);
     }
 
     u32 idx = 0;
