@@ -418,7 +418,6 @@ struct WrLds {
     u64 pl[WR_G];       // payloads by position (permutation / compaction buffer)
     u16 aux[WR_G];      // slot of a position (offset from the window start)
     u8 hd[WR_G];        // compaction: head flags of the positions
-    u32 hb[36];         // head bits of the window [a, a + 1024]
 };
 
 // smallest set bit position >= p in the wave's window bitmap (33 words), WR_FAR if none
@@ -661,7 +660,7 @@ __device__ __forceinline__ void wr_run(const WrCtx & cx, WrLds & lds, u64 (&pl)[
 }
 
 template <int E>
-__device__ __forceinline__ void wr_batch(const WrCtx & cx, WrLds & lds, u32 c, u32 L) {
+__device__ __forceinline__ void wr_batch(const WrCtx & cx, WrLds & lds, u32 L) {  // ONE group: slots cx.slot0 .. + L
     const u32 lane = (u32)lane_id();
     u64 pl[E];
     u32 hm = 0;
@@ -670,23 +669,20 @@ __device__ __forceinline__ void wr_batch(const WrCtx & cx, WrLds & lds, u32 c, u
 #pragma unroll
     for (int r = 0; r < E; r++) {
         const u32 j = lane * E + r;
-        const u64 p = cx.slot0 + c + (j < L ? j : L - 1u);
+        const u64 p = cx.slot0 + (j < L ? j : L - 1u);
         xv[r] = cx.v[p];
         xp[r] = cx.pb[p];
     }
 #pragma unroll
     for (int r = 0; r < E; r++) {
         const u32 j = lane * E + r;
-        const u32 wpos = c + j;
         const bool in = j < L;
-        const u32 h = in ? ((lds.hb[wpos >> 5] >> (wpos & 31u)) & 1u) : 1u;
-        hm |= h << r;
+        hm |= ((in && j > 0u) ? 0u : 1u) << r;  // the group's head; positions past it are heads without content
         pl[r] = in ? pl_make(xv[r] & V_MASK, 0u, xp[r]) : 0ull;
-        lds.aux[j] = (u16)(c + (in ? j : 0u));
+        lds.aux[j] = (u16)(in ? j : 0u);
     }
     wave_sync();
     wr_run<E>(cx, lds, pl, hm, L, 0u);
-    wave_sync();  // the next batch reuses the buffers
 }
 
 __device__ __forceinline__ void wr_emit_big(u32 * __restrict__ big_slot, u32 * __restrict__ big_hp, u32 big_cap, u32 * __restrict__ counters, u64 slot0, u32 p0, u32 p1,
@@ -707,22 +703,28 @@ __device__ __forceinline__ void wr_emit_big(u32 * __restrict__ big_slot, u32 * _
     }
 }
 
-__global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_resolve(const u8 * __restrict__ t, u32 n, u32 * __restrict__ v, u8 * __restrict__ pb,
-                                                                const u32 * __restrict__ hbits, const u32 * __restrict__ carry_local,
-                                                                const u32 * __restrict__ group_carry, const u8 * __restrict__ dirty,
-                                                                const u32 * __restrict__ vlc, u32 * __restrict__ big_slot, u32 * __restrict__ big_hp, u32 big_cap,
-                                                                u32 * __restrict__ tail_v, u32 * __restrict__ tail_slot, u16 * __restrict__ tail_d,
-                                                                u8 * __restrict__ tail_pb, u32 tail_cap, u32 * __restrict__ counters, u32 chain) {
-    __shared__ u32 tab[256];
-    __shared__ WrLds wl[WR_WAVES];
-    tab[threadIdx.x] = vlc[threadIdx.x];
-    __syncthreads();  // the only workgroup barrier: from here on the waves do not know of each other
+// The router: one wave per 512 anchor slots looks at the head bits and sends every group headed there where it belongs --
+//   up to 64 members   : its ambiguous suffixes to the tail list (k_bwt_tail)
+//   65 .. 512 members  : a (head slot, size) descriptor to the mid list (k_bwt_wide)
+//   more               : its slots to the big list (k_big_*)
+// It keeps nothing but a 33-word bitmap per wave, so dozens of waves share a CU (the first version did the wide work in the same
+// kernel and ran two waves per SIMD: 13 ms instead of 3).
+struct RtLds {
+    u32 hb[36];  // head bits of the window [a, a + 1024]
+};
+__global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_route(u32 n, const u32 * __restrict__ v, const u8 * __restrict__ pb, const u32 * __restrict__ hbits,
+                                                              const u32 * __restrict__ carry_local, const u32 * __restrict__ group_carry,
+                                                              const u8 * __restrict__ dirty, u32 * __restrict__ big_slot, u32 * __restrict__ big_hp, u32 big_cap,
+                                                              u32 * __restrict__ mid_slot, u16 * __restrict__ mid_size, u32 mid_cap, u32 * __restrict__ tail_v,
+                                                              u32 * __restrict__ tail_slot, u16 * __restrict__ tail_d, u8 * __restrict__ tail_pb, u32 tail_cap,
+                                                              u32 * __restrict__ counters) {
+    __shared__ RtLds wl[WR_WAVES];
     const u32 lane = (u32)lane_id();
     const u32 tile = blockIdx.x * WR_WAVES + (u32)wave_id();
     const u64 a = (u64)tile * WR_A;
     if (a >= n) return;
     if (dirty && !(dirty[tile] | dirty[tile + 1])) return;
-    WrLds & lds = wl[wave_id()];
+    RtLds & lds = wl[wave_id()];
     // head bits of [a, a + 1024] from the snapshot; slots past the end are heads
     if (lane < 33u) {
         const u64 first = a + 32ull * lane;
@@ -730,7 +732,6 @@ __global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_resolve(const u8 * __re
         lds.hb[lane] = first < limit ? hbits[first >> 5] : 0xFFFFFFFFu;
     }
     wave_sync();
-    WrCtx cx{t, n, v, pb, tab, counters, chain, a, tail_v, tail_slot, tail_d, tail_pb, tail_cap};
     const u32 wend = (u64)n - a < 1025ull ? (u32)((u64)n - a) : 1025u;  // window positions that exist (the first slot past the end is a head)
     // 64 head bits starting at window position `start` (may be negative: nothing is known before the window)
     auto bits64 = [&](int start) -> u64 {
@@ -803,7 +804,7 @@ __global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_resolve(const u8 * __re
         const u32 stop = c0 < (u32)WR_A ? c0 : (u32)WR_A;
         if (big) wr_emit_big(big_slot, big_hp, big_cap, counters, a, 0u, stop < wend ? stop : wend, hp);
     }
-    // ---- groups of more than 64 headed here: the wide path (up to 512 members, 2 / 4 / 8 suffixes per lane), or the big list
+    // ---- groups of more than 64 headed here: a descriptor for the wide kernel (up to 512 members), or the big list
     for (u32 k = 0; k < 8u; k++) {
         const u32 p = lane + 64u * k;
         const bool head = (lds.hb[p >> 5] >> (p & 31u)) & 1u;
@@ -818,12 +819,38 @@ __global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_resolve(const u8 * __re
                 wr_emit_big(big_slot, big_hp, big_cap, counters, a, c, stop < wend ? stop : wend, (u32)a + c);
                 continue;
             }
-            const u32 L = (nh < wend ? nh : wend) - c;
-            if (L <= 128u) wr_batch<2>(cx, lds, c, L);
-            else if (L <= 256u) wr_batch<4>(cx, lds, c, L);
-            else wr_batch<8>(cx, lds, c, L);
+            if (lane == 0) {
+                const u32 d = atomicAdd(&counters[8], 1u);
+                if (d < mid_cap) {
+                    mid_slot[d] = (u32)a + c;
+                    mid_size[d] = (u16)((nh < wend ? nh : wend) - c);
+                } else {  // cannot happen (the list holds n / 65 groups); the group stays as it is
+                    counters[3] = 1u;
+                    atomicAdd(&counters[1], nh - c);
+                }
+            }
         }
     }
+}
+
+// The wide kernel: one wave per group of 65 .. 512 suffixes (a descriptor of the router), 2 / 4 / 8 suffixes per lane in registers.
+// A step or two later its sub-groups have at most 64 members and go to the tail list.
+__global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_wide(const u8 * __restrict__ t, u32 n, u32 * __restrict__ v, u8 * __restrict__ pb, const u32 * __restrict__ vlc,
+                                                             const u32 * __restrict__ mid_slot, const u16 * __restrict__ mid_size, u32 nmid, u32 * __restrict__ tail_v,
+                                                             u32 * __restrict__ tail_slot, u16 * __restrict__ tail_d, u8 * __restrict__ tail_pb, u32 tail_cap,
+                                                             u32 * __restrict__ counters, u32 chain) {
+    __shared__ u32 tab[256];
+    __shared__ WrLds wl[WR_WAVES];
+    tab[threadIdx.x] = vlc[threadIdx.x];
+    __syncthreads();  // the only workgroup barrier: from here on the waves do not know of each other
+    const u32 g = blockIdx.x * WR_WAVES + (u32)wave_id();
+    if (g >= nmid) return;
+    WrLds & lds = wl[wave_id()];
+    const u32 L = mid_size[g];
+    WrCtx cx{t, n, v, pb, tab, counters, chain, (u64)mid_slot[g], tail_v, tail_slot, tail_d, tail_pb, tail_cap};
+    if (L <= 128u) wr_batch<2>(cx, lds, L);
+    else if (L <= 256u) wr_batch<4>(cx, lds, L);
+    else wr_batch<8>(cx, lds, L);
 }
 
 // ---- the tail: tiny groups that need many more windows ---------------------------------------------------------------------------
@@ -1321,7 +1348,7 @@ static int bits_for(u64 x) {
 
 size_t bwt_workspace_bytes(u64 n) {
     // 2 keys (16) + 2 suffix arrays (8) + payload (1) + tail list (11) + ISA (4) + 2 slot lists (8) + ranks (4) + tile words (4) + a third suffix list (4)
-    return n * (16 + 8 + 1 + 11 + 4 + 8 + 4 + 4 + 4) + radix_temp_bytes(n) + scan_temp_words(n) * 4 + (1u << 20) + 16384;
+    return n * (16 + 8 + 1 + 11 + 4 + 8 + 4 + 4 + 4) + n / 8 + radix_temp_bytes(n) + scan_temp_words(n) * 4 + (1u << 20) + 16384;
 }
 
 // full LSD sort of (keys, iota) over key bits [bit_lo, bit_hi): the first pass generates the values.  Returns the buffer index of the result.
@@ -1360,7 +1387,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     u32 * group_carry = tmp.take<u32>(sp_groups + 1);
     u8 * dirty = tmp.take<u8>(tiles + 2);
     u32 * hbits = tmp.take<u32>(((size_t)n + 63) / 64 * 2 + (size_t)TR_S / 32 + 8);  // snapshot of the head flags, whole 64-slot words of every anchor tile
-    u32 * d_words = tmp.take<u32>(8);   // counters [0] big elements, [1] left ambiguous by the resolve / tail kernels, [2] slot of suffix 0, [3] a list overflowed, [4] tail entries, [5] start of the first tail append that did not fit; [6] scan total, [7] primary index
+    u32 * d_words = tmp.take<u32>(16);   // counters [0] big elements, [1] left ambiguous by the resolve / tail kernels, [2] slot of suffix 0, [3] a list overflowed, [4] tail entries, [5] start of the first tail append that did not fit; [6] scan total, [7] primary index, [8] mid descriptors
     u32 * d_vlc = tmp.take<u32>(256);
     u32 * d_hist = tmp.take<u32>(256);
     BwtStats st;
@@ -1370,7 +1397,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     // ---- codes
     u32 h_hist[256], h_vlc[256];
     HIP_CHECK(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), s));
-    HIP_CHECK(hipMemsetAsync(d_words, 0, 8 * sizeof(u32), s));
+    HIP_CHECK(hipMemsetAsync(d_words, 0, 16 * sizeof(u32), s));
     HIP_CHECK(hipMemsetAsync(d_words + 5, 0xFF, sizeof(u32), s));
     launch(k_bwt_sym_hist, grid(((u64)n + 63) / 64), dim3(BW_BLOCK), 0, s, d_in, n, d_hist);
     HIP_CHECK(hipMemcpyAsync(h_hist, d_hist, sizeof h_hist, hipMemcpyDeviceToHost, s));
@@ -1408,15 +1435,25 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     u32 * tail_slot = tmp.take<u32>(tail_cap);
     u16 * tail_d = tmp.take<u16>(tail_cap);
     u8 * tail_pb = tmp.take<u8>(tail_cap);
+    const u32 mid_cap = n / 64 + 16;  // groups of more than 64
+    u32 * mid_slot = tmp.take<u32>(mid_cap);
+    u16 * mid_size = tmp.take<u16>(mid_cap);
     u32 g = 7;            // symbols every group is known to share at least (7 per 56-bit window)
     bool deep = false;    // fall back to rank doubling
-    u32 h_words[8];
+    u32 h_words[16];
     for (int pass = 0;; pass++) {
-        launch(k_bwt_resolve, dim3((tiles + WR_WAVES - 1) / WR_WAVES), dim3(WR_WAVES * WAVE), 0, s, d_in, n, V, pb, (const u32 *)hbits, (const u32 *)carry, (const u32 *)group_carry,
-               (const u8 *)(pass ? dirty : nullptr), (const u32 *)d_vlc, big_slot, big_hp, big_cap, tail_v, tail_slot, tail_d, tail_pb, tail_cap, d_words,
-               (u32)pass + 1u);
+        launch(k_bwt_route, dim3((tiles + WR_WAVES - 1) / WR_WAVES), dim3(WR_WAVES * WAVE), 0, s, n, (const u32 *)V, (const u8 *)pb, (const u32 *)hbits,
+               (const u32 *)carry, (const u32 *)group_carry, (const u8 *)(pass ? dirty : nullptr), big_slot, big_hp, big_cap, mid_slot, mid_size, mid_cap, tail_v, tail_slot,
+               tail_d, tail_pb, tail_cap, d_words);
         HIP_CHECK(hipMemcpyAsync(h_words, d_words, sizeof h_words, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
+        const u32 nmid = h_words[8] < mid_cap ? h_words[8] : mid_cap;
+        if (nmid) {
+            launch(k_bwt_wide, dim3((nmid + WR_WAVES - 1) / WR_WAVES), dim3(WR_WAVES * WAVE), 0, s, d_in, n, V, pb, (const u32 *)d_vlc, (const u32 *)mid_slot,
+                   (const u16 *)mid_size, nmid, tail_v, tail_slot, tail_d, tail_pb, tail_cap, d_words, (u32)pass + 1u);
+            HIP_CHECK(hipMemcpyAsync(h_words, d_words, sizeof h_words, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        }
         const u32 ntail = h_words[4] < h_words[5] ? h_words[4] : h_words[5];  // ([5]: where the first append that did not fit would have started)
         if (ntail)
             launch(k_bwt_tail, dim3((ntail + WAVE - 1) / WAVE), dim3(WAVE), 0, s, d_in, n, V, pb, (const u32 *)d_vlc, (const u32 *)tail_v, (const u32 *)tail_slot,
@@ -1424,7 +1461,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
         HIP_CHECK(hipMemcpyAsync(h_words, d_words, sizeof h_words, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         const u32 nb = h_words[0];
-        if (getenv("BZ3_BWT_TRACE")) fprintf(stderr, "[bwt] n %u pass %d depth %u: %u suffixes in groups > %d, %u through the tail kernel, %u given up, overflow %u\n", n, pass, g, nb, TR_G, h_words[4], h_words[1], h_words[3]);
+        if (getenv("BZ3_BWT_TRACE")) fprintf(stderr, "[bwt] n %u pass %d depth %u: %u suffixes in groups > %d, %u groups through the wide kernel, %u suffixes through the tail kernel, %u given up, overflow %u\n", n, pass, g, nb, TR_G, h_words[8], h_words[4], h_words[1], h_words[3]);
         if (nb == 0) {  // no group left that is too large: done, unless the resolve kernel gave some up (counted over all passes)
             deep = h_words[1] != 0;
             break;
@@ -1469,6 +1506,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
         HIP_CHECK(hipMemsetAsync(d_words, 0, sizeof(u32), s));      // the big list and the tail list are rebuilt by the next pass
         HIP_CHECK(hipMemsetAsync(d_words + 4, 0, sizeof(u32), s));
         HIP_CHECK(hipMemsetAsync(d_words + 5, 0xFF, sizeof(u32), s));
+        HIP_CHECK(hipMemsetAsync(d_words + 8, 0, sizeof(u32), s));
         launch(k_bwt_reduce_heads, dim3(tiles), dim3(BW_BLOCK), 0, s, (const u32 *)V, n, tile_last, hbits);
         launch(k_bwt_spine_a, dim3(sp_groups), dim3(SP_BLOCK), 0, s, (const u32 *)tile_last, tiles, carry, group_max);
     launch(k_bwt_spine_b, dim3(1), dim3(1024), 0, s, (const u32 *)group_max, sp_groups, group_carry);
