@@ -466,11 +466,11 @@ struct WrCtx {
 // One batch: window positions [c, c + L) (whole groups, L <= 512), E = suffixes per lane.  Returns when every group is resolved (or the
 // step cap is reached: the groups are written back as they are and counted as given up).
 template <int E>
-__device__ __forceinline__ void wr_run(const WrCtx & cx, WrLds & lds, u64 (&pl)[E], u32 hm, u32 L, u32 step);
+__device__ __forceinline__ u32 wr_run(const WrCtx & cx, WrLds & lds, u64 (&pl)[E], u32 hm, u32 L, u32 step);
 
 // the `total` ambiguous suffixes a shrink left in the wave's LDS buffer, E2 per lane
 template <int E2>
-__device__ __forceinline__ void wr_reload(const WrCtx & cx, WrLds & lds, u32 total, u32 step) {
+__device__ __forceinline__ u32 wr_reload(const WrCtx & cx, WrLds & lds, u32 total, u32 step) {
     const u32 lane = (u32)lane_id();
     u64 q[E2];
     u32 h2 = 0;
@@ -482,11 +482,12 @@ __device__ __forceinline__ void wr_reload(const WrCtx & cx, WrLds & lds, u32 tot
         h2 |= (in ? (u32)lds.hd[j] : 1u) << r;
     }
     wave_sync();
-    wr_run<E2>(cx, lds, q, h2, total, step);
+    return wr_run<E2>(cx, lds, q, h2, total, step);
 }
 
+// Returns the number of suffixes it left in lds.pl / aux / hd for the tail list (0: the batch is done).
 template <int E>
-__device__ __forceinline__ void wr_run(const WrCtx & cx, WrLds & lds, u64 (&pl)[E], u32 hm, u32 L, u32 step) {
+__device__ __forceinline__ u32 wr_run(const WrCtx & cx, WrLds & lds, u64 (&pl)[E], u32 hm, u32 L, u32 step) {
     // pl[r] / bit r of hm: payload and head flag of position j = lane * E + r; lds.aux[j] = the position's slot (offset from cx.slot0);
     // positions >= L are heads without content
     const u32 lane = (u32)lane_id();
@@ -512,7 +513,7 @@ __device__ __forceinline__ void wr_run(const WrCtx & cx, WrLds & lds, u64 (&pl)[
                     if (sv == 0u) cx.counters[2] = (u32)p;
                 }
             if (total && lane == 0) atomicAdd(&cx.counters[1], total);
-            return;
+            return 0u;
         }
         // ---- group starts (running maximum of the head positions) and the largest group
         u32 lasth = 0;  // 1 + position of this lane's last head
@@ -561,32 +562,7 @@ __device__ __forceinline__ void wr_run(const WrCtx & cx, WrLds & lds, u64 (&pl)[
             }
             wave_sync();
             // continue with the smallest capacity that holds them
-            if (small_groups || total <= 64u) {  // the rest is the tail kernel's (one suffix per lane, many waves per CU)
-                u32 base = 0;
-                if (lane == 0) base = atomicAdd(&cx.counters[4], total);
-                base = __shfl(base, 0);
-                const bool fits = base + total <= cx.tail_cap;
-                if (!fits && lane == 0) {
-                    cx.counters[3] = 1u;
-                    atomicMin(&cx.counters[5], base);  // the list is valid up to the first append that did not fit
-                    atomicAdd(&cx.counters[1], total);
-                }
-                for (u32 q = lane; q < total; q += WAVE) {
-                    const u64 x = lds.pl[q];
-                    if (fits) {
-                        cx.tail_v[base + q] = pl_v(x) | (lds.hd[q] ? V_HEAD : 0u);
-                        cx.tail_slot[base + q] = (u32)(cx.slot0 + lds.aux[q]);
-                        cx.tail_d[base + q] = (u16)pl_d(x);
-                        cx.tail_pb[base + q] = (u8)pl_p(x);
-                    } else {  // back where they are
-                        const u64 p = cx.slot0 + lds.aux[q];
-                        cx.v[p] = pl_v(x) | (lds.hd[q] ? V_HEAD : 0u);
-                        cx.pb[p] = (u8)pl_p(x);
-                    }
-                }
-                wave_sync();
-                return;
-            }
+            if (small_groups || total <= 64u) return total;  // the rest is the tail kernel's: the caller appends lds.pl / aux / hd [0, total) to its list
             if constexpr (E == 8) {
                 if (total > 128u) return wr_reload<4>(cx, lds, total, step);
                 return wr_reload<2>(cx, lds, total, step);
@@ -660,7 +636,7 @@ __device__ __forceinline__ void wr_run(const WrCtx & cx, WrLds & lds, u64 (&pl)[
 }
 
 template <int E>
-__device__ __forceinline__ void wr_batch(const WrCtx & cx, WrLds & lds, u32 L) {  // ONE group: slots cx.slot0 .. + L
+__device__ __forceinline__ u32 wr_batch(const WrCtx & cx, WrLds & lds, u32 L) {  // ONE group: slots cx.slot0 .. + L
     const u32 lane = (u32)lane_id();
     u64 pl[E];
     u32 hm = 0;
@@ -682,25 +658,7 @@ __device__ __forceinline__ void wr_batch(const WrCtx & cx, WrLds & lds, u32 L) {
         lds.aux[j] = (u16)(in ? j : 0u);
     }
     wave_sync();
-    wr_run<E>(cx, lds, pl, hm, L, 0u);
-}
-
-__device__ __forceinline__ void wr_emit_big(u32 * __restrict__ big_slot, u32 * __restrict__ big_hp, u32 big_cap, u32 * __restrict__ counters, u64 slot0, u32 p0, u32 p1,
-                                            u32 hp) {
-    if (p1 <= p0) return;
-    const u32 lane = (u32)lane_id();
-    const u32 cnt = p1 - p0;
-    u32 base = 0;
-    if (lane == 0) base = atomicAdd(&counters[0], cnt);
-    base = __shfl(base, 0);
-    if (base + cnt > big_cap) {
-        if (lane == 0) counters[3] = 1u;
-        return;
-    }
-    for (u32 q = lane; q < cnt; q += WAVE) {
-        big_slot[base + q] = (u32)slot0 + p0 + q;
-        big_hp[base + q] = hp;
-    }
+    return wr_run<E>(cx, lds, pl, hm, L, 0u);
 }
 
 // The router: one wave per 512 anchor slots looks at the head bits and sends every group headed there where it belongs --
@@ -709,30 +667,38 @@ __device__ __forceinline__ void wr_emit_big(u32 * __restrict__ big_slot, u32 * _
 //   more               : its slots to the big list (k_big_*)
 // It keeps nothing but a 33-word bitmap per wave, so dozens of waves share a CU (the first version did the wide work in the same
 // kernel and ran two waves per SIMD: 13 ms instead of 3).
+constexpr int RT_WAVES = 16;  // waves per router workgroup: one append to each list per WORKGROUP (an append per wave made the
+                              // lists' counters the bottleneck: a single word takes ~90 atomics per microsecond)
 struct RtLds {
-    u32 hb[36];  // head bits of the window [a, a + 1024]
+    u32 hb[36];     // head bits of the window [a, a + 1024]
+    u16 lg_c[10];   // groups of more than 64 headed in the anchor slots (at most 7) and the run that enters from the left: start ...
+    u16 lg_e[10];   // ... end (exclusive, clipped to the anchor slots for the big ones) ...
+    u32 lg_hp[10];  // ... and for the big ones the group's head slot; 0xFFFFFFFF marks a mid-size group (a descriptor)
+    u32 cnt[4];     // what this wave appends: [0] tail entries, [1] mid descriptors, [2] big slots
+    u32 base[4];    // where
 };
-__global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_route(u32 n, const u32 * __restrict__ v, const u8 * __restrict__ pb, const u32 * __restrict__ hbits,
+__global__ void __launch_bounds__(RT_WAVES * WAVE) k_bwt_route(u32 n, const u32 * __restrict__ v, const u8 * __restrict__ pb, const u32 * __restrict__ hbits,
                                                               const u32 * __restrict__ carry_local, const u32 * __restrict__ group_carry,
                                                               const u8 * __restrict__ dirty, u32 * __restrict__ big_slot, u32 * __restrict__ big_hp, u32 big_cap,
                                                               u32 * __restrict__ mid_slot, u16 * __restrict__ mid_size, u32 mid_cap, u32 * __restrict__ tail_v,
                                                               u32 * __restrict__ tail_slot, u16 * __restrict__ tail_d, u8 * __restrict__ tail_pb, u32 tail_cap,
                                                               u32 * __restrict__ counters) {
-    __shared__ RtLds wl[WR_WAVES];
+    __shared__ RtLds wl[RT_WAVES];
+    __shared__ u32 ok[3];  // the workgroup's appends fit their lists
     const u32 lane = (u32)lane_id();
-    const u32 tile = blockIdx.x * WR_WAVES + (u32)wave_id();
+    const u32 tile = blockIdx.x * RT_WAVES + (u32)wave_id();
     const u64 a = (u64)tile * WR_A;
-    if (a >= n) return;
-    if (dirty && !(dirty[tile] | dirty[tile + 1])) return;
     RtLds & lds = wl[wave_id()];
+    const bool active = a < n && !(dirty && !(dirty[tile] | dirty[tile + 1]));
+    const u32 wend = !active ? 0u : ((u64)n - a < 1025ull ? (u32)((u64)n - a) : 1025u);  // window positions that exist (the first slot past the end is a head)
+    if (lane < 4u) lds.cnt[lane] = 0;
     // head bits of [a, a + 1024] from the snapshot; slots past the end are heads
-    if (lane < 33u) {
+    if (active && lane < 33u) {
         const u64 first = a + 32ull * lane;
         const u64 limit = ((u64)n + 63u) & ~63ull;  // the snapshot is written in whole 64-slot words
         lds.hb[lane] = first < limit ? hbits[first >> 5] : 0xFFFFFFFFu;
     }
     wave_sync();
-    const u32 wend = (u64)n - a < 1025ull ? (u32)((u64)n - a) : 1025u;  // window positions that exist (the first slot past the end is a head)
     // 64 head bits starting at window position `start` (may be negative: nothing is known before the window)
     auto bits64 = [&](int start) -> u64 {
         const int s0 = start < 0 ? 0 : start;
@@ -745,12 +711,13 @@ __global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_route(u32 n, const u32 
         return x;
     };
     // ---- groups of up to 64 suffixes go to the tail kernel (one suffix per lane, ~50 registers, dozens of waves per CU: measured four
-    // times the throughput per suffix of the wide path below).  Every slot decides for itself from the head bits around it: its group's
-    // head h (within 63 slots before it) and end e (within 64 after it); it goes if h lies in this wave's anchor slots, 2 <= e - h <= 64.
-    // One append per wave (an append per group made the list's counter the bottleneck: 200 ms).
-    {
-        u32 flags = 0, cnt = 0;  // bit k: position lane + 64 k goes
-        u64 row_ballot[9];
+    // times the throughput per suffix of the wide path).  Every slot decides for itself from the head bits around it: its group's head h
+    // (within 63 slots before it) and end e (within 64 after it); it goes if h lies in this wave's anchor slots and 2 <= e - h <= 64.
+    u32 flags = 0, tcnt = 0;  // bit k: position lane + 64 k goes
+    u64 row_ballot[9];
+    u32 row_base[9];
+    u32 nlg = 0;  // large groups / runs noted in lds.lg_*
+    if (active) {
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             const u32 p = lane + 64u * k;
@@ -764,71 +731,115 @@ __global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_route(u32 n, const u32 
             row_ballot[k] = __ballot(go);
             flags |= (go ? 1u : 0u) << k;
         }
-        u32 row_base[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) {
-            row_base[k] = cnt;
-            cnt += (u32)__popcll((unsigned long long)row_ballot[k]);
+            row_base[k] = tcnt;
+            tcnt += (u32)__popcll((unsigned long long)row_ballot[k]);
         }
-        if (cnt) {
-            u32 base = 0;
-            if (lane == 0) base = atomicAdd(&counters[4], cnt);
-            base = __shfl(base, 0);
-            if (base + cnt > tail_cap) {
+        // ---- the slots before the first head continue a group headed before this window (tile > 0: slot 0 is always a head)
+        u32 nmid = 0, nbig = 0;
+        const u32 c0 = wr_next_head(lds.hb, 0u);
+        if (c0 > 0u) {
+            const u32 cl = carry_local[tile], cg = group_carry[tile / (u32)SP_GROUP];
+            const u32 hp = (cl > cg ? cl : cg) - 1u;  // (tile > 0: slot 0 is a head, so there is one)
+            const bool big = c0 == WR_FAR || (u32)a + c0 - hp > (u32)WR_G;
+            u32 stop = c0 < (u32)WR_A ? c0 : (u32)WR_A;
+            stop = stop < wend ? stop : wend;
+            if (big && stop > 0u) {
                 if (lane == 0) {
-                    counters[3] = 1u;
-                    atomicMin(&counters[5], base);  // the list is valid up to the first append that did not fit
-                    atomicAdd(&counters[1], cnt);
+                    lds.lg_c[nlg] = 0;
+                    lds.lg_e[nlg] = (u16)stop;
+                    lds.lg_hp[nlg] = hp;
                 }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 9; k++)
-                    if ((flags >> k) & 1u) {
-                        const u32 p = lane + 64u * k;
-                        const u32 d = base + row_base[k] + (u32)__popcll((unsigned long long)(row_ballot[k] & (((u64)1 << lane) - 1ull)));
-                        const u64 slot = a + p;
-                        tail_v[d] = (v[slot] & V_MASK) | (((lds.hb[p >> 5] >> (p & 31u)) & 1u) ? V_HEAD : 0u);
-                        tail_slot[d] = (u32)slot;
-                        tail_d[d] = 0;  // the tail kernel walks the windows the group was formed on
-                        tail_pb[d] = pb[slot];
-                    }
+                nlg++;
+                nbig += stop;
             }
         }
-    }
-    // ---- the slots before the first head continue a group headed before this window (tile > 0: slot 0 is always a head)
-    const u32 c0 = wr_next_head(lds.hb, 0u);
-    if (c0 > 0u) {
-        const u32 cl = carry_local[tile], cg = group_carry[tile / (u32)SP_GROUP];
-        const u32 hp = (cl > cg ? cl : cg) - 1u;  // (tile > 0: slot 0 is a head, so there is one)
-        const bool big = c0 == WR_FAR || (u32)a + c0 - hp > (u32)WR_G;
-        const u32 stop = c0 < (u32)WR_A ? c0 : (u32)WR_A;
-        if (big) wr_emit_big(big_slot, big_hp, big_cap, counters, a, 0u, stop < wend ? stop : wend, hp);
-    }
-    // ---- groups of more than 64 headed here: a descriptor for the wide kernel (up to 512 members), or the big list
-    for (u32 k = 0; k < 8u; k++) {
-        const u32 p = lane + 64u * k;
-        const bool head = (lds.hb[p >> 5] >> (p & 31u)) & 1u;
-        u64 large = __ballot(head && p < wend && bits64((int)p + 1) == 0ull);  // no other head within the next 64 slots
-        while (large) {
-            const u32 l = (u32)__ffsll((unsigned long long)large) - 1u;
-            large &= large - 1ull;
-            const u32 c = l + 64u * k;
-            const u32 nh = wr_next_head(lds.hb, c + 1u);  // end of the group
-            if (nh == WR_FAR || nh - c > (u32)WR_G) {     // too large for a wave
-                const u32 stop = nh < (u32)WR_A ? nh : (u32)WR_A;
-                wr_emit_big(big_slot, big_hp, big_cap, counters, a, c, stop < wend ? stop : wend, (u32)a + c);
-                continue;
-            }
-            if (lane == 0) {
-                const u32 d = atomicAdd(&counters[8], 1u);
-                if (d < mid_cap) {
-                    mid_slot[d] = (u32)a + c;
-                    mid_size[d] = (u16)((nh < wend ? nh : wend) - c);
-                } else {  // cannot happen (the list holds n / 65 groups); the group stays as it is
-                    counters[3] = 1u;
-                    atomicAdd(&counters[1], nh - c);
+        // ---- groups of more than 64 headed here: a descriptor for the wide kernel (up to 512 members), or the big list
+        for (u32 k = 0; k < 8u; k++) {
+            const u32 p = lane + 64u * k;
+            const bool head = (lds.hb[p >> 5] >> (p & 31u)) & 1u;
+            u64 large = __ballot(head && p < wend && bits64((int)p + 1) == 0ull);  // no other head within the next 64 slots
+            while (large) {
+                const u32 l = (u32)__ffsll((unsigned long long)large) - 1u;
+                large &= large - 1ull;
+                const u32 c = l + 64u * k;
+                const u32 nh = wr_next_head(lds.hb, c + 1u);  // end of the group
+                const bool big = nh == WR_FAR || nh - c > (u32)WR_G;  // too large for a wave
+                u32 stop = big ? (nh < (u32)WR_A ? nh : (u32)WR_A) : nh;
+                stop = stop < wend ? stop : wend;
+                if (lane == 0) {
+                    lds.lg_c[nlg] = (u16)c;
+                    lds.lg_e[nlg] = (u16)stop;
+                    lds.lg_hp[nlg] = big ? (u32)a + c : 0xFFFFFFFFu;
                 }
+                nlg++;
+                if (big) nbig += stop - c;
+                else nmid++;
             }
+        }
+        if (lane == 0) {
+            lds.cnt[0] = tcnt;
+            lds.cnt[1] = nmid;
+            lds.cnt[2] = nbig;
+        }
+    }
+    __syncthreads();
+    // ---- one reservation per list for the whole workgroup
+    if (threadIdx.x < 3u) {
+        const u32 q = threadIdx.x;
+        u32 tot = 0;
+        for (int w = 0; w < RT_WAVES; w++) {
+            wl[w].base[q] = tot;
+            tot += wl[w].cnt[q];
+        }
+        u32 fits = 1;
+        if (tot) {
+            u32 * ctr = q == 0 ? &counters[4] : q == 1 ? &counters[8] : &counters[0];
+            const u32 cap = q == 0 ? tail_cap : q == 1 ? mid_cap : big_cap;
+            const u32 b0 = atomicAdd(ctr, tot);
+            fits = b0 + tot <= cap ? 1u : 0u;
+            if (!fits) {
+                counters[3] = 1u;
+                if (q == 0) atomicMin(&counters[5], b0);  // the tail list is valid up to the first append that did not fit
+                if (q != 2) atomicAdd(&counters[1], 1u);  // (suffixes that stay where they are: the deep path takes them)
+            }
+            for (int w = 0; w < RT_WAVES; w++) wl[w].base[q] += b0;
+        }
+        ok[q] = fits;
+    }
+    __syncthreads();
+    if (!active) return;
+    if (tcnt && ok[0]) {
+        const u32 base = lds.base[0];
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+            if ((flags >> k) & 1u) {
+                const u32 p = lane + 64u * k;
+                const u32 d = base + row_base[k] + (u32)__popcll((unsigned long long)(row_ballot[k] & (((u64)1 << lane) - 1ull)));
+                const u64 slot = a + p;
+                tail_v[d] = (v[slot] & V_MASK) | (((lds.hb[p >> 5] >> (p & 31u)) & 1u) ? V_HEAD : 0u);
+                tail_slot[d] = (u32)slot;
+                tail_d[d] = 0;  // the tail kernel walks the windows the group was formed on
+                tail_pb[d] = pb[slot];
+            }
+    }
+    u32 dm = lds.base[1], db = lds.base[2];
+    for (u32 i = 0; i < nlg; i++) {
+        const u32 c = lds.lg_c[i], e = lds.lg_e[i], hp = lds.lg_hp[i];
+        if (hp == 0xFFFFFFFFu) {
+            if (ok[1] && lane == 0) {
+                mid_slot[dm] = (u32)a + c;
+                mid_size[dm] = (u16)(e - c);
+            }
+            dm++;
+        } else {
+            if (ok[2])
+                for (u32 q = c + lane; q < e; q += WAVE) {
+                    big_slot[db + (q - c)] = (u32)a + q;
+                    big_hp[db + (q - c)] = hp;
+                }
+            db += e - c;
         }
     }
 }
@@ -841,16 +852,59 @@ __global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_wide(const u8 * __restr
                                                              u32 * __restrict__ counters, u32 chain) {
     __shared__ u32 tab[256];
     __shared__ WrLds wl[WR_WAVES];
+    __shared__ u32 pend[WR_WAVES], pbase[WR_WAVES], pfit;
     tab[threadIdx.x] = vlc[threadIdx.x];
-    __syncthreads();  // the only workgroup barrier: from here on the waves do not know of each other
+    __syncthreads();
+    const u32 lane = (u32)lane_id();
     const u32 g = blockIdx.x * WR_WAVES + (u32)wave_id();
-    if (g >= nmid) return;
     WrLds & lds = wl[wave_id()];
-    const u32 L = mid_size[g];
-    WrCtx cx{t, n, v, pb, tab, counters, chain, (u64)mid_slot[g], tail_v, tail_slot, tail_d, tail_pb, tail_cap};
-    if (L <= 128u) wr_batch<2>(cx, lds, L);
-    else if (L <= 256u) wr_batch<4>(cx, lds, L);
-    else wr_batch<8>(cx, lds, L);
+    u32 pending = 0;
+    u64 slot0 = 0;
+    if (g < nmid) {
+        const u32 L = mid_size[g];
+        slot0 = mid_slot[g];
+        WrCtx cx{t, n, v, pb, tab, counters, chain, slot0, tail_v, tail_slot, tail_d, tail_pb, tail_cap};
+        if (L <= 128u) pending = wr_batch<2>(cx, lds, L);
+        else if (L <= 256u) pending = wr_batch<4>(cx, lds, L);
+        else pending = wr_batch<8>(cx, lds, L);
+    }
+    // ---- one append to the tail list per workgroup (an append per wave made the list's counter the bottleneck)
+    if (lane == 0) pend[wave_id()] = pending;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 tot = 0;
+        for (int w = 0; w < WR_WAVES; w++) {
+            pbase[w] = tot;
+            tot += pend[w];
+        }
+        u32 fits = 1;
+        if (tot) {
+            const u32 b0 = atomicAdd(&counters[4], tot);
+            fits = b0 + tot <= tail_cap ? 1u : 0u;
+            if (!fits) {
+                counters[3] = 1u;
+                atomicMin(&counters[5], b0);  // the list is valid up to the first append that did not fit
+                atomicAdd(&counters[1], tot);
+            }
+            for (int w = 0; w < WR_WAVES; w++) pbase[w] += b0;
+        }
+        pfit = fits;
+    }
+    __syncthreads();
+    const u32 base = pbase[wave_id()];
+    for (u32 q = lane; q < pending; q += WAVE) {
+        const u64 x = lds.pl[q];
+        if (pfit) {
+            tail_v[base + q] = pl_v(x) | (lds.hd[q] ? V_HEAD : 0u);
+            tail_slot[base + q] = (u32)(slot0 + lds.aux[q]);
+            tail_d[base + q] = (u16)pl_d(x);
+            tail_pb[base + q] = (u8)pl_p(x);
+        } else {  // back where they are: the deep path takes them
+            const u64 p = slot0 + lds.aux[q];
+            v[p] = pl_v(x) | (lds.hd[q] ? V_HEAD : 0u);
+            pb[p] = (u8)pl_p(x);
+        }
+    }
 }
 
 // ---- the tail: tiny groups that need many more windows ---------------------------------------------------------------------------
@@ -1442,7 +1496,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     bool deep = false;    // fall back to rank doubling
     u32 h_words[16];
     for (int pass = 0;; pass++) {
-        launch(k_bwt_route, dim3((tiles + WR_WAVES - 1) / WR_WAVES), dim3(WR_WAVES * WAVE), 0, s, n, (const u32 *)V, (const u8 *)pb, (const u32 *)hbits,
+        launch(k_bwt_route, dim3((tiles + RT_WAVES - 1) / RT_WAVES), dim3(RT_WAVES * WAVE), 0, s, n, (const u32 *)V, (const u8 *)pb, (const u32 *)hbits,
                (const u32 *)carry, (const u32 *)group_carry, (const u8 *)(pass ? dirty : nullptr), big_slot, big_hp, big_cap, mid_slot, mid_size, mid_cap, tail_v, tail_slot,
                tail_d, tail_pb, tail_cap, d_words);
         HIP_CHECK(hipMemcpyAsync(h_words, d_words, sizeof h_words, hipMemcpyDeviceToHost, s));
