@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bwt_vlc_keys(const u8 * __restrict
 // Resolve-kernel geometry: a workgroup owns the groups whose head lies in its RS_S anchor slots; such a group of <= TR_G suffixes
 // ends inside the TR_WIN-slot window.
 constexpr int WR_A = 512;     // anchor slots per wave
-constexpr int WR_G = 512;     // largest group a wave resolves (8 suffixes per lane)
+constexpr int WR_G = 256;     // largest group a wave resolves (4 suffixes per lane; with 8 the wide kernel needs 200 registers: two waves per SIMD)
 constexpr int WR_WAVES = 4;   // waves per workgroup (independent of each other after the code table is loaded)
 constexpr int WR_CAP = 160;   // resolve steps before a group is left to the deep path
 constexpr int TL_CAP = 160;   // tail steps before a group is left to the deep path (>= 800 symbols)
@@ -865,8 +865,7 @@ __global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_wide(const u8 * __restr
         slot0 = mid_slot[g];
         WrCtx cx{t, n, v, pb, tab, counters, chain, slot0, tail_v, tail_slot, tail_d, tail_pb, tail_cap};
         if (L <= 128u) pending = wr_batch<2>(cx, lds, L);
-        else if (L <= 256u) pending = wr_batch<4>(cx, lds, L);
-        else pending = wr_batch<8>(cx, lds, L);
+        else pending = wr_batch<4>(cx, lds, L);
     }
     // ---- one append to the tail list per workgroup (an append per wave made the list's counter the bottleneck)
     if (lane == 0) pend[wave_id()] = pending;
