@@ -68,6 +68,8 @@ def _declare(L):
         "bz3_hip_stage_bwt": (i32, [vp, vp, i32]),
         "bz3_hip_stage_unbwt": (i32, [vp, vp, i32, i32]),
         "bz3_hip_stage_last_ms": (C.c_float, []),
+        "bz3_hip_set_collect_window_us": (None, [C.c_int]),
+        "bz3_hip_debug_collected_batches": (C.c_uint, [C.c_int, C.POINTER(C.c_uint)]),
         "bz3_hip_stage_cm_encode": (i32, [vp, i32, vp]),
         "bz3_hip_stage_cm_decode": (None, [vp, i32, vp, i32]),
         "bz3_hip_stage_cm_decode_many": (C.c_float, [vp, i32, vp, i32, i32, vp]),

@@ -13,6 +13,7 @@
 // bz3_new() returns NULL and the stage hooks abort loudly.
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
@@ -57,20 +58,36 @@ struct DeviceCtx {
     static constexpr int AUX = 4;
     hipStream_t aux[AUX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_prep = nullptr, ev_d0[AUX] = {nullptr, nullptr, nullptr, nullptr}, ev_d1[AUX] = {nullptr, nullptr, nullptr, nullptr};
+    bool aux_ready = false;
     void ensure_aux() {  // caller holds mu
-        if (aux[0]) return;
-        HIP_CHECK(hipEventCreate(&ev_prep));
-        // experiments: BZ3_HIP_AUX_PRIO=1 creates the side streams with the highest stream priority (the serial kernels on them are
-        // latency-bound single workgroups whose run time grows from 0.75 s to 1.23 s beside the whole-GPU kernels of the group's stream)
-        int prio_least = 0, prio_greatest = 0;
-        const bool prio = getenv("BZ3_HIP_AUX_PRIO") != nullptr && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess &&
-                          prio_greatest != prio_least;
-        for (int k = 0; k < AUX; k++) {
-            if (prio) HIP_CHECK(hipStreamCreateWithPriority(&aux[k], hipStreamNonBlocking, prio_greatest));
-            else HIP_CHECK(hipStreamCreateWithFlags(&aux[k], hipStreamNonBlocking));
-            HIP_CHECK(hipEventCreate(&ev_d0[k]));
-            HIP_CHECK(hipEventCreate(&ev_d1[k]));
+        if (aux_ready) return;
+        // built into locals and committed only when everything exists: a failure half way must not leave a context whose first
+        // stream is there and whose events are not (every later call would record on null events)
+        hipStream_t st[AUX] = {nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t e0[AUX] = {nullptr, nullptr, nullptr, nullptr}, e1[AUX] = {nullptr, nullptr, nullptr, nullptr}, ep = nullptr;
+        try {
+            HIP_CHECK(hipEventCreate(&ep));
+            for (int k = 0; k < AUX; k++) {
+                HIP_CHECK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
+                HIP_CHECK(hipEventCreate(&e0[k]));
+                HIP_CHECK(hipEventCreate(&e1[k]));
+            }
+        } catch (...) {
+            if (ep) (void)hipEventDestroy(ep);
+            for (int k = 0; k < AUX; k++) {
+                if (st[k]) (void)hipStreamDestroy(st[k]);
+                if (e0[k]) (void)hipEventDestroy(e0[k]);
+                if (e1[k]) (void)hipEventDestroy(e1[k]);
+            }
+            throw;
         }
+        ev_prep = ep;
+        for (int k = 0; k < AUX; k++) {
+            aux[k] = st[k];
+            ev_d0[k] = e0[k];
+            ev_d1[k] = e1[k];
+        }
+        aux_ready = true;
     }
 
     // Swap buffers lent to "lean" states for the duration of a stage sequence (see bz3_hip_set_lean_states).
@@ -730,8 +747,11 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     const float cm_ms = run_cm_jobs(lead->ctx, arena, jobs, d_jobs, lead->stream, lead->ev0, lead->ev1,
                                     [](const CmEncodeJob * j, u32 nj, hipStream_t st, int variant) { cm_encode_batch(j, nj, st, variant); });
     for (s32 i = 0; i < n; i++) encode_finish(sts[i], cm_ms);
-    size_t slack = (size_t)1 << 30;
-    if (const char * e = getenv("BZ3_HIP_WS_KEEP_MB")) slack = (size_t)strtoull(e, nullptr, 10) << 20;  // tests / experiments
+    // Hand-back only where it matters: a workspace that a GPU-filling batch grew to tens of GB (the decode call that follows needs the
+    // room).  A stream of ordinary batches (the CLI, bz3_hip_encode_stream) keeps its workspace: a multi-GB hipMalloc plus a
+    // device-synchronising hipFree per call would cost more than the memory is worth.
+    size_t slack = (size_t)16 << 30;
+    if (const char * e = getenv("BZ3_HIP_WS_KEEP_MB")) slack = (size_t)strtoull(e, nullptr, 10) << 20;  // tests only
     if (lead->ctx->ws_cap > 2 * need + slack) {  // mostly LZP contexts of a large batch: hand the memory back (see above)
         HIP_CHECK(hipStreamSynchronize(s));  // the side streams are idle: every driver launch has been waited for
         (void)hipFree(lead->ctx->ws);
@@ -1112,12 +1132,19 @@ void for_each_device_group(bz3_state ** states, s32 n, F && f) {
         } catch (const HipError & e) {
             fprintf(stderr, "bzip3_amd: HIP failure '%s' at %s:%d\n", e.what, e.file, e.line);
             for (s32 j : idx) on_failure(states[j]);
-        } catch (const std::bad_alloc &) {
+        } catch (...) {  // bad_alloc, system_error, length_error ...: nothing may leave a worker thread (std::terminate)
             for (s32 j : idx) on_failure(states[j]);
         }
         g_groups_running.fetch_sub(1);
     };
     std::vector<std::thread> workers;
+    struct Joiner {  // whatever happens on the calling thread, the workers are joined before their std::thread objects die
+        std::vector<std::thread> & w;
+        ~Joiner() {
+            for (std::thread & t : w)
+                if (t.joinable()) t.join();
+        }
+    } joiner{workers};
     size_t spawned = 1;  // groups [1, spawned) run on a worker thread each, group 0 and the rest on this thread
     for (size_t g = 1; g < groups.size(); g++) {
         try {
@@ -1129,7 +1156,6 @@ void for_each_device_group(bz3_state ** states, s32 n, F && f) {
     }
     if (!groups.empty()) run(groups[0]);
     for (size_t g = spawned; g < groups.size(); g++) run(groups[g]);
-    for (std::thread & t : workers) t.join();
 }
 
 // Host-buffer API: the blocks of a group are staged through the states' d_io buffers inside the group's own thread, all
@@ -1139,7 +1165,7 @@ void stage_in(bz3_state * st, const void * host, size_t bytes, hipStream_t s) {
     try {
         ensure_io(st);
         if (bytes) HIP_CHECK(hipMemcpyAsync(st->d_io, host, bytes, hipMemcpyHostToDevice, s));
-    } catch (const HipError &) {
+    } catch (...) {  // HIP failure or bad_alloc from ensure_io: this block fails, the others of the group go on
         on_failure(st);
         st->skip = true;
     }
@@ -1341,14 +1367,104 @@ BZIP3_API void bz3_decode_blocks(struct bz3_state * states[], uint8_t * buffers[
     run_decode(states, (void **)buffers, buffer_sizes, sizes, orig_sizes, hdrs.data(), n, true);
 }
 
+// ---- single-block calls from several host threads ----------------------------------------------------------------------------
+// The reference's batch API IS "N threads, one bz3_encode_block each" (src/libbz3.c:831-856), and a binding that does its own
+// threading calls the single-block functions the same way.  Here a block's CM stage is a serial ~300 ns-per-byte recurrence that only
+// pays off with many blocks in ONE launch, and a group call holds its device for its whole duration: N concurrent single-block calls
+// would run as N launches one after the other.  So concurrent callers are COLLECTED: the first one in becomes the leader, waits a
+// short window (bz3_hip_set_collect_window_us, default 200 us -- nothing beside a block's milliseconds) for the others, and takes
+// everything that has arrived through bz3_encode_blocks / bz3_decode_blocks as one batch; callers that arrive while a batch runs form
+// the next one.  Same bytes, return values and error codes: a batch call treats its blocks independently.
+namespace {
+struct SingleReq {
+    bz3_state * st;
+    u8 * buffer;
+    size_t buffer_size;
+    s32 size, orig_size;
+    bool done = false;
+};
+struct Collector {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<SingleReq *> pending[2];  // [0] encode, [1] decode
+    bool leader[2] = {false, false};
+};
+Collector g_collect;
+std::atomic<int> g_collect_window_us{200};
+std::atomic<unsigned> g_collect_batches{0}, g_collect_largest{0};
+
+void run_collected(int kind, std::vector<SingleReq *> & batch) {
+    const s32 n = (s32)batch.size();
+    g_collect_batches.fetch_add(1u);
+    unsigned big = g_collect_largest.load();
+    while ((unsigned)n > big && !g_collect_largest.compare_exchange_weak(big, (unsigned)n)) {}
+    std::vector<bz3_state *> sts((size_t)n);
+    std::vector<u8 *> bufs((size_t)n);
+    std::vector<s32> sizes((size_t)n), orig((size_t)n);
+    std::vector<size_t> bsz((size_t)n);
+    for (s32 i = 0; i < n; i++) {
+        sts[(size_t)i] = batch[(size_t)i]->st;
+        bufs[(size_t)i] = batch[(size_t)i]->buffer;
+        sizes[(size_t)i] = batch[(size_t)i]->size;
+        orig[(size_t)i] = batch[(size_t)i]->orig_size;
+        bsz[(size_t)i] = batch[(size_t)i]->buffer_size;
+    }
+    if (kind == 0) {
+        bz3_encode_blocks(sts.data(), bufs.data(), sizes.data(), n);
+        for (s32 i = 0; i < n; i++) batch[(size_t)i]->size = sizes[(size_t)i];
+    } else {
+        bz3_decode_blocks(sts.data(), bufs.data(), bsz.data(), sizes.data(), orig.data(), n);
+    }
+}
+
+void collect(int kind, SingleReq & r) {
+    Collector & c = g_collect;
+    std::unique_lock<std::mutex> lk(c.mu);
+    c.pending[kind].push_back(&r);
+    while (!r.done) {
+        if (c.leader[kind]) {
+            c.cv.wait(lk);
+            continue;
+        }
+        c.leader[kind] = true;
+        const int win = g_collect_window_us.load();
+        if (win > 0) c.cv.wait_for(lk, std::chrono::microseconds(win), [] { return false; });  // the others arrive meanwhile (the lock is released)
+        std::vector<SingleReq *> batch;
+        batch.swap(c.pending[kind]);
+        lk.unlock();
+        try {
+            run_collected(kind, batch);
+        } catch (...) {  // (the batch calls do not throw; belt and braces: nobody may wait for ever)
+            for (SingleReq * q : batch) on_failure(q->st);
+        }
+        lk.lock();
+        for (SingleReq * q : batch) q->done = true;
+        c.leader[kind] = false;
+        c.cv.notify_all();
+    }
+}
+}  // namespace
+
+BZIP3_API void bz3_hip_set_collect_window_us(int us) { g_collect_window_us.store(us < 0 ? 200 : us); }
+BZIP3_API unsigned bz3_hip_debug_collected_batches(int reset, unsigned * largest) {  // batches run for single-block callers; *largest = blocks in the largest
+    if (largest) *largest = g_collect_largest.load();
+    const unsigned b = g_collect_batches.load();
+    if (reset) {
+        g_collect_batches.store(0);
+        g_collect_largest.store(0);
+    }
+    return b;
+}
+
 BZIP3_API int32_t bz3_encode_block(struct bz3_state * st, uint8_t * buffer, int32_t size) {
-    s32 sz = size;
-    bz3_encode_blocks(&st, &buffer, &sz, 1);
-    return sz;
+    SingleReq r{st, buffer, 0, size, 0};
+    collect(0, r);
+    return r.size;
 }
 
 BZIP3_API int32_t bz3_decode_block(struct bz3_state * st, uint8_t * buffer, size_t buffer_size, int32_t compressed_size, int32_t orig_size) {
-    bz3_decode_blocks(&st, &buffer, &buffer_size, &compressed_size, &orig_size, 1);
+    SingleReq r{st, buffer, buffer_size, compressed_size, orig_size};
+    collect(1, r);
     return st->result;
 }
 

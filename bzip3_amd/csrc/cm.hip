@@ -71,17 +71,6 @@ __device__ __forceinline__ void cm_raise_priority() {
 #endif
 }
 
-__device__ __forceinline__ void cm_set_priority2() {
-#ifndef BZ3_EMU
-    __builtin_amdgcn_s_setprio(2);
-#endif
-}
-__device__ __forceinline__ void cm_set_priority0() {
-#ifndef BZ3_EMU
-    __builtin_amdgcn_s_setprio(0);
-#endif
-}
-
 template <class M>
 __device__ __forceinline__ void cm_model_init(M & m) {  // begin(): :350-358
     for (int i = threadIdx.x; i < M::ROWS * 256; i += blockDim.x) m.c1[i] = 32768;
@@ -1311,7 +1300,6 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         // the directory byte value -> slot also lives in a register (lane k: entries 4k .. 4k+3): the lookup on a wrong guess is a
         // v_readlane instead of an LDS round trip on the path the walker waits for
         u32 rowreg = R ? reinterpret_cast<const u32 *>(rc.row_of)[lane] : 0u;
-        const bool redo_prio = ((jobs[blockIdx.x].debug >> 4) & 2u) != 0u;
         __syncthreads();  // barrier 0: table 0 is there
         for (u32 i = 1; i < n; i++) {
             u32 * __restrict__ pt = ptab[i & 1u];
@@ -1334,10 +1322,8 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
             if (c != g) {
                 // wrong guess: put the old counters back (the old values are still in `prev`), apply the real update
                 // and evaluate again.  The new c1 row differs from the row being repaired, so its read goes first.
-                // The walker WAITS for this (barrier 2): until then the block's critical path runs through these four waves, which
-                // share their SIMDs with the other blocks' model waves (whose speculation nobody waits for) -- experiment
-                // BZ3_CM_TUNE bit 1: they take issue priority 2 for the repair.
-                if (redo_prio) cm_set_priority2();
+                // (Issue priority for these waves during the repair -- the walker waits for it -- was measured in round 3: 804 -> 800 ns per
+                // byte at three per CU, nothing.)
                 u32 row = c;
                 bool give_up = false;
                 if (R) {
@@ -1374,7 +1360,6 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
                 if (on_g || cell2 != prev.p1) m.c1[prev.a1] = (u16)cell2;
                 cur = cm_evaluate(m, pt, node, c0, a1, p1, cell2, 0u);  // c != k1: the run counter restarts
                 __syncthreads();  // barrier 2: the corrected table of byte i is there
-                if (redo_prio) cm_set_priority0();
                 run_prev = 0;
             } else {
                 run_prev++;

@@ -216,11 +216,8 @@ void bwt_inverse(const u8 * d_in, u32 n, u32 idx, u8 * d_out, Arena & tmp, hipSt
     // round trips of 1.15 / 1.5 us, while the 268 M reads themselves need ~11 ms at the random-access rate the other kernels reach.
     // One splitter per 256 rows (the workspace is sized for it) cuts the longest segment to ~3.5 k steps and doubles the
     // lanes with a load in flight; the list ranking grows to n / 256 elements (tens of microseconds per jump round).
-    static const int max_log_stride = [] {  // experiments: BZ3_UB_LOG_STRIDE=10 is the round-2 measured configuration
-        const char * e = getenv("BZ3_UB_LOG_STRIDE");
-        const int v = e ? atoi(e) : 8;
-        return v >= 8 && v <= 10 ? v : 8;  // the workspace holds n / 256 splitters
-    }();
+    // (measured in round 3 on a 256 MiB block: the two walks 14.6 ms per block at one splitter per 256 rows, 21.0 ms at one per 1024)
+    constexpr int max_log_stride = 8;
     int log_stride = 0;
     while (log_stride < max_log_stride && ((u64)rows >> (log_stride + 1)) >= 65536) log_stride++;
     const dim3 grows((rows + UB_BLOCK - 1) / UB_BLOCK);

@@ -93,6 +93,12 @@ BZIP3_API void bz3_hip_last_timings(struct bz3_state * state, float ms[BZ3_HIP_T
 /* BWT statistics of the last encoded block: doubling rounds, radix passes, elements pushed through the sorter. */
 BZIP3_API void bz3_hip_last_bwt_stats(struct bz3_state * state, int32_t * rounds, int32_t * radix_passes, uint64_t * sorted_elements);
 
+/* Single-block calls (bz3_encode_block / bz3_decode_block) that arrive from several host threads within this window are collected into
+ * ONE batch per direction (the reference's own batch API is N threads with one block each, src/libbz3.c:831-856; here a batch is one
+ * CM launch instead of N).  Default 200 us; 0 = no waiting (callers that arrive while a batch runs still form the next batch). */
+BZIP3_API void bz3_hip_set_collect_window_us(int us);
+BZIP3_API unsigned bz3_hip_debug_collected_batches(int reset, unsigned * largest); /* statistics: batches run for single-block callers */
+
 /* ---- per-stage hooks on HOST buffers (tests / profiling).  Return values mirror the reference stage. */
 BZIP3_API uint32_t bz3_hip_stage_crc32c(const uint8_t * data, size_t n, uint32_t init);             /* crc32sum        */
 BZIP3_API int32_t bz3_hip_stage_mrle_encode(const uint8_t * in, int32_t n, uint8_t * out);          /* mrlec           */

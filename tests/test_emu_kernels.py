@@ -761,3 +761,66 @@ def test_suffix_sorter_deep_path_for_big_groups(emu, oracle, monkeypatch):
     t = datagen.shakespeare()
     d = t[40000:70000] + t[40000:52000]
     assert bzip3_amd.encode_block(d, 65 * 1024, emu)[2] == oracle.encode_block(d, 65 * 1024)[2]
+
+
+def test_single_block_calls_from_many_threads_are_collected(oracle):
+    """Eight host threads call bz3_encode_block / bz3_decode_block at once on states of their own (what the reference's batch API does
+    with pthreads, src/libbz3.c:831-856, and what a threaded binding does): the calls are collected into ONE batch per direction --
+    one CM launch, not eight one after the other --, every thread gets the oracle's bytes and return values, and a failing block
+    (too much data) fails alone.  A process of its own: the collector's window is widened so that the test does not depend on timing."""
+    import subprocess
+
+    code = r'''
+import sys, threading, ctypes as C
+sys.path[:0] = [%r, %r, %r]
+import bzip3_amd, datagen
+from build_emu import build
+from oracle_lib import Oracle
+lib = bzip3_amd._declare(C.CDLL(build()))
+o = Oracle()
+bs = 65 * 1024
+t = datagen.shakespeare()
+n = 8
+blocks = [t[i * 5000 : i * 5000 + 3000 + 11 * i] for i in range(n)]
+states = [lib.bz3_new(bs) for _ in range(n)]
+cap = lib.bz3_bound(bs) + 64
+bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+for b, d in zip(bufs, blocks):
+    C.memmove(b, d, len(d))
+sizes = [len(d) for d in blocks]
+sizes[5] = bs + 1  # too much data for its state
+lib.bz3_hip_set_collect_window_us(300000)
+lib.bz3_hip_debug_collected_batches(1, None)
+ret = [None] * n
+def enc(i):
+    ret[i] = lib.bz3_encode_block(states[i], bufs[i], sizes[i])
+th = [threading.Thread(target=enc, args=(i,)) for i in range(n)]
+[x.start() for x in th]; [x.join() for x in th]
+big = C.c_uint(0)
+assert lib.bz3_hip_debug_collected_batches(1, C.byref(big)) == 1 and big.value == n, (big.value,)
+for i, d in enumerate(blocks):
+    if i == 5:
+        assert ret[i] == -1 and lib.bz3_last_error(states[i]) == bzip3_amd.BZ3_ERR_DATA_TOO_BIG
+        continue
+    want = o.encode_block(d, bs)
+    assert ret[i] == want[0] and lib.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: ret[i]]) == want[2], i
+enc5 = o.encode_block(blocks[5], bs)[2]
+C.memmove(bufs[5], enc5, len(enc5)); ret[5] = len(enc5)
+back = [None] * n
+def dec(i):
+    back[i] = lib.bz3_decode_block(states[i], bufs[i], cap, ret[i], len(blocks[i]))
+th = [threading.Thread(target=dec, args=(i,)) for i in range(n)]
+[x.start() for x in th]; [x.join() for x in th]
+assert lib.bz3_hip_debug_collected_batches(1, C.byref(big)) == 1 and big.value == n
+for i, d in enumerate(blocks):
+    assert back[i] == len(d) and lib.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: len(d)]) == d, i
+# one caller alone: a batch of one, the same bytes
+lib.bz3_hip_set_collect_window_us(-1)
+C.memmove(bufs[0], blocks[0], len(blocks[0]))
+assert lib.bz3_encode_block(states[0], bufs[0], len(blocks[0])) == o.encode_block(blocks[0], bs)[0]
+for s in states:
+    lib.bz3_free(s)
+print("ok")
+''' % (os.path.dirname(HERE), HERE, os.path.join(HERE, "emu"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-300:], r.stderr[-1500:])

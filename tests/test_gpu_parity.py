@@ -297,6 +297,64 @@ def test_suffix_sorter_paths_on_gpu(gpu_lib, oracle, monkeypatch):
     assert g.bwt(d) == oracle.bwt(d)
 
 
+def test_batch_over_all_gpus_of_the_node(gpu_lib, oracle, text):
+    """bz3_encode_blocks / bz3_decode_blocks with states on EVERY visible GPU (the reference forks a thread per block,
+    src/libbz3.c:845-870): bz3_new round-robins the states over the devices, the batch is split into one group per GPU and the groups
+    run at the same time (api.hip for_each_device_group).  Oracle bytes both ways, as many groups inside their group function at once
+    as there are devices, and the batch takes no longer than 1.3 x the same per-GPU load on one GPU alone.  Skipped on a 1-GPU lease:
+    it costs nothing there, and it is the only hardware evidence of row (e) when the node has more."""
+    import time
+
+    ndev = gpu_lib.bz3_hip_device_count()
+    if ndev < 2:
+        pytest.skip("one visible GPU: the multi-device path needs at least two (the emulator suite runs it with two emulated devices)")
+    bs = 4 << 20
+    per_dev = 6
+    pieces = [text[(i * 700001) % (len(text) - bs) :][:bs - 1000 * i] for i in range(per_dev * ndev)]
+
+    def run(blocks):
+        n = len(blocks)
+        states = (C.c_void_p * n)(*[gpu_lib.bz3_new(bs) for _ in range(n)])
+        assert all(states)
+        cap = gpu_lib.bz3_bound(bs) + 64
+        bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+        for b, d in zip(bufs, blocks):
+            C.memmove(b, d, len(d))
+        ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+        sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+        gpu_lib.bz3_hip_debug_peak_concurrent_groups(1)
+        t0 = time.perf_counter()
+        gpu_lib.bz3_encode_blocks(states, ptrs, sizes, n)
+        t_enc = time.perf_counter() - t0
+        peak_enc = gpu_lib.bz3_hip_debug_peak_concurrent_groups(1)
+        coded = [bytes(bufs[i][: sizes[i]]) for i in range(n)]
+        assert all(gpu_lib.bz3_last_error(states[i]) == 0 for i in range(n))
+        bsz = (C.c_size_t * n)(*[cap] * n)
+        orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+        t0 = time.perf_counter()
+        gpu_lib.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+        t_dec = time.perf_counter() - t0
+        peak_dec = gpu_lib.bz3_hip_debug_peak_concurrent_groups(1)
+        assert all(gpu_lib.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: len(d)]) == d for i, d in enumerate(blocks))
+        devs = sorted(gpu_lib.bz3_hip_state_device(s) for s in states)
+        for s in states:
+            gpu_lib.bz3_free(s)
+        return coded, t_enc + t_dec, min(peak_enc, peak_dec), devs
+
+    gpu_lib.bz3_hip_bind_device(-1)  # round robin over the visible devices
+    run(pieces[:ndev])               # first touch of every device (contexts, streams) outside the timed calls
+    coded, t_all, peak, devs = run(pieces)
+    assert devs == sorted(list(range(ndev)) * per_dev), devs
+    assert peak == ndev, f"{peak} device groups ran at the same time, {ndev} devices"
+    for d, c in zip(pieces, coded):
+        assert c == oracle.encode_block(d, bs)[2]
+    gpu_lib.bz3_hip_bind_device(0)
+    _, t_one, _, devs1 = run(pieces[:per_dev])  # the same per-GPU load on one GPU
+    gpu_lib.bz3_hip_bind_device(-1)
+    assert set(devs1) == {0}
+    assert t_all < 1.3 * t_one + 0.5, f"{ndev} GPUs x {per_dev} blocks took {t_all:.2f}s, one GPU x {per_dev} blocks {t_one:.2f}s"
+
+
 def test_device_resident_api(gpu_lib, oracle, text):
     import torch
 
