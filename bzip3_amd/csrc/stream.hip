@@ -93,11 +93,15 @@ struct Pipe {
     std::vector<std::vector<u8 *>> bufs;      // [slot][block]: host buffers of bz3_bound(block_size) bytes
     Batch batch[SLOTS];
     Lane to_reader, to_coder, to_writer;
+    bool pinned = false;                      // the buffers are page-locked (hipHostMalloc): the copies of a batch run at the link's rate
 
     ~Pipe() {
         for (bz3_state * s : states) bz3_free(s);
         for (auto & v : bufs)
-            for (u8 * p : v) free(p);
+            for (u8 * p : v) {
+                if (pinned) (void)hipHostFree(p);
+                else free(p);
+            }
     }
     bool init(s32 bs, s32 nb) {
         block_size = bs;
@@ -109,11 +113,20 @@ struct Pipe {
             states.push_back(s);
         }
         bufs.assign(SLOTS, std::vector<u8 *>());
+        // Page-locked buffers (the reference's buffers are plain malloc, main.c:227-228, so the staging has to be the
+        // backend's business) while the three slots stay within 16 GiB; beyond that pageable memory: pinning tens of GB of a host
+        // is not this library's call.
+        pinned = (size_t)SLOTS * (size_t)nb * cap <= ((size_t)16 << 30);
         for (int k = 0; k < SLOTS; k++) {
             batch[k].size.assign((size_t)nb, 0);
             batch[k].orig.assign((size_t)nb, 0);
             for (s32 i = 0; i < nb; i++) {
-                u8 * p = (u8 *)malloc(cap);
+                u8 * p = nullptr;
+                if (pinned) {
+                    if (hipHostMalloc((void **)&p, cap, hipHostMallocDefault) != hipSuccess) p = nullptr;
+                } else {
+                    p = (u8 *)malloc(cap);
+                }
                 if (!p) return false;
                 bufs[(size_t)k].push_back(p);
             }

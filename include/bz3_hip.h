@@ -17,6 +17,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include "libbz3.h"
+#define BZ3_HIP 1 /* this libbzip3 is the HIP implementation: the bz3_hip_* entry points exist */
 
 #ifdef __cplusplus
 extern "C" {
