@@ -1971,7 +1971,7 @@ BZIP3_API float bz3_hip_stage_cm_decode_many(const uint8_t * in, int32_t in_size
         HIP_CHECK(hipEventCreate(&e0));
         HIP_CHECK(hipEventCreate(&e1));
         HIP_CHECK(hipEventRecord(e0, e.s));
-        cm_decode_batch(d_jobs, (u32)copies, e.s, variant);
+        cm_decode_batch(d_jobs, (u32)copies, e.s, variant, (debug & 15u) == 3u);
         HIP_CHECK(hipEventRecord(e1, e.s));
         HIP_CHECK(hipStreamSynchronize(e.s));
         float ms = 0.f;

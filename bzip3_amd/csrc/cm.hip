@@ -47,6 +47,18 @@ __device__ __forceinline__ u32 cm_readlane(u32 v, int lane) {
 #endif
 }
 
+// A zero the compiler cannot see through: what is derived from it stays in vector registers (a wave-uniform counter that would
+// otherwise live in an SGPR and cost a v_mov at every use as a store offset).
+__device__ __forceinline__ u32 cm_opaque_zero() {
+#ifdef BZ3_EMU
+    return 0;
+#else
+    u32 z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+#endif
+}
+
 // Tells the compiler a value is wave-uniform so that it lives in scalar registers and branches on it
 // are scalar branches (the serial coder recurrences run entirely on the scalar unit).
 __device__ __forceinline__ u32 cm_uniform(u32 v) {
@@ -54,6 +66,15 @@ __device__ __forceinline__ u32 cm_uniform(u32 v) {
     return v;
 #else
     return (u32)__builtin_amdgcn_readfirstlane((int)v);
+#endif
+}
+
+// a * b for operands below 2^24: one full-rate v_mul_u32_u24 / v_mad_u32_u24 (a 32-bit v_mul_lo_u32 runs at quarter rate)
+__device__ __forceinline__ u32 cm_mul24(u32 a, u32 b) {
+#ifdef BZ3_EMU
+    return a * b;
+#else
+    return __umul24(a, b);
 #endif
 }
 
@@ -266,7 +287,7 @@ __device__ __forceinline__ void cm_chain_step(M & m, CmEvent * __restrict__ ev_r
         const u32 a1 = c1s + path, a2 = c2s + path;     // C1 indices (c1 * 256 + node)
         const u32 p1 = m.c1[a1];
         const u32 p2 = m.c1[a2];
-        const u32 p = ((p0 + p1) * 7u + 2u * p2) >> 4;  // :380
+        const u32 p = (cm_mul24(p0 + p1, 7u) + 2u * p2) >> 4;  // :380 (p0 + p1 < 2^17)
         const u32 ci = (2u * path + f) * CM_C2_STRIDE + (p >> 12);
         const u32 w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[ci]));  // x1 | x2 << 16 (cells j, j+1)
         const u32 na = cm_upd(p0, 2, mk & 16383u);      // :396-399 / :411-414
@@ -719,7 +740,7 @@ __device__ __forceinline__ CmEval cm_evaluate(const M & m, u32 * __restrict__ pt
     CmEval e;
     e.a1 = a1;
     e.p1 = p1;
-    const int p = (int)(((c0 + p1) * 7u + 2u * p2) >> 4);
+    const int p = (int)((cm_mul24(c0 + p1, 7u) + 2u * p2) >> 4);  // (c0 + p1 < 2^17)
     e.ci = (2u * node + f) * CM_C2_STRIDE + (u32)(p >> 12);
     e.w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[e.ci]));
     const int x1 = (int)(e.w & 0xFFFFu), x2 = (int)(e.w >> 16);
@@ -1151,7 +1172,7 @@ __device__ __forceinline__ void cm_decode_block_lockstep(const CmDecodeJob * __r
         const u32 a1 = row1 * 256u + node;
         const u32 p1 = m.c1[a1];
         const u32 p2 = m.c1[row2 * 256u + node];
-        const int p = (int)(((c0 + p1) * 7u + 2u * p2) >> 4);
+        const int p = (int)((cm_mul24(c0 + p1, 7u) + 2u * p2) >> 4);  // (c0 + p1 < 2^17)
         const u32 ci = (2u * node + f) * CM_C2_STRIDE + (u32)(p >> 12);
         const u32 w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[ci]));  // x1 | x2 << 16
         {
@@ -1264,13 +1285,26 @@ __device__ __forceinline__ void cm_decode_block_lockstep(const CmDecodeJob * __r
 // register allocation up to what its LDS-derived occupancy estimate allows -- 97 VGPRs for 50 KB, i.e. four waves per SIMD --
 // and three five-wave workgroups then no longer fit a CU although their LDS does (measured: the 320-thread decoders ran two per
 // CU, the third waited for a second round; tools/occupancy_probe.hip shows that the hardware co-schedules the shape happily).
-template <int R>
+// Address space of the LDS: a pointer of this kind is 32 bits wide and every access through it a ds_ instruction (a generic pointer
+// would be 64 bits and its accesses flat_ instructions).  The emulator's LDS is ordinary memory.
+#ifdef BZ3_EMU
+#define CM_LDS
+#else
+#define CM_LDS __attribute__((address_space(3)))
+#endif
+struct CmEvalP {              // CmEval with the cells remembered by address
+    CM_LDS u16 * a1;          // C1[c1][node]
+    u32 p1;                   // its value
+    CM_LDS PackedU32 * ci;    // the first of the two C2 cells
+    u32 w;                    // both cells, x1 | x2 << 16
+};
+
+template <int R, bool PROF>  // PROF: cycle counters instead of the first output bytes (profiling only, BZ3_CM_DEBUG=3)
 __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restrict__ jobs, CmLdsT<R> & m) {
     const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 in_size = jobs[blockIdx.x].in_size;
     u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
     const u32 n = jobs[blockIdx.x].n;
-    const u32 debug = jobs[blockIdx.x].debug & 15u;  // 3: cycle counters instead of the first output bytes (profiling only)
     __shared__ u32 ptab[2][256];  // (18-bit probability of node) << 14
     __shared__ u32 s_done[2];     // [i & 1] = byte i, written by the walker before barrier 1 of byte i.  Two words: after a right guess the
                                   // walker decodes byte i+1 and stores it while a model wave that was held up may not have read byte i yet
@@ -1282,16 +1316,49 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
     if (n == 0) return;
     const int lane = lane_id();
     const u32 role = cm_uniform((u32)wave_id());
+    u32 hw_id = 0, xcc_id = 0;  // PROF: where the hardware put this wave (HW_ID: wave, SIMD, CU, SE; XCC_ID), u32[22 + 2 * role] of the output
+#ifndef BZ3_EMU
+    if (PROF) {
+        hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
     if (role != 0) {
         // ---- model waves ------------------------------------------------------------------------------------
+        // These four waves are three quarters of the workgroup's instructions, and at three blocks per CU the waves of a SIMD take turns:
+        // a model wave's instruction costs ~8 cycles, so the ~50 instructions of a byte with a right guess are what the walker (80) has to
+        // hide.  Hence: LDS cells are remembered as address-space-3 POINTERS (the address that read a cell also writes it back: no index
+        // arithmetic), the two C2 rows of the node (run flag 0 / 1) are pointers that only change when the flag does, both order-1
+        // counters of the speculative table are the same cell (7 c0 + 9 cell), and two bytes are unrolled per loop trip.
         const u32 node = threadIdx.x - 64u;
         const u32 lvl = node ? (u32)(31 - __clz((int)node)) : 0u;
         const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
+        const u32 nodelow = node ^ hibit;  // the bits of a byte that lead to this node, i.e. byte >> shr (lane 0 of wave 1 owns no node: nodelow = 1 > byte >> 8)
         u32 c0 = 32768u;  // the node's C0 counter lives in a register
+        CM_LDS u16 * const c1col = (CM_LDS u16 *)&m.c1[node];                                // C1[slot 0][node]; slot s is 512 bytes further
+        CM_LDS u16 * const c2row0 = (CM_LDS u16 *)&m.c2[(2u * node) * CM_C2_STRIDE];         // run flag 0
+        CM_LDS u16 * const c2row1 = (CM_LDS u16 *)&m.c2[(2u * node + 1u) * CM_C2_STRIDE];    // run flag 1
+        CM_LDS u32 * const ptab0 = (CM_LDS u32 *)&ptab[0][node];
+        CM_LDS u32 * const ptab1 = (CM_LDS u32 *)&ptab[1][node];
+        // Probability of the node (:377-388) into *pt, given 16 p = (c0 + p1) * 7 + 2 * p2 and the node's C2 row for the run flag.
+        auto evaluate = [&](CM_LDS u32 * pt, CM_LDS u16 * a1, u32 p1, u32 p16, CM_LDS u16 * c2row) __attribute__((always_inline)) -> CmEvalP {
+            CmEvalP e;
+            e.a1 = a1;
+            e.p1 = p1;
+            e.ci = (CM_LDS PackedU32 *)(c2row + (p16 >> 16));  // p >> 12
+            e.w = e.ci->v;                                     // x1 | x2 << 16 (cells j, j + 1)
+            const int p = (int)(p16 >> 4);
+            const int x1 = (int)(e.w & 0xFFFFu), x2 = (int)(e.w >> 16);
+            const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);
+            *pt = (cm_mul24((u32)ssep, 3u) + (u32)p) << 14;    // (ssep < 2^16)
+            return e;
+        };
         // byte 0: nothing to guess (c1 = c2 = 0, run = 1, :367-372)
-        CmEval prev = cm_evaluate(m, ptab[0], node, c0, node, m.c1[node], m.c1[node], 0u);
+        const u32 first = *c1col;
+        CmEvalP prev = evaluate(ptab0, c1col, first, cm_mul24(c0 + first, 7u) + 2u * first, c2row0);
         u32 k1 = 0;        // newest confirmed byte (byte i-2 inside the loop; the initial c1 = 0 before the block starts)
         u32 run_prev = 1;  // run counter the evaluation of byte i-1 was made with
+        CM_LDS u16 * c2row = c2row0;  // the C2 row for the run flag of the NEXT speculative evaluation (flag = run_prev + 1 > 2)
         CmRowCache<R> & rc = rcs[R ? role - 1 : 0];
         CmRowState rs;
         u16 * __restrict__ spill = global_ptr<u16>(jobs[blockIdx.x].spill);
@@ -1300,72 +1367,107 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         // the directory byte value -> slot also lives in a register (lane k: entries 4k .. 4k+3): the lookup on a wrong guess is a
         // v_readlane instead of an LDS round trip on the path the walker waits for
         u32 rowreg = R ? reinterpret_cast<const u32 *>(rc.row_of)[lane] : 0u;
+        u64 mprof_spec = 0, mprof_wait = 0, mprof_redo = 0;  // PROF
         __syncthreads();  // barrier 0: table 0 is there
-        for (u32 i = 1; i < n; i++) {
-            u32 * __restrict__ pt = ptab[i & 1u];
+        // One byte: `prev` = what the evaluation of byte i-1 left, `cur` receives that of byte i.  Two bytes per loop trip with the two
+        // records swapping roles, so that neither they nor the table buffer / the s_done word of a byte cost a move or an address
+        // computation (BUF = i & 1 is a compile-time constant).  Returns false when the block was given up.
+        auto step = [&](const u32 i, auto buf_tag, const CmEvalP & prev, CmEvalP & cur) __attribute__((always_inline)) -> bool {
+            constexpr u32 BUF = decltype(buf_tag)::value;
+            CM_LDS u32 * const pt = BUF ? ptab1 : ptab0;
+            bool give_up = false;
+            u64 m0 = 0, m1 = 0, m2 = 0;
+            if (PROF) m0 = cm_clock();
             // -- speculate: byte i-1 == k1.  Update of byte i-1 (:396-399, :411-414; branch-free, see cm_upd) ...
             const u32 g = k1;
-            const bool on_g = (hibit | (g >> shr)) == node;
+            const bool on_g = (g >> shr) == nodelow;
             const u32 c0_old = c0;
             u32 cell = prev.p1;  // C1[k1][node]: byte i-1 was evaluated with c1 = k1, so this is the cell its update moves
             if (on_g) {
                 const u32 mk = 0u - ((g >> bitpos) & 1u);
                 c0 = cm_upd(c0, 2, mk & 16383u);
                 cell = cm_upd(prev.p1, 4, mk & 4095u);
-                m.c1[prev.a1] = (u16)cell;
-                reinterpret_cast<PackedU32 *>(&m.c2[prev.ci])->v = cm_upd_pair6(prev.w, mk & 0x03FF03FFu);
+                *prev.a1 = (u16)cell;
+                prev.ci->v = cm_upd_pair6(prev.w, mk & 0x03FF03FFu);
             }
             // ... and the table of byte i with c1 = g, c2 = k1: both order-1 counters are `cell`, the run counter goes up
-            CmEval cur = cm_evaluate(m, pt, node, c0, prev.a1, cell, cell, run_prev + 1u > 2u ? 1u : 0u);
+            run_prev++;
+            if (__builtin_expect(run_prev == 3u, 0)) c2row = c2row1;
+            cur = evaluate(pt, prev.a1, cell, cm_mul24(cell, 9u) + cm_mul24(c0, 7u), c2row);
+            if (PROF) m1 = cm_clock();
             __syncthreads();  // barrier 1: the walker has decoded byte i-1
-            const u32 c = cm_uniform(LDS_PEEK(s_done[(i - 1u) & 1u])) & 0xFFu;
+            const u32 c = cm_uniform(LDS_PEEK(s_done[BUF ^ 1u]));
+            if (PROF) {
+                m2 = cm_clock();
+                mprof_spec += m1 - m0;
+                mprof_wait += m2 - m1;
+            }
+            k1 = c;
             if (c != g) {
                 // wrong guess: put the old counters back (the old values are still in `prev`), apply the real update
                 // and evaluate again.  The new c1 row differs from the row being repaired, so its read goes first.
                 // (Issue priority for these waves during the repair -- the walker waits for it -- was measured in round 3: 804 -> 800 ns per
                 // byte at three per CU, nothing.)
                 u32 row = c;
-                bool give_up = false;
                 if (R) {
                     row = (cm_readlane(rowreg, (int)(c >> 2)) >> (8u * (c & 3u))) & 0xFFu;
                     if (__builtin_expect(row >= CM_ROW_SPILLED, 0)) {
                         // the only row still needed is the one of byte i-2 (prev.a1 points into it): pin it
                         rs.tick++;
-                        if (lane == 0) rc.stamp[cm_uniform(prev.a1 >> 8)] = rs.tick;
+                        if (lane == 0) rc.stamp[cm_uniform((u32)(prev.a1 - c1col) >> 8)] = rs.tick;
                         wave_sync();
                         row = cm_rows_fetch<R, 1>(m, rc, rs, spill, c, row, node);
                         rowreg = reinterpret_cast<const u32 *>(rc.row_of)[lane];
-                        give_up = rs.misses > miss_base + (i >> miss_shift);  // the working set does not fit (every model wave gets here at the same byte)
+                        if (__builtin_expect(rs.misses > miss_base + (i >> miss_shift), 0)) {
+                            // the working set does not fit (every model wave gets here at the same byte): the block is given up.  The repair
+                            // below still runs -- no second way out of this branch, the compiler pays for one with moves on every path --
+                            // and the walker reads s_abort behind barrier 2
+                            give_up = true;
+                            if (threadIdx.x == 64) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
+                            LDS_POKE(s_abort, 1u);
+                        }
                     }
                 }
-                if (__builtin_expect(give_up, 0)) {
-                    if (threadIdx.x == 64) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
-                    LDS_POKE(s_abort, 1u);
-                    __syncthreads();  // barrier 2: the walker reads s_abort behind it
-                    return;
-                }
-                const u32 a1 = row * 256u + node;
-                const u32 p1 = m.c1[a1];
+                CM_LDS u16 * const a1 = c1col + row * 256u;
+                const u32 p1 = *a1;
                 u32 cell2 = prev.p1;
                 if (on_g) {
                     c0 = c0_old;
-                    reinterpret_cast<PackedU32 *>(&m.c2[prev.ci])->v = prev.w;
+                    prev.ci->v = prev.w;
                 }
-                if ((hibit | (c >> shr)) == node) {
+                if ((c >> shr) == nodelow) {
                     const u32 mk = 0u - ((c >> bitpos) & 1u);
                     c0 = cm_upd(c0, 2, mk & 16383u);
                     cell2 = cm_upd(prev.p1, 4, mk & 4095u);
-                    reinterpret_cast<PackedU32 *>(&m.c2[prev.ci])->v = cm_upd_pair6(prev.w, mk & 0x03FF03FFu);
+                    prev.ci->v = cm_upd_pair6(prev.w, mk & 0x03FF03FFu);
                 }
-                if (on_g || cell2 != prev.p1) m.c1[prev.a1] = (u16)cell2;
-                cur = cm_evaluate(m, pt, node, c0, a1, p1, cell2, 0u);  // c != k1: the run counter restarts
+                if (on_g || cell2 != prev.p1) *prev.a1 = (u16)cell2;
+                c2row = c2row0;  // c != k1: the run counter restarts
+                cur = evaluate(pt, a1, p1, cm_mul24(c0 + p1, 7u) + 2u * cell2, c2row0);
+                if (R) wave_sync();  // (test emulation: a row fetch de-synchronises the fibers of a wave; no instruction on the GPU)
+                if (PROF) mprof_redo += cm_clock() - m2;  // up to the arrival at barrier 2
                 __syncthreads();  // barrier 2: the corrected table of byte i is there
                 run_prev = 0;
-            } else {
-                run_prev++;
             }
-            prev = cur;
-            k1 = c;
+            return !give_up;
+        };
+        CmEvalP other = prev;
+        for (u32 i = 1; i < n;) {
+            if (!step(i, CmConst<1>{}, prev, other)) return;
+            if (++i >= n) break;
+            if (!step(i, CmConst<0>{}, other, prev)) return;
+            ++i;
+        }
+        if (PROF && n >= 256 && threadIdx.x == 64) {  // profiling only: model wave 1's phases (cycles) at u64[8..10] of the output
+            u64 * o = reinterpret_cast<u64 *>(out) + 8;
+            o[0] = mprof_spec;
+            o[1] = mprof_wait;
+            o[2] = mprof_redo;
+        }
+        if (PROF && n >= 256 && lane == 0) {
+            u32 * o = reinterpret_cast<u32 *>(out) + 22 + 2 * role;
+            o[0] = hw_id;
+            o[1] = xcc_id;
         }
         return;
     }
@@ -1373,6 +1475,18 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
     // The walker is the critical path of its block: highest issue priority among the waves of its SIMD.  Measured with three blocks
     // per CU (the other blocks' model waves share the SIMD): 918 -> 805 ns per byte and block (profiles/r02_cm_priority.txt);
     // BZ3_CM_TUNE bit 3 switches it off.
+    //
+    // A single wave issues one instruction every 5-8 cycles whatever it is, so the walker's instruction count per byte IS its time
+    // (round 3: the loop the compiler made of the first version spent 165 instructions on a byte, 40 of them scalar moves between the
+    // arms of its control flow).  What keeps the count down:
+    //  * validity without votes: a lane that took a wrong turn ends with d > range and stays there (assumed 1 but d > t: range' = t < d;
+    //    assumed 0 but d <= t: d' = d - t - 1 wraps above range' = range - t - 1; once d > range both ways keep it, and so do the two
+    //    real levels, which then decode 0s), the lane on the true path keeps d <= range -- so the six speculated levels are mul_hi + four
+    //    ALU operations each, and a comparison every other level names the surviving lane.  An invalid lane whose range reached zero
+    //    can wrap back to d <= range (range - t - 1 with range = t = 0): more than one survivor sends the byte to the checked walk;
+    //  * two bytes per loop trip, so that the table buffer, the s_done word and the LDS offsets of a byte are compile-time constants;
+    //  * every lane stores the decoded byte to the same address (one instruction; its offset is a vector counter);
+    //  * the cycle counters are a separate kernel instantiation (PROF).
     if (!((jobs[blockIdx.x].debug >> 4) & 8u)) cm_raise_priority();
     const u32 ul = (u32)lane;
     const bool as0 = (ul >> 5) & 1u, as1 = (ul >> 4) & 1u, as2 = (ul >> 3) & 1u, as3 = (ul >> 2) & 1u, as4 = (ul >> 1) & 1u, as5 = ul & 1u;
@@ -1387,91 +1501,137 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         CM_NEXT_BYTE(b);
         code = (code << 8) + b;
     }
-    u64 prof_wait = 0, prof_walk = 0, prof_slow = 0, prof_miss = 0;  // debug == 3
+    u64 prof_wait = 0, prof_walk = 0, prof_slow = 0, prof_miss = 0, prof_wait_miss = 0;  // PROF
+    u64 t0 = 0, t1 = 0;
     u32 P0, P1, P2, P3, P4, P5, P6, P7a, P7b;  // this lane's slice of the table of the byte being decoded
+    u32 vi = cm_opaque_zero();                 // the byte index as a vector register: the offset of the byte's store
 #define CM_SYNC_FETCH(BUF)                                                                            \
     do {                                                                                              \
         const u32 * __restrict__ pt_ = ptab[BUF];                                                     \
         P0 = pt_[ix0]; P1 = pt_[ix1]; P2 = pt_[ix2]; P3 = pt_[ix3]; P4 = pt_[ix4]; P5 = pt_[ix5];     \
         P6 = pt_[ix6]; P7a = pt_[ix7]; P7b = pt_[ix7 + 1u];                                           \
     } while (0)
-    __syncthreads();  // barrier 0
-    CM_SYNC_FETCH(0);
-    for (u32 i = 0; i < n; i++) {
-        u64 t0 = 0, t1 = 0;
-        if (debug == 3) t0 = cm_clock();
-        u32 c;
-        {
-            u32 range = range_u, low;  // per-lane copies of the wave-uniform coder state
-            u32 d = code - low_u;
-            const bool inside = d <= range_u;  // low <= code <= high: always, unless a truncated stream fed -1 bytes (:345)
-            u32 acc = 0;
-            bool bit6, bit7;
-            CM_FAST_SPEC(P0, nb0, as0);  // :453-489
-            CM_FAST_SPEC(P1, nb1, as1);
-            CM_FAST_SPEC(P2, nb2, as2);
-            CM_FAST_SPEC(P3, nb3, as3);
-            CM_FAST_SPEC(P4, nb4, as4);
-            CM_FAST_SPEC(P5, nb5, as5);
-            const u64 ok = __ballot(acc == ul);  // exactly one lane decoded the six bits it had assumed
-            u32 cbits = acc;
-            CM_FAST_REAL(P6, bit6);
-            const u32 P7f = bit6 ? P7b : P7a;
-            CM_FAST_REAL(P7f, bit7);
-            const int w = __ffsll((unsigned long long)ok) - 1;
-            const u32 low_f = code - cm_readlane(d, w), range_f = cm_readlane(range, w);
-            if (__builtin_expect(inside && (low_f ^ (low_f + range_f)) >= (1u << 24), 1)) {
-                low_u = low_f;
-                range_u = range_f;
-                c = cm_readlane(cbits, w);
-            } else {  // a renormalisation was due on the true path: decode this byte again, checking every level
-                prof_slow++;
-                low = low_u;
-                range = range_u;
-                u64 valid = ~0ull;
-                CM_SPEC_LEVEL(P0, nb0, 0xFFFFFFFF00000000ull);
-                CM_SPEC_LEVEL(P1, nb1, 0xFFFF0000FFFF0000ull);
-                CM_SPEC_LEVEL(P2, nb2, 0xFF00FF00FF00FF00ull);
-                CM_SPEC_LEVEL(P3, nb3, 0xF0F0F0F0F0F0F0F0ull);
-                CM_SPEC_LEVEL(P4, nb4, 0xCCCCCCCCCCCCCCCCull);
-                CM_SPEC_LEVEL(P5, nb5, 0xAAAAAAAAAAAAAAAAull);
-                CM_REAL_LEVEL(P6, bit6);
-                const u32 P7 = bit6 ? P7b : P7a;
-                CM_REAL_LEVEL(P7, bit7);
-                const int w2 = __ffsll((unsigned long long)valid) - 1;  // exactly one lane survives
-                low_u = cm_readlane(low, w2);
-                range_u = cm_readlane(range, w2);
-                c = cm_readlane((ul << 2) | ((u32)bit6 << 1) | (u32)bit7, w2);
-            }
+// one speculated level of the fast walk: (range, d) along the lane's assumed bit, no comparison (see above)
+#define CM_WALK_SPEC(P, NB)                                                                           \
+    do {                                                                                              \
+        const u32 keep_ = range & (NB);                                                               \
+        const u32 t_ = (u32)(((u64)range * (P)) >> 32);            /* (range * p18) >> 18, :464 */    \
+        range = cm_xad(t_, (NB), keep_);                           /* t  |  range - t - 1 */          \
+        d = cm_xad(t_ | ~(NB), 0xFFFFFFFFu, d);                    /* d  |  d - t - 1     */          \
+    } while (0)
+// one decoded level: the lane takes the bit it decodes and shifts it into cb
+#define CM_WALK_REAL(P, BIT)                                                                          \
+    do {                                                                                              \
+        const u32 t_ = (u32)(((u64)range * (P)) >> 32);                                               \
+        BIT = d <= t_;                                                                                \
+        cb = cm_shift_in(cb, __ballot(BIT), BIT);                                                     \
+        range = BIT ? t_ : range + ~t_;                            /* t  |  range - t - 1 */          \
+        d = BIT ? d : d + ~t_;                                                                        \
+    } while (0)
+    // Decodes byte i from the table in P0..P7b; returns it.
+    auto walk = [&]() __attribute__((always_inline)) -> u32 {
+        u32 range = range_u, low;  // per-lane copies of the wave-uniform coder state
+        u32 d = code - low_u;
+        const bool inside = d <= range_u;  // low <= code <= high: always, unless a truncated stream fed -1 bytes (:345)
+        CM_WALK_SPEC(P0, nb0);  // :453-489
+        CM_WALK_SPEC(P1, nb1);
+        const u64 ok1 = __ballot(d <= range);
+        CM_WALK_SPEC(P2, nb2);
+        CM_WALK_SPEC(P3, nb3);
+        const u64 ok3 = __ballot(d <= range);
+        CM_WALK_SPEC(P4, nb4);
+        CM_WALK_SPEC(P5, nb5);
+        // the lane that decoded the six bits it had assumed.  (Tested every other level: a lane on an improbable wrong path often
+        // reaches range 0 within two levels and wraps at the next 0 it assumes -- with one test at the end 14 % of the bytes of
+        // text had a second "survivor" -- but between two tests it has no time for both.)
+        const u64 ok = ok1 & ok3 & __ballot(d <= range);
+        u32 cb = 0;
+        bool bit6, bit7;
+        CM_WALK_REAL(P6, bit6);
+        const u32 P7f = bit6 ? P7b : P7a;
+        CM_WALK_REAL(P7f, bit7);
+        const int w = __ffsll((unsigned long long)ok) - 1;
+        const u32 low_f = code - cm_readlane(d, w), range_f = cm_readlane(range, w);
+        // The fast result is committed unconditionally and the checked walk is a plain `if` without an `else`: with two arms the
+        // compiler routes every loop-carried value (code, the input window, ...) through copies on BOTH arms.
+        const u32 low_old = low_u, range_old = range_u;
+        u32 c = ((u32)w << 2) | cm_readlane(cb, w);
+        low_u = low_f;
+        range_u = range_f;
+        const bool good = inside & ((ok & (ok - 1ull)) == 0ull) & (ok != 0ull) & ((low_f ^ (low_f + range_f)) >= (1u << 24));
+        if (__builtin_expect(!good, 0)) {  // a renormalisation was due on the true path: decode this byte again, checking every level
+            if (PROF) prof_slow++;
+            low = low_old;
+            range = range_old;
+            u64 valid = ~0ull;
+            CM_SPEC_LEVEL(P0, nb0, 0xFFFFFFFF00000000ull);
+            CM_SPEC_LEVEL(P1, nb1, 0xFFFF0000FFFF0000ull);
+            CM_SPEC_LEVEL(P2, nb2, 0xFF00FF00FF00FF00ull);
+            CM_SPEC_LEVEL(P3, nb3, 0xF0F0F0F0F0F0F0F0ull);
+            CM_SPEC_LEVEL(P4, nb4, 0xCCCCCCCCCCCCCCCCull);
+            CM_SPEC_LEVEL(P5, nb5, 0xAAAAAAAAAAAAAAAAull);
+            CM_REAL_LEVEL(P6, bit6);
+            const u32 P7 = bit6 ? P7b : P7a;
+            CM_REAL_LEVEL(P7, bit7);
+            const int w2 = __ffsll((unsigned long long)valid) - 1;  // exactly one lane survives
+            low_u = cm_readlane(low, w2);
+            range_u = cm_readlane(range, w2);
+            c = cm_readlane((ul << 2) | ((u32)bit6 << 1) | (u32)bit7, w2);
         }
-        LDS_POKE(s_done[i & 1u], c);  // every lane stores the same word: no EXEC juggling on the critical path
-        if (debug == 3) t1 = cm_clock();
+        return c;
+    };
+    // What follows the walk of byte i (BUF = i & 1, a compile-time constant): hand the byte over, meet the model waves, fetch the next
+    // table.  Returns false when the loop ends (last byte, or the block was given up).
+    auto after = [&](const u32 i, const u32 c, auto buf_tag) __attribute__((always_inline)) -> bool {
+        constexpr u32 BUF = decltype(buf_tag)::value;
+        LDS_POKE(s_done[BUF], c);  // every lane stores the same word: no EXEC juggling on the critical path
+        if (PROF) t1 = cm_clock();
+        out[vi] = (u8)c;
+        vi++;
         const bool hit = c == c1;  // the models' guess for byte i was byte i-1 (0 before the block starts)
         c1 = c;
-        out[i] = (u8)c;  // every lane stores the same byte to the same address: one instruction, where collecting 64 bytes per lane costs six per byte
-        if (i + 1u < n) {
-            __syncthreads();  // barrier 1: the speculative table of byte i+1 is complete, the models read byte i
-            if (!hit) {
-                if (debug == 3) prof_miss++;
-                __syncthreads();  // barrier 2: the corrected table
-                if (R && LDS_PEEK(s_abort) != 0u) return;  // given up (R > 0)
-            }
-            CM_SYNC_FETCH((i + 1u) & 1u);
+        if (i + 1u == n) return false;
+        __syncthreads();  // barrier 1: the speculative table of byte i+1 is complete, the models read byte i
+        if (!hit) {
+            if (PROF) prof_miss++;
+            __syncthreads();  // barrier 2: the corrected table
+            if (R && LDS_PEEK(s_abort) != 0u) return false;  // given up (R > 0): the block is decoded again by the full-model kernel
         }
-        if (debug == 3) {
+        CM_SYNC_FETCH(BUF ^ 1u);
+        if (PROF) {
             const u64 t2 = cm_clock();
             prof_walk += t1 - t0;
             prof_wait += t2 - t1;
+            if (!hit) prof_wait_miss += t2 - t1;
         }
+        return true;
+    };
+    __syncthreads();  // barrier 0
+    CM_SYNC_FETCH(0);
+    u32 i = 0;
+    for (;;) {
+        if (PROF) t0 = cm_clock();
+        const u32 ca = walk();
+        if (!after(i, ca, CmConst<0>{})) break;
+        i++;
+        if (PROF) t0 = cm_clock();
+        const u32 cb2 = walk();
+        if (!after(i, cb2, CmConst<1>{})) break;
+        i++;
     }
-    if (debug == 3 && n >= 256 && lane == 0) {  // profiling only: output bytes 0..31 become counters
+    if (PROF && n >= 256 && lane == 0) {  // profiling only: output bytes 0..31 become counters
         u64 * o = reinterpret_cast<u64 *>(out);
         o[0] = prof_wait;
         o[1] = prof_walk;
         o[2] = prof_slow;
         o[3] = prof_miss;
+        o[4] = prof_wait_miss;  // the part of prof_wait spent behind wrong guesses
+        reinterpret_cast<u32 *>(out)[22] = hw_id;
+        reinterpret_cast<u32 *>(out)[23] = xcc_id;
     }
 #undef CM_SYNC_FETCH
+#undef CM_WALK_SPEC
+#undef CM_WALK_REAL
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1500,7 +1660,7 @@ struct CmNodeEval {
 template <class M>
 __device__ __forceinline__ CmNodeEval cm_evaluate_node(const M & m, u32 node, u32 c0, u32 p1, u32 p2, u32 f) {  // :377-388
     CmNodeEval e;
-    const int p = (int)(((c0 + p1) * 7u + 2u * p2) >> 4);
+    const int p = (int)((cm_mul24(c0 + p1, 7u) + 2u * p2) >> 4);  // (c0 + p1 < 2^17)
     e.ci = (2u * node + f) * CM_C2_STRIDE + (u32)(p >> 12);
     e.w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[e.ci]));
     const int x1 = (int)(e.w & 0xFFFFu), x2 = (int)(e.w >> 16);
@@ -1706,14 +1866,18 @@ __global__ void __launch_bounds__(64) k_cm_decode_solo3(const CmDecodeJob * __re
 #ifdef BZ3_EMU
 __global__ void __launch_bounds__(64) k_cm_decode_solo_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_solo_entry<CM_ROWS_TEST>(jobs); }
 #endif
-template <int R>
+template <int R, bool PROF = false>
 __device__ __forceinline__ void cm_decode_sync_entry(const CmDecodeJob * __restrict__ jobs) {
     BZ3_DYN_SMEM(dyn_lds);
-    cm_decode_block_sync<R>(jobs, *reinterpret_cast<CmLdsT<R> *>(dyn_lds));
+    cm_decode_block_sync<R, PROF>(jobs, *reinterpret_cast<CmLdsT<R> *>(dyn_lds));
 }
 __global__ void __launch_bounds__(320) k_cm_decode_sync(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<0>(jobs); }
 __global__ void __launch_bounds__(320) k_cm_decode_sync2(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS_DEC>(jobs); }
 __global__ void __launch_bounds__(320) k_cm_decode_sync3(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS3_DEC>(jobs); }
+// the same kernels with the walker's cycle counters (tools/cm_coresidency.py --cycles)
+__global__ void __launch_bounds__(320) k_cm_decode_sync_prof(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<0, true>(jobs); }
+__global__ void __launch_bounds__(320) k_cm_decode_sync2_prof(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS_DEC, true>(jobs); }
+__global__ void __launch_bounds__(320) k_cm_decode_sync3_prof(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS3_DEC, true>(jobs); }
 #ifdef BZ3_EMU
 __global__ void __launch_bounds__(320) k_cm_decode_sync_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS_TEST>(jobs); }
 #endif
@@ -1736,7 +1900,7 @@ void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int v
     else launch(k_cm_encode, dim3(njobs), dim3(256), 0, s, d_jobs);
 }
 
-void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant) {
+void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant, bool prof) {
     if (!njobs) return;
 #ifdef BZ3_EMU
     if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_decode_rows_test, dim3(njobs), dim3(320), 0, s, d_jobs);
@@ -1754,15 +1918,17 @@ void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int v
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_solo2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<CM_ROWS_SOLO2>)));
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_sync), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<0>)));
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_sync2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<CM_ROWS_DEC>)));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_sync_prof), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<0>)));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_sync2_prof), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<CM_ROWS_DEC>)));
             word.fetch_or(bit);
         }
     }
 #endif
     if (variant == CM_VARIANT_SOLO3) launch(k_cm_decode_solo3, dim3(njobs), dim3(64), sizeof(CmLdsT<CM_ROWS_SOLO3>), s, d_jobs);
     else if (variant == CM_VARIANT_SOLO2) launch(k_cm_decode_solo2, dim3(njobs), dim3(64), sizeof(CmLdsT<CM_ROWS_SOLO2>), s, d_jobs);
-    else if (variant == CM_VARIANT_SYNC) launch(k_cm_decode_sync, dim3(njobs), dim3(320), sizeof(CmLdsT<0>), s, d_jobs);
-    else if (variant == CM_VARIANT_SYNC2) launch(k_cm_decode_sync2, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS_DEC>), s, d_jobs);
-    else if (variant == CM_VARIANT_SYNC3) launch(k_cm_decode_sync3, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS3_DEC>), s, d_jobs);
+    else if (variant == CM_VARIANT_SYNC) launch(prof ? k_cm_decode_sync_prof : k_cm_decode_sync, dim3(njobs), dim3(320), sizeof(CmLdsT<0>), s, d_jobs);
+    else if (variant == CM_VARIANT_SYNC2) launch(prof ? k_cm_decode_sync2_prof : k_cm_decode_sync2, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS_DEC>), s, d_jobs);
+    else if (variant == CM_VARIANT_SYNC3) launch(prof ? k_cm_decode_sync3_prof : k_cm_decode_sync3, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS3_DEC>), s, d_jobs);
     else if (variant == CM_VARIANT_LOCK3) launch(k_cm_decode_lock3, dim3(njobs), dim3(256), 0, s, d_jobs);
     else if (variant == CM_VARIANT_LOCK2) launch(k_cm_decode_lock2, dim3(njobs), dim3(256), 0, s, d_jobs);
     else if (variant == CM_VARIANT_ROWS3) launch(k_cm_decode_rows3, dim3(njobs), dim3(320), 0, s, d_jobs);

@@ -135,6 +135,6 @@ inline bool cm_variant_has_rows(int v) { return v != CM_VARIANT_FULL && v != CM_
 inline bool cm_variant_is_test(int v) { return v == CM_VARIANT_ROWS_TEST || v == CM_VARIANT_LOCK_TEST || v == CM_VARIANT_SYNC_TEST || v == CM_VARIANT_SOLO_TEST; }
 constexpr size_t CM_SPILL_BYTES = 256 * 256 * 2;
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL);
-void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL);
+void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL, bool prof = false);  // prof: the sync decoders' cycle-counter build
 
 }  // namespace bz3

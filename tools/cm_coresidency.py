@@ -56,8 +56,10 @@ def main():
                     print(json.dumps(rec), flush=True)
                     continue
                 rec["walker_cyc_per_byte"] = {"wait": round(a[0] / n, 1), "walk": round(a[1] / n, 1)}
+                if name.startswith("sync") and a[3] > 0 and n > a[3]:  # wait per right / per wrong guess
+                    rec["walker_wait_cyc"] = {"per_right_guess": round((a[0] - a[4]) / (n - a[3]), 1), "per_wrong_guess": round(a[4] / a[3], 1)}
                 rec["walker_share"] = {"slow_path": round(a[2] / n, 3), "wrong_guess": round(a[3] / n, 3)}
-                if not name.startswith("sync"):
+                if True:
                     rec["model_wave_cyc_per_byte"] = {"speculate": round(a[8] / n, 1), "wait": round(a[9] / n, 1), "redo": round(a[10] / n, 1)}
             print(json.dumps(rec), flush=True)
     os.environ.pop("BZ3_CM_DEBUG", None)
