@@ -78,6 +78,27 @@ __device__ __forceinline__ u32 cm_mul24(u32 a, u32 b) {
 #endif
 }
 
+// a * b + c for a, b below 2^24, as the one full-rate instruction it is (left to the compiler, `cm_mul24(a, b) + c` becomes a
+// quarter-rate v_mul_lo_u32 or v_mad_u64_u32 whenever it cannot prove the operand ranges itself)
+__device__ __forceinline__ u32 cm_mad24(u32 a, u32 b, u32 c) {
+#ifdef BZ3_EMU
+    return a * b + c;
+#else
+    u32 r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#endif
+}
+
+// bits [lo, lo + width) of v: one v_bfe_u32 (the compiler does not know the value ranges that make `(v >> lo)` enough)
+__device__ __forceinline__ u32 cm_bfe(u32 v, u32 lo, u32 width) {
+#ifdef BZ3_EMU
+    return (v >> lo) & ((1u << width) - 1u);
+#else
+    return __builtin_amdgcn_ubfe(v, lo, width);
+#endif
+}
+
 // Nothing is scheduled across this point (keeps a prefetch where it is written instead of at the top of its basic block).
 __device__ __forceinline__ void cm_sched_fence() {
 #ifndef BZ3_EMU
@@ -1345,12 +1366,21 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
             CmEvalP e;
             e.a1 = a1;
             e.p1 = p1;
-            e.ci = (CM_LDS PackedU32 *)(c2row + (p16 >> 16));  // p >> 12
+#ifdef BZ3_EMU
+            e.ci = (CM_LDS PackedU32 *)(c2row + cm_bfe(p16, 16, 4));  // cell p >> 12 of the row
+#else
+            {  // the same in two instructions (the compiler's own rendering of the line above takes three)
+                u32 j, a;
+                asm("v_bfe_u32 %0, %1, 16, 4" : "=v"(j) : "v"(p16));
+                asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(a) : "v"(j), "v"((u32)(__UINTPTR_TYPE__)c2row));
+                e.ci = (CM_LDS PackedU32 *)(__UINTPTR_TYPE__)a;
+            }
+#endif
             e.w = e.ci->v;                                     // x1 | x2 << 16 (cells j, j + 1)
             const int p = (int)(p16 >> 4);
             const int x1 = (int)(e.w & 0xFFFFu), x2 = (int)(e.w >> 16);
             const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);
-            *pt = (cm_mul24((u32)ssep, 3u) + (u32)p) << 14;    // (ssep < 2^16)
+            *pt = cm_mad24((u32)ssep, 3u, (u32)p) << 14;       // (ssep < 2^16)
             return e;
         };
         // byte 0: nothing to guess (c1 = c2 = 0, run = 1, :367-372)
@@ -1393,7 +1423,7 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
             // ... and the table of byte i with c1 = g, c2 = k1: both order-1 counters are `cell`, the run counter goes up
             run_prev++;
             if (__builtin_expect(run_prev == 3u, 0)) c2row = c2row1;
-            cur = evaluate(pt, prev.a1, cell, cm_mul24(cell, 9u) + cm_mul24(c0, 7u), c2row);
+            cur = evaluate(pt, prev.a1, cell, cm_mad24(cell, 9u, cm_mad24(c0, 7u, 0u)), c2row);
             if (PROF) m1 = cm_clock();
             __syncthreads();  // barrier 1: the walker has decoded byte i-1
             const u32 c = cm_uniform(LDS_PEEK(s_done[BUF ^ 1u]));
@@ -1441,9 +1471,9 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
                     cell2 = cm_upd(prev.p1, 4, mk & 4095u);
                     prev.ci->v = cm_upd_pair6(prev.w, mk & 0x03FF03FFu);
                 }
-                if (on_g || cell2 != prev.p1) *prev.a1 = (u16)cell2;
+                *prev.a1 = (u16)cell2;  // (unconditionally: storing the value that is there already costs less than finding out)
                 c2row = c2row0;  // c != k1: the run counter restarts
-                cur = evaluate(pt, a1, p1, cm_mul24(c0 + p1, 7u) + 2u * cell2, c2row0);
+                cur = evaluate(pt, a1, p1, cm_mad24(c0 + p1, 7u, 2u * cell2), c2row0);
                 if (R) wave_sync();  // (test emulation: a row fetch de-synchronises the fibers of a wave; no instruction on the GPU)
                 if (PROF) mprof_redo += cm_clock() - m2;  // up to the arrival at barrier 2
                 __syncthreads();  // barrier 2: the corrected table of byte i is there
