@@ -86,6 +86,7 @@ def parse():
                     help="wall budget from process start: steps/warmup are clamped and the extra legs skipped so that the run ends before it")
     ap.add_argument("--deadline-s", type=float, default=float(os.environ.get("BZ3_BENCH_DEADLINE_S", "1690")),
                     help="hard deadline: the watchdog prints the JSON line as measured so far and exits")
+    ap.add_argument("--lib", default=None, help="another build of libbzip3.so (same-box A/B of two code states; never used by the driver)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cfg3 / random legs")
     ap.add_argument("--cpu-threads", type=int, default=64)
@@ -383,6 +384,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     lib = bzip3_amd.load()
+    if a.lib:
+        lib = bzip3_amd.load(a.lib)
     assert lib.bz3_hip_device_count() > 0, "no HIP device"
     assert lib.bz3_hip_bind_device(local_rank) == 0
     assert lib.bz3_hip_set_cm_mode(CM_MODES[a.cm_mode]) == 0

@@ -1,5 +1,5 @@
 """How do CM decoder variants behave when several blocks share a CU?  (GPU box, no torch import.)
-    python tools/cm_coresidency.py [MiB=2] [copies ...=256 512 768] [--cycles]
+    python tools/cm_coresidency.py [MiB=2] [copies ...=256 512 768] [--cycles] [--only=a,b] [--lib=path]
 For every variant (full, rows, rows3, lock2, lock3) and every number of identical blocks: ONE launch of the CM decoder over
 `copies` copies of the same coded block (bz3_hip_stage_cm_decode_many), launch time by HIP events, ns per byte and block,
 aggregate MiB/s.  --cycles additionally runs the guess-ahead variants with BZ3_CM_DEBUG=3 and prints the decoder's phase
@@ -26,7 +26,8 @@ def main():
     copies = [int(a) for a in args[1:]] or [256, 512, 768]
     cycles = "--cycles" in sys.argv
     n = int(mib * (1 << 20))
-    lib = bzip3_amd.load()
+    libs = [a[len("--lib="):] for a in sys.argv if a.startswith("--lib=")]  # --lib=<path>: another build of the library (same-box A/B)
+    lib = bzip3_amd.load(libs[0]) if libs else bzip3_amd.load()
     assert lib.bz3_hip_device_count() > 0
     g = bzip3_amd.StageApi(lib)
     assert lib.bz3_hip_set_cm_mode(0) == 0
