@@ -59,7 +59,7 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 ALG_BYTES_ROUND_TRIP = 32.4  # 17.2 B/B encode + 15.2 B/B decode
 ALG_BYTES_BWT = 11.0
 CFG3_BYTES = 1_000_000_000  # BASELINE.json configs[2]: "enwik9 (1 GB), -b 256, single MI355X"
-CM_MODES = {"auto": -1, "full": 0, "rows": 1, "rows3": 2, "lock3": 3, "lock2": 4, "sync": 5, "sync2": 6, "sync3": 7, "solo2": 8, "solo3": 12, "measured": 100}
+CM_MODES = {"auto": -1, "full": 0, "rows": 1, "rows3": 2}
 
 T_START = time.perf_counter()
 RANK = int(os.environ.get("RANK", "0"))
@@ -79,7 +79,7 @@ def parse():
     ap.add_argument("--kind", default="text", choices=["text", "random"])
     ap.add_argument("--cm-mode", default=os.environ.get("BZ3_BENCH_CM_MODE", "auto"), choices=sorted(CM_MODES),
                     help="CM kernel variant (bz3_hip_set_cm_mode): auto = the library's policy; full = whole model in LDS, one block per CU; "
-                         "rows / rows3 / lock2 / lock3 = row-cache kernels, two / three blocks per CU")
+                         "rows / rows3 = row-cache kernels, two / three blocks per CU")
     ap.add_argument("--lean", type=int, default=int(os.environ.get("BZ3_BENCH_LEAN", "-1")),
                     help="lean states (bz3_hip_set_lean_states): 1 = no per-state swap buffer, in-place CM encode (room for 3x256 blocks of 256 MiB); -1 = by block count")
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("BZ3_BENCH_BUDGET_S", "1500")),
@@ -389,7 +389,7 @@ def main():
     assert lib.bz3_hip_device_count() > 0, "no HIP device"
     assert lib.bz3_hip_bind_device(local_rank) == 0
     assert lib.bz3_hip_set_cm_mode(CM_MODES[a.cm_mode]) == 0
-    per_cu = {"rows": 2, "lock2": 2, "sync2": 2, "rows3": 3, "lock3": 3, "sync3": 3, "solo3": 3, "solo2": 2, "measured": 3, "auto": 3, "full": 1, "sync": 1}[a.cm_mode]  # blocks per CU the mode is made for
+    per_cu = {"rows": 2, "rows3": 3, "auto": 3, "full": 1}[a.cm_mode]  # blocks per CU the mode is made for
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     nblk = a.blocks if a.blocks > 0 else cus * per_cu
     lean = a.lean == 1 or (a.lean < 0 and nblk > cus)
@@ -581,10 +581,8 @@ def main():
         # launching stream (api.hip run_cm_jobs).
         dec_dominant = cm_dec_ms >= cm_enc_ms
         dom_ms = cm_dec_ms if dec_dominant else cm_enc_ms
-        enc_names = {0: "k_cm_encode", 1: "k_cm_encode_rows", 2: "k_cm_encode_rows3", 3: "k_cm_encode_rows3", 4: "k_cm_encode_rows", 5: "k_cm_encode", 6: "k_cm_encode_rows",
-                     7: "k_cm_encode_rows3", 8: "k_cm_encode_rows", 12: "k_cm_encode_rows3"}
-        dec_names = {0: "k_cm_decode", 1: "k_cm_decode_rows", 2: "k_cm_decode_rows3", 3: "k_cm_decode_lock3", 4: "k_cm_decode_lock2", 5: "k_cm_decode_sync", 6: "k_cm_decode_sync2",
-                     7: "k_cm_decode_sync3", 8: "k_cm_decode_solo2", 12: "k_cm_decode_solo3"}
+        enc_names = {0: "k_cm_encode", 1: "k_cm_encode_rows", 2: "k_cm_encode_rows3"}
+        dec_names = {0: "k_cm_decode_sync", 1: "k_cm_decode_sync2", 2: "k_cm_decode_sync3"}
         kern = (dec_names if dec_dominant else enc_names)[lib.bz3_hip_cm_variant_for(local_rank, nblk, 0 if dec_dominant else 1)]
         cm_bytes = n_dec * nblk + comp_total
         # HBM traffic of the dominant kernel from the PMC pass (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs,
@@ -662,7 +660,7 @@ def main():
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "bytes_per_input_byte": ALG_BYTES_ROUND_TRIP,
             },
             "bwt_roofline": {
-                "stage": "bwt_forward (radix-sort prefix doubling), one block",
+                "stage": "bwt_forward (one 56-bit code-window radix sort + in-LDS group resolution), one block",
                 "achieved": round(ALG_BYTES_BWT * block_size / (bwt_ms * 1e-3) / 1e9, 3),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ALG_BYTES_BWT * block_size / (bwt_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),

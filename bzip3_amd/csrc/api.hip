@@ -207,16 +207,9 @@ size_t workspace_bytes_for(u64 n) {
 }
 
 // ---- CM kernel variant -------------------------------------------------------------------------------
-// The full-model CM kernels need a whole CU's LDS per block; the row-cache kernels (cm.hip) need half or a third of
-// it, so two or three blocks share a CU, but they give up blocks whose order-1 working set does not fit (binary
-// data).  Measured on MI355X (profiles/r01_cm_rows_probe.txt; time of one launch relative to one block per CU):
-//   encode  two blocks per CU 1.30x, three 1.59x   (throughput x1.54 / x1.89)
-//   decode  two blocks per CU 2.07x, three 2.2x    (throughput x0.97 / x1.36)
-// Policy (BZ3_HIP_CM_MODE=auto|full|rows|rows3|lock2|lock3|measured, bz3_hip_set_cm_mode): `auto` picks by batch size, see
-// cm_variant_for().  (Round 1 kept the row-cache kernels opt-in because two probe runs had stalled; the cause -- a one-word
-// mailbox in the guess-ahead decoder that a delayed model wave could miss -- was found with the emulator's hostile
-// scheduler and fixed, and round 2 re-ran every variant at 256 / 512 / 768 blocks on the GPU.)
-constexpr int CM_MODE_MEASURED = 100;
+// The full-model CM kernels need a whole CU's LDS per block; the row-cache kernels (cm.hip) need half or a third of it, so two or
+// three blocks share a CU, but they give up blocks whose order-1 working set does not fit (binary data), which are then coded again
+// by the full-model kernel.  Policy (BZ3_HIP_CM_MODE=auto|full|rows|rows3, bz3_hip_set_cm_mode): `auto` picks by batch size.
 std::atomic<int> g_cm_mode{-2};  // -2 = not read from the environment yet, -1 = auto, else CM_VARIANT_*
 
 int cm_mode() {
@@ -227,14 +220,6 @@ int cm_mode() {
         if (e && !strcmp(e, "full")) m = CM_VARIANT_FULL;
         else if (e && !strcmp(e, "rows")) m = CM_VARIANT_ROWS;
         else if (e && !strcmp(e, "rows3")) m = CM_VARIANT_ROWS3;
-        else if (e && !strcmp(e, "lock3")) m = CM_VARIANT_LOCK3;
-        else if (e && !strcmp(e, "lock2")) m = CM_VARIANT_LOCK2;
-        else if (e && !strcmp(e, "sync")) m = CM_VARIANT_SYNC;
-        else if (e && !strcmp(e, "sync2")) m = CM_VARIANT_SYNC2;
-        else if (e && !strcmp(e, "sync3")) m = CM_VARIANT_SYNC3;
-        else if (e && !strcmp(e, "solo2")) m = CM_VARIANT_SOLO2;
-        else if (e && !strcmp(e, "solo3")) m = CM_VARIANT_SOLO3;
-        else if (e && !strcmp(e, "measured")) m = CM_MODE_MEASURED;
 #ifdef BZ3_EMU
         else if (e && !strcmp(e, "rows-test")) m = CM_VARIANT_ROWS_TEST;
 #endif
@@ -254,22 +239,17 @@ bool lean_states() {
 }
 
 int cm_variant_for(const DeviceCtx * ctx, size_t njobs, bool encode) {
+    (void)encode;
     const int m = cm_mode();
     const size_t c = (size_t)ctx->cus;
-    if (m == CM_MODE_MEASURED) {  // round-1 policy: row-cache encoder beyond one block per CU, guess-ahead row-cache decoder only where three share a CU
-        if (njobs > 2 * c) return CM_VARIANT_ROWS3;
-        return (encode && njobs > c) ? CM_VARIANT_ROWS : CM_VARIANT_FULL;
-    }
     if (m >= 0) return m;
-    // auto, by batch size (profiles/r02_cm_coresidency*.txt, MI355X, ns per byte and block of a 2 MiB text block).  Up to one block
-    // per CU the whole model sits in LDS; beyond that the CM launch would need a second round of workgroups, and the row-cache
-    // kernels put two / three blocks on a CU instead.  The encoder's model waves interleave well (x1.5 / x2.0 throughput).
-    // Decoders: the barrier-synchronised guess-ahead decoder (sync) is the fastest at every co-residency -- 653 / 807 / 880 ns with
-    // one / two / three blocks per CU, against 687 / (no co-residency) for the polling decoder and 787 / 853 / 915 ns for the
-    // lock-step one; the single-wave decoder (solo) needs 919 / 970 / 1000 ns.
-    if (njobs > 2 * c) return CM_VARIANT_SYNC3;  // rows3 encoder + sync decoder with 56 rows, three blocks per CU
-    if (njobs > c) return CM_VARIANT_SYNC2;      // rows encoder + sync decoder with 96 rows, two blocks per CU
-    return CM_VARIANT_SYNC;                      // full-model encoder + sync decoder with the whole model
+    // auto, by batch size.  Up to one block per CU the whole model sits in LDS; beyond that the CM launch would need a second round of
+    // workgroups, and the row-cache kernels put two / three blocks on a CU instead: ns per byte and block of a 2 MiB text block on
+    // MI355X, decoder 551 / ~650 / 737 with one / two / three blocks per CU (profiles/r03_cm_decoder_steps.txt), the encoder's
+    // model waves interleave even better (x1.5 / x2.0 throughput, profiles/r01_cm_rows_probe.txt).
+    if (njobs > 2 * c) return CM_VARIANT_ROWS3;
+    if (njobs > c) return CM_VARIANT_ROWS;
+    return CM_VARIANT_FULL;
 }
 
 size_t cm_scratch_bytes(size_t njobs) { return njobs * (CM_SPILL_BYTES + 256) + 4096; }
@@ -313,7 +293,7 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
         if (!again.empty()) {
             HIP_CHECK(hipMemcpyAsync(d_jobs, again.data(), sizeof(Job) * again.size(), hipMemcpyHostToDevice, s));
             HIP_CHECK(hipEventRecord(ev0, s));
-            go(d_jobs, (u32)again.size(), s, (int)CM_VARIANT_SYNC);  // whole model in LDS: nothing to give up
+            go(d_jobs, (u32)again.size(), s, (int)CM_VARIANT_FULL);  // whole model in LDS: nothing to give up
             HIP_CHECK(hipEventRecord(ev1, s));
             HIP_CHECK(hipStreamSynchronize(s));
             (void)hipEventElapsedTime(&ms2, ev0, ev1);
@@ -1636,9 +1616,9 @@ BZIP3_API int bz3_hip_bind_device(int device) {
 BZIP3_API int bz3_hip_state_device(struct bz3_state * st) { return st->device; }
 
 BZIP3_API int bz3_hip_set_cm_mode(int mode) {
-    bool ok = (mode >= -1 && mode <= CM_VARIANT_SOLO2) || mode == CM_VARIANT_SOLO3 || mode == CM_MODE_MEASURED;
+    bool ok = mode >= -1 && mode <= CM_VARIANT_ROWS3;
 #ifdef BZ3_EMU
-    ok = ok || mode == CM_VARIANT_ROWS_TEST || mode == CM_VARIANT_LOCK_TEST || mode == CM_VARIANT_SYNC_TEST || mode == CM_VARIANT_SOLO_TEST;
+    ok = ok || mode == CM_VARIANT_ROWS_TEST;
 #endif
     if (!ok) return -1;
     g_cm_mode.store(mode);
@@ -1883,7 +1863,7 @@ void stage_cm_job(StageEnv & e, Job job, Launch && go) {
     go(d_job, 1u, e.s, variant);
     if (cm_variant_has_rows(variant) && e.word(status) != 0u) {
         g_cm_given_up.fetch_add(1u);
-        go(d_job, 1u, e.s, (int)CM_VARIANT_SYNC);
+        go(d_job, 1u, e.s, (int)CM_VARIANT_FULL);
     }
 }
 

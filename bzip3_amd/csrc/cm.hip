@@ -5,10 +5,11 @@
 // codes the block, so the 5 table reads and 4 counter updates per coded bit never leave the CU; HBM traffic is the
 // algorithmic minimum (read n bytes, write the coded bytes, or the reverse).  Blocks are independent: a batch is ONE
 // launch with one workgroup per block.  Kernel variants (stages.hpp CM_VARIANT_*):
-//   full model   k_cm_encode / k_cm_decode            the whole C1 table in LDS: one block per CU
-//   row cache    k_cm_*_rows, k_cm_*_rows3            only the C1 rows a block uses are resident (96 or 44/56 rows, the
-//                                                     others spill to HBM): two / three blocks per CU
-//   lock step    k_cm_decode_lock3                    row-cache decoder that trades latency for VALU work
+//   full model   k_cm_encode / k_cm_decode_sync                       the whole C1 table in LDS: one block per CU
+//   row cache    k_cm_encode_rows{,3} / k_cm_decode_sync{2,3}         only the C1 rows a block uses are resident (96 or 44 / 56
+//                                                                     rows, the others spill to HBM): two / three blocks per CU
+// (Rounds 1-2 also had a polling, a lock-step and a single-wave decoder; they were slower at every co-residency and were removed
+// in round 3 -- profiles/HISTORY.md has their measurements.)
 //
 // Exact facts used:
 //  * encode: all 8 tree nodes of a byte are known up front (the encoder knows the byte) and touch disjoint counters; the
@@ -665,8 +666,6 @@ constexpr int CM_ROWS_ENC = 96;   // 48 KiB of C1 rows: 79.5 KB of LDS per workg
 constexpr int CM_ROWS_DEC = 96;   // 48 KiB of C1 rows: 72.1 KB of LDS per workgroup (112 rows = 80.6 KB: measured, two of those do NOT share a CU)
 constexpr int CM_ROWS3_ENC = 44;  // 22 KiB of C1 rows: 52.9 KB of LDS per workgroup, three workgroups per CU (a chunk pins up to 34 rows)
 constexpr int CM_ROWS3_DEC = 56;  // 28 KiB of C1 rows: 50.8 KB of LDS per workgroup
-constexpr int CM_ROWS_SOLO3 = 64;  // single-wave decoder: 32 KiB of C1 rows, 50.9 KB of LDS per workgroup, three per CU
-constexpr int CM_ROWS_SOLO2 = 112; // 56 KiB of C1 rows: 75.5 KB, two per CU
 #ifdef BZ3_EMU
 constexpr int CM_ROWS_TEST = 40;  // emulator tests: small enough that short inputs recycle slots all the time
 #endif
@@ -679,28 +678,7 @@ __global__ void __launch_bounds__(256) k_cm_encode_rows_test(const CmEncodeJob *
 #endif
 
 // ------------------------------------------------------------------------------------------------
-// decode: five waves.  Wave 0 ("walker") runs the coder; waves 1..4 ("model waves") hold one tree node per lane
-// (node = thread - 64) and run AHEAD of it on a guess.
-//
-//  model   : for byte i every lane evaluates its node's 18-bit probability (the 255 nodes of a byte depend only on
-//            state that is fixed once byte i-1 is known) and leaves it, pre-shifted by 14 so that ((range * P) >> 18)
-//            is a single v_mul_hi_u32, in an LDS table (double-buffered).  The model waves do not wait for byte i-1:
-//            they ASSUME it repeats byte i-2 (the coder's input is BWT output: ~65 % of its bytes repeat their
-//            predecessor), apply that byte's counter update and evaluate byte i while the walker is still decoding
-//            byte i-1.  The update only touches cells owned by the updating lane and its old values stay in
-//            registers, so a wrong guess is undone with three stores, the real update applied, and the table
-//            evaluated again.  s_ready[w] = 2i+1 announces the speculative table of byte i, 2i+2 the corrected one.
-//  walk    : the walker decodes byte i from table i.  The 8 serial decisions are SPECULATED across lanes: lane l
-//            assumes that the first six bits of the byte are l and runs the (d = code - low, range) recurrence along
-//            that path without waiting for any comparison; the comparisons are only shifted into a per-lane
-//            accumulator.  The lane whose accumulator spells its own number took no wrong turn (induction over the
-//            levels: its first comparison used the true state), so it holds the true coder state; every lane decodes
-//            its last two bits for real.  Per level the dependent chain is v_mul_hi_u32 + v_xad_u32, with no branch.
-//            Intervals are nested while nothing is renormalised, so "a renormalisation (:470-474) was due at some
-//            level" is equivalent to "the final interval lies within one 2^24 bucket": one scalar test on the
-//            surviving lane's final state; if it fires (about one byte in four) the byte is decoded again by the
-//            checked walk, which renormalises on the scalar unit after every level.
-//            The byte goes to the model waves through s_done (tag of the byte index in the upper bits).
+// decode: helpers of the guess-ahead decoder (cm_decode_block_sync below).
 // ------------------------------------------------------------------------------------------------
 template <u32 V>
 struct CmConst {
@@ -738,196 +716,8 @@ __device__ __forceinline__ u64 cm_clock() {
 #endif
 }
 
-__device__ __forceinline__ u32 cm_min4(u32 a, u32 b, u32 c, u32 d) {
-    const u32 x = a < b ? a : b, y = c < d ? c : d;
-    return x < y ? x : y;
-}
-#ifndef BZ3_EMU
-typedef u32 cm_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32 cm_min4v(cm_u32x4 v) { return cm_min4(v.x, v.y, v.z, v.w); }
-#endif
 
-struct CmEval {  // what a model lane remembers of its node's last evaluation (the inputs of the counter update)
-    u32 a1;  // index of C1[c1][node]
-    u32 p1;  // its value
-    u32 ci;  // index of the first of the two C2 cells
-    u32 w;   // both cells, x1 | x2 << 16
-};
-
-// Probability of one node (:377-388) into the table, given the two order-1 counters p1 = C1[c1][node] (at index a1)
-// and p2 = C1[c2][node]; returns what the update of that byte will need.
-template <class M>
-__device__ __forceinline__ CmEval cm_evaluate(const M & m, u32 * __restrict__ pt, u32 node, u32 c0, u32 a1, u32 p1, u32 p2, u32 f) {
-    CmEval e;
-    e.a1 = a1;
-    e.p1 = p1;
-    const int p = (int)((cm_mul24(c0 + p1, 7u) + 2u * p2) >> 4);  // (c0 + p1 < 2^17)
-    e.ci = (2u * node + f) * CM_C2_STRIDE + (u32)(p >> 12);
-    e.w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[e.ci]));
-    const int x1 = (int)(e.w & 0xFFFFu), x2 = (int)(e.w >> 16);
-    const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);
-    pt[node] = (u32)(ssep * 3 + p) << 14;
-    return e;
-}
-
-template <int R>
-__device__ __forceinline__ void cm_decode_block(const CmDecodeJob * __restrict__ jobs) {
-    const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
-    const u32 in_size = jobs[blockIdx.x].in_size;
-    u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
-    const u32 n = jobs[blockIdx.x].n;
-    const u32 debug = jobs[blockIdx.x].debug & 15u;  // 3: cycle counters instead of the first output bytes (profiling only)
-    const u32 tune = jobs[blockIdx.x].debug >> 4;    // experiments: bit 0 = raise the walker's issue priority (measured: no effect)
-    __shared__ CmLdsT<R> m;
-    __shared__ u32 ptab[2][256];  // (18-bit probability of node) << 14
-    __shared__ __attribute__((aligned(16))) u32 s_ready[4];  // per model wave: 2i+1 = speculative table of byte i is there, 2i+2 = corrected one
-    __shared__ u32 s_done;        // ((i + 1) & 0xFFFFFF) << 8 | byte i, written by the walker
-    __shared__ u32 s_abort;       // R > 0: the model waves gave the block up
-    __shared__ CmRowCache<R> rcs[R ? 4 : 1];  // R > 0: one private directory per model wave
-    if (threadIdx.x < 4) s_ready[threadIdx.x] = 0;
-    if (threadIdx.x == 4) s_done = 0;
-    if (threadIdx.x == 5) s_abort = 0;
-    cm_model_init(m);
-    if (n == 0) return;
-    const int lane = lane_id();
-    const u32 role = cm_uniform((u32)wave_id());
-    if (role != 0) {
-        // ---- model waves ------------------------------------------------------------------------------------
-        const u32 node = threadIdx.x - 64u;
-        const u32 lvl = node ? (u32)(31 - __clz((int)node)) : 0u;
-        const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
-        u32 c0 = 32768u;  // the node's C0 counter lives in a register
-        u64 prof_spec = 0, prof_wait = 0, prof_redo = 0, prof_miss = 0;
-        // byte 0: nothing to guess (c1 = c2 = 0, run = 1, :367-372)
-        CmEval prev = cm_evaluate(m, ptab[0], node, c0, node, m.c1[node], m.c1[node], 0u);
-        lds_release();
-        LDS_POKE(s_ready[role - 1], 2u);  // (every lane stores the same word: cheaper than masking the wave down to one lane)
-        u32 k1 = 0;        // newest confirmed byte (byte i-2 inside the loop; the initial c1 = 0 before the block starts)
-        u32 run_prev = 1;  // run counter the evaluation of byte i-1 was made with
-        // R > 0: row cache of this wave (slot 0 = byte value 0, which the evaluation of byte 0 above has used)
-        CmRowCache<R> & rc = rcs[R ? role - 1 : 0];
-        CmRowState rs;
-        u16 * __restrict__ spill = global_ptr<u16>(jobs[blockIdx.x].spill);
-        const u32 miss_base = jobs[blockIdx.x].miss_base, miss_shift = jobs[blockIdx.x].miss_shift;
-        if (R) cm_rows_init<R>(rc);
-        for (u32 i = 1; i < n; i++) {
-            u64 t0 = 0, t1 = 0, t2 = 0;
-            if (debug == 3) t0 = cm_clock();
-            u32 * __restrict__ pt = ptab[i & 1u];
-            // -- speculate: byte i-1 == k1.  Update of byte i-1 (:396-399, :411-414; branch-free, see cm_upd) ...
-            const u32 g = k1;
-            const bool on_g = (hibit | (g >> shr)) == node;
-            const u32 c0_old = c0;
-            u32 cell = prev.p1;  // C1[k1][node]: byte i-1 was evaluated with c1 = k1, so this is the cell its update moves
-            if (on_g) {
-                const u32 mk = 0u - ((g >> bitpos) & 1u);
-                c0 = cm_upd(c0, 2, mk & 16383u);
-                cell = cm_upd(prev.p1, 4, mk & 4095u);
-                m.c1[prev.a1] = (u16)cell;
-                reinterpret_cast<PackedU32 *>(&m.c2[prev.ci])->v = cm_upd_pair6(prev.w, mk & 0x03FF03FFu);
-            }
-            // ... and the table of byte i with c1 = g, c2 = k1.  They are equal: both order-1 counters are `cell` (no LDS
-            // read), and the run counter goes up.
-            CmEval cur = cm_evaluate(m, pt, node, c0, prev.a1, cell, cell, run_prev + 1u > 2u ? 1u : 0u);
-            lds_release();
-            LDS_POKE(s_ready[role - 1], 2u * i + 1u);
-            if (debug == 3) t1 = cm_clock();
-            // -- the walker's verdict on byte i-1.  s_done is a one-word mailbox and this wave announced the speculative table
-            // of byte i BEFORE reading it: if the guess was right the walker does not wait for anybody, decodes byte i from
-            // that table and overwrites the word with the verdict on byte i (tag i+1).  A model wave that was held up
-            // meanwhile (waves of other workgroups on the same CU, a context switch) then never sees tag i -- but tag i+1
-            // can only appear after a right guess (a wrong one makes the walker wait for this wave's corrected table), so it
-            // carries the missed verdict: byte i-1 was g.  The walker cannot get further ahead than that: byte i+1 needs a
-            // table this wave has not announced yet.
-            u32 word, ahead;  // ahead = how far the mailbox is ahead of the verdict this wave waits for (tags are 24 bits wide)
-            const u32 tag = i & 0xFFFFFFu;
-#ifdef BZ3_EMU_WATCH
-            unsigned long long spins_ = 0;
-#endif
-            for (;;) {
-                word = cm_uniform(LDS_PEEK(s_done));
-                ahead = ((word >> 8) - tag) & 0xFFFFFFu;
-                if (ahead <= 1u) break;
-                BZ3_SPIN_TIGHT();
-#ifdef BZ3_EMU_WATCH
-                if (++spins_ == 300000ull && lane == 0) fprintf(stderr, "[model wave %u] stuck at i=%u waiting tag %u: s_done=%08x s_ready=%u %u %u %u\n", role, i, tag, s_done, s_ready[0], s_ready[1], s_ready[2], s_ready[3]);
-#endif
-            }
-            const u32 c = ahead == 0u ? (word & 0xFFu) : g;
-            if (debug == 3) t2 = cm_clock();
-            if (c != g) {
-                // wrong guess: put the old counters back (the old values are still in `prev`), apply the real update
-                // and evaluate again.  The new c1 row differs from the row being repaired, so its read goes first.
-                u32 row = c;
-                if (R) {
-                    row = cm_uniform((u32)rc.row_of[c]);
-                    if (__builtin_expect(row >= CM_ROW_SPILLED, 0)) {
-                        // the only row still needed is the one of byte i-2 (prev.a1 points into it): pin it
-                        rs.tick++;
-                        if (lane == 0) rc.stamp[cm_uniform(prev.a1 >> 8)] = rs.tick;
-                        wave_sync();
-                        row = cm_rows_fetch<R, 1>(m, rc, rs, spill, c, row, node);
-                        if (__builtin_expect(rs.misses > miss_base + (i >> miss_shift), 0)) {
-                            // the working set does not fit: give the block up (every model wave gets here at the same byte)
-                            if (threadIdx.x == 64) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
-                            LDS_POKE(s_abort, 1u);
-                            LDS_POKE(s_ready[role - 1], CM_ABORT_MARK);
-                            return;
-                        }
-                    }
-                }
-                const u32 a1 = row * 256u + node;
-                const u32 p1 = m.c1[a1];
-                u32 cell2 = prev.p1;
-                if (on_g) {
-                    c0 = c0_old;
-                    reinterpret_cast<PackedU32 *>(&m.c2[prev.ci])->v = prev.w;
-                }
-                if ((hibit | (c >> shr)) == node) {
-                    const u32 mk = 0u - ((c >> bitpos) & 1u);
-                    c0 = cm_upd(c0, 2, mk & 16383u);
-                    cell2 = cm_upd(prev.p1, 4, mk & 4095u);
-                    reinterpret_cast<PackedU32 *>(&m.c2[prev.ci])->v = cm_upd_pair6(prev.w, mk & 0x03FF03FFu);
-                }
-                if (on_g || cell2 != prev.p1) m.c1[prev.a1] = (u16)cell2;
-                cur = cm_evaluate(m, pt, node, c0, a1, p1, cell2, 0u);  // c != k1: the run counter restarts
-                if (R) wave_sync();  // (test emulation: a row fetch de-synchronises the fibers of a wave; no instruction on the GPU)
-                lds_release();
-                LDS_POKE(s_ready[role - 1], 2u * i + 2u);
-                run_prev = 0;
-                prof_miss++;
-            } else {
-                run_prev++;
-            }
-            prev = cur;
-            k1 = c;
-            if (debug == 3) {
-                const u64 t3 = cm_clock();
-                prof_spec += t1 - t0;
-                prof_wait += t2 - t1;
-                prof_redo += t3 - t2;
-            }
-        }
-        if (debug == 3 && n >= 256 && threadIdx.x == 64) {
-            u64 * o = reinterpret_cast<u64 *>(out) + 8;
-            o[0] = prof_spec;
-            o[1] = prof_wait;
-            o[2] = prof_redo;
-            o[3] = prof_miss;
-        }
-        return;
-    }
-    // ---- walker ---------------------------------------------------------------------------------------------
-    if (tune & 1u) cm_raise_priority();
-    // lane l assumes bits b0..b5 = l; nbK = all-ones where the assumed bit of level K is 0
-    const u32 ul = (u32)lane;
-    const bool as0 = (ul >> 5) & 1u, as1 = (ul >> 4) & 1u, as2 = (ul >> 3) & 1u, as3 = (ul >> 2) & 1u, as4 = (ul >> 1) & 1u, as5 = ul & 1u;
-    const u32 nb0 = (u32)as0 - 1u, nb1 = (u32)as1 - 1u, nb2 = (u32)as2 - 1u, nb3 = (u32)as3 - 1u, nb4 = (u32)as4 - 1u, nb5 = (u32)as5 - 1u;
-    const u32 ix0 = 1u, ix1 = 2u | (ul >> 5), ix2 = 4u | (ul >> 4), ix3 = 8u | (ul >> 3), ix4 = 16u | (ul >> 2), ix5 = 32u | (ul >> 1);
-    const u32 ix6 = 64u | ul, ix7 = 128u | (ul << 1);
-    u32 low_u = 0, range_u = 0xFFFFFFFFu, code = 0, c1 = 0, c2 = 0;
-    u32 ip = 0, ibase = 0;
-    u32 window = (ibase + lane < in_size) ? in[ibase + lane] : 0xFFFFFFFFu;
+// The coded bytes are read 64 at a time (one byte per lane) and handed out by v_readlane.  Bytes past the end read as -1 (:345).
 #define CM_NEXT_BYTE(dst)                                                              \
     do {                                                                               \
         if (ip - ibase >= 64u) {                                                       \
@@ -937,11 +727,6 @@ __device__ __forceinline__ void cm_decode_block(const CmDecodeJob * __restrict__
         dst = cm_readlane(window, (int)(ip - ibase));                                  \
         ip++;                                                                          \
     } while (0)
-    for (int j = 0; j < 4; j++) {  // :438-441; bytes past the end read as -1 (:345)
-        u32 b;
-        CM_NEXT_BYTE(b);
-        code = (code << 8) + b;
-    }
 // ---- checked walk (slow path) -------------------------------------------------------------------------------
 // Renormalisation of the surviving path (:470-474).  All valid lanes carry the same (low, range): take them from one
 // of those lanes, shift on the scalar unit, and hand the result to every lane (the others are dead anyway).
@@ -986,304 +771,6 @@ __device__ __forceinline__ void cm_decode_block(const CmDecodeJob * __restrict__
         low = BIT ? low : mid_ + 1u;                                                                  \
         CM_RENORM();                                                                                  \
     } while (0)
-// ---- fast walk: no branches, no renormalisation ------------------------------------------------------------------
-// Works on d = code - low instead of low (the comparison becomes d <= t; equivalent as long as low <= code <= high,
-// which is checked per byte: a truncated stream feeds -1 bytes (:345) and can push `code` out of the interval; inside
-// it, d <= range holds along the true path, so the range never wraps there).
-#define CM_FAST_SPEC(P, NB, AS)                                                                       \
-    do {                                                                                              \
-        const u32 keep_ = range & (NB);                                                               \
-        const u32 t_ = (u32)(((u64)range * (P)) >> 32);            /* (range * p18) >> 18, :464 */    \
-        const bool bit_ = d <= t_;                                                                    \
-        acc = cm_shift_in(acc, __ballot(bit_), bit_);                                                 \
-        range = cm_xad(t_, (NB), keep_);                           /* t  |  range - t - 1 */          \
-        d = cm_xad(t_ | ~(NB), 0xFFFFFFFFu, d);                    /* d  |  d + ~t = d - t - 1: assumed 1 -> (~0 ^ ~0) + d */ \
-    } while (0)
-#define CM_FAST_REAL(P, BIT)                                                                          \
-    do {                                                                                              \
-        const u32 t_ = (u32)(((u64)range * (P)) >> 32);                                               \
-        BIT = d <= t_;                                                                                \
-        cbits = cm_shift_in(cbits, __ballot(BIT), BIT);                                               \
-        range = BIT ? t_ : range + ~t_;                            /* t  |  range - t - 1 */          \
-        d = BIT ? d : d + ~t_;                                                                        \
-    } while (0)
-    u32 staged = 0;
-    u64 prof_wait = 0, prof_walk = 0, prof_slow = 0, prof_miss = 0;  // debug == 3
-    u32 P0, P1, P2, P3, P4, P5, P6, P7a, P7b;  // this lane's slice of the table of the byte being decoded
-// min over the four model waves of what they have announced (one 16-byte LDS read)
-#ifdef BZ3_EMU
-#define CM_READY_MIN() cm_min4(s_ready[0], s_ready[1], s_ready[2], s_ready[3])
-#else
-#define CM_READY_MIN() cm_min4v(*(const volatile __attribute__((address_space(3))) cm_u32x4 *)(s_ready))  // LDS address space: ds_read_b128, not a flat load
-#endif
-#ifdef BZ3_EMU_WATCH
-#define CM_WATCH_DECL unsigned long long spins_ = 0;
-#define CM_WATCH_SPIN(need) if (++spins_ == 300000ull && lane == 0) fprintf(stderr, "[walker] stuck waiting for %u: s_ready=%u %u %u %u s_done=%08x\n", (u32)(need), s_ready[0], s_ready[1], s_ready[2], s_ready[3], s_done);
-#else
-#define CM_WATCH_DECL
-#define CM_WATCH_SPIN(need)
-#endif
-// Wait until every model wave has announced at least `need`, then fetch this lane's nine probabilities from table BUF.
-// `seen` is an earlier CM_READY_MIN() (announcements only grow): when it already suffices nothing is polled.
-#define CM_FETCH_TABLE(BUF, seen, need)                                                               \
-    do {                                                                                              \
-        if (cm_uniform(seen) < (need)) {                                                              \
-            CM_WATCH_DECL                                                                             \
-            while (cm_uniform(CM_READY_MIN()) < (need)) { BZ3_SPIN_TIGHT(); CM_WATCH_SPIN(need) }     \
-        }                                                                                             \
-        lds_acquire();                                                                                \
-        const u32 * __restrict__ pt_ = ptab[BUF];                                                     \
-        P0 = pt_[ix0]; P1 = pt_[ix1]; P2 = pt_[ix2]; P3 = pt_[ix3]; P4 = pt_[ix4]; P5 = pt_[ix5];     \
-        P6 = pt_[ix6]; P7a = pt_[ix7]; P7b = pt_[ix7 + 1u];                                           \
-    } while (0)
-    // One byte.  BUF (compile time) is the half of the double-buffered probability table this byte uses; its table
-    // has been fetched already, and the table of the next byte is fetched before the byte is stored.
-    auto decode_byte = [&](const u32 i, auto buf_tag) __attribute__((always_inline)) -> bool {  // true: the block was given up (R > 0)
-        constexpr u32 BUF = decltype(buf_tag)::value;
-        u64 t0 = 0, t1 = 0;
-        if (debug == 3) t0 = cm_clock();
-        u32 c, seen;
-        {
-            u32 range = range_u, low;  // per-lane copies of the wave-uniform coder state
-            u32 d = code - low_u;
-            const bool inside = d <= range_u;  // low <= code <= high: always, unless a truncated stream fed -1 bytes (:345)
-            u32 acc = 0;
-            bool bit6, bit7;
-            CM_FAST_SPEC(P0, nb0, as0);  // :453-489
-            CM_FAST_SPEC(P1, nb1, as1);
-            CM_FAST_SPEC(P2, nb2, as2);
-            CM_FAST_SPEC(P3, nb3, as3);
-            CM_FAST_SPEC(P4, nb4, as4);
-            CM_FAST_SPEC(P5, nb5, as5);
-            const u64 ok = __ballot(acc == ul);  // exactly one lane decoded the six bits it had assumed
-            u32 cbits = acc;
-            CM_FAST_REAL(P6, bit6);
-            const u32 P7f = bit6 ? P7b : P7a;
-            CM_FAST_REAL(P7f, bit7);
-            const int w = __ffsll((unsigned long long)ok) - 1;
-            seen = CM_READY_MIN();  // issued here, needed only after the byte is known: is the next table there already?
-            const u32 low_f = code - cm_readlane(d, w), range_f = cm_readlane(range, w);
-            if (__builtin_expect(inside && (low_f ^ (low_f + range_f)) >= (1u << 24), 1)) {
-                low_u = low_f;
-                range_u = range_f;
-                c = cm_readlane(cbits, w);
-            } else {  // a renormalisation was due on the true path: decode this byte again, checking every level
-                prof_slow++;
-                low = low_u;
-                range = range_u;
-                u64 valid = ~0ull;
-                CM_SPEC_LEVEL(P0, nb0, 0xFFFFFFFF00000000ull);
-                CM_SPEC_LEVEL(P1, nb1, 0xFFFF0000FFFF0000ull);
-                CM_SPEC_LEVEL(P2, nb2, 0xFF00FF00FF00FF00ull);
-                CM_SPEC_LEVEL(P3, nb3, 0xF0F0F0F0F0F0F0F0ull);
-                CM_SPEC_LEVEL(P4, nb4, 0xCCCCCCCCCCCCCCCCull);
-                CM_SPEC_LEVEL(P5, nb5, 0xAAAAAAAAAAAAAAAAull);
-                CM_REAL_LEVEL(P6, bit6);
-                const u32 P7 = bit6 ? P7b : P7a;
-                CM_REAL_LEVEL(P7, bit7);
-                const int w2 = __ffsll((unsigned long long)valid) - 1;  // exactly one lane survives
-                low_u = cm_readlane(low, w2);
-                range_u = cm_readlane(range, w2);
-                c = cm_readlane((ul << 2) | ((u32)bit6 << 1) | (u32)bit7, w2);
-            }
-        }
-        LDS_POKE(s_done, (((i + 1u) & 0xFFFFFFu) << 8) | c);  // every lane stores the same word: no EXEC juggling on the critical path
-        if (debug == 3) t1 = cm_clock();
-        c2 = c1;
-        c1 = c;
-        if (i + 1u < n) {
-            // The table of byte i+1: the speculative one will do if byte i repeated byte i-1 (that was the guess);
-            // otherwise the model waves announce a corrected one.
-            const bool hit = c1 == c2;
-            if (debug == 3) prof_miss += hit ? 0u : 1u;
-            CM_FETCH_TABLE(BUF ^ 1u, seen, 2u * (i + 1u) + (hit ? 1u : 2u));
-        }
-        if ((u32)lane == (i & 63u)) staged = c;
-        if ((i & 63u) == 63u || i + 1 == n) {
-            const u32 first = i & ~63u;
-            if (first + lane <= i) out[first + lane] = (u8)staged;
-            if (R && LDS_PEEK(s_abort) != 0u) return true;  // given up (the bytes decoded since then are of no use)
-        }
-        if (debug == 3) {
-            const u64 t2 = cm_clock();
-            prof_walk += t1 - t0;
-            prof_wait += t2 - t1;
-        }
-        return false;
-    };
-    CM_FETCH_TABLE(0, 0u, 2u);  // byte 0: nothing to guess
-    u32 i = 0;
-    for (; i + 1 < n; i += 2) {
-        if (decode_byte(i, CmConst<0>{})) return;
-        if (decode_byte(i + 1, CmConst<1>{})) return;
-    }
-    if (i < n && decode_byte(i, CmConst<0>{})) return;
-    if (debug == 3 && n >= 256 && lane == 0) {  // profiling only: output bytes 0..39 and 64..95 become counters
-        u64 * o = reinterpret_cast<u64 *>(out);
-        o[0] = prof_wait;
-        o[1] = prof_walk;
-        o[2] = prof_slow;
-        o[3] = prof_miss;
-    }
-#undef CM_FETCH_TABLE
-#undef CM_READY_MIN
-}
-
-// ------------------------------------------------------------------------------------------------
-// decode, lock-step variant (row cache only): four waves, one tree node per lane, TWO barriers per byte.
-//
-// The guess-ahead decoder above buys single-block latency with VALU work: every model lane evaluates its node for
-// every byte, 45 % of the time twice, next to a fifth wave that walks -- about 2/3 of a CU's issue slots for ONE block,
-// so workgroups that share a CU slow each other down (profiles/r01_cm_rows_probe.txt: two per CU = 2.07x the time).
-// This variant does the minimum instead: evaluate all nodes once the previous byte is known, barrier, wave 0 walks the
-// byte (same lane-speculated walk, same checked slow path) while the other waves sleep in the barrier, barrier, the 8
-// lanes on the decoded path update.  More latency per byte for a block that is alone, but roughly half the issue slots
-// (~380 wave-instructions per byte by the ISA), no polling and no speculation to undo: made for several blocks per CU.
-// Opt-in (CM_VARIANT_LOCK2 / LOCK3); not measured on the GPU yet (written after the round-1 GPU budget was spent).
-// ------------------------------------------------------------------------------------------------
-template <int R>
-__device__ __forceinline__ void cm_decode_block_lockstep(const CmDecodeJob * __restrict__ jobs) {
-    static_assert(R > 0, "row-cache kernel");
-    const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
-    const u32 in_size = jobs[blockIdx.x].in_size;
-    u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
-    const u32 n = jobs[blockIdx.x].n;
-    __shared__ CmLdsT<R> m;
-    __shared__ u32 ptab[256];  // (18-bit probability of node) << 14
-    __shared__ u32 s_byte;     // the byte wave 0 decoded
-    __shared__ CmRowCache<R> rcs[4];
-    cm_model_init(m);
-    if (n == 0) return;
-    const int lane = lane_id();
-    // The walking wave is "wave 0" below.  Experiment (BZ3_CM_TUNE bit 2): rotate that role with the block index, so that
-    // the walkers of workgroups sharing a CU do not all sit on the SIMD that hosts hardware wave 0 of every workgroup.
-    const u32 hw_wave = cm_uniform((u32)wave_id());
-    const u32 wave = ((jobs[blockIdx.x].debug >> 4) & 4u) ? ((hw_wave + blockIdx.x) & 3u) : hw_wave;
-    const u32 node = threadIdx.x;
-    const u32 lvl = node ? (u32)(31 - __clz((int)node)) : 0u;
-    const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
-    u32 c0 = 32768u;  // the node's C0 counter lives in a register
-    CmRowCache<R> & rc = rcs[hw_wave];
-    CmRowState rs;
-    u16 * __restrict__ spill = global_ptr<u16>(jobs[blockIdx.x].spill);
-    const u32 miss_base = jobs[blockIdx.x].miss_base, miss_shift = jobs[blockIdx.x].miss_shift;
-    cm_rows_init<R>(rc);
-    // walk side (wave 0 only): lane l assumes bits b0..b5 = l
-    const u32 ul = (u32)lane;
-    const bool as0 = (ul >> 5) & 1u, as1 = (ul >> 4) & 1u, as2 = (ul >> 3) & 1u, as3 = (ul >> 2) & 1u, as4 = (ul >> 1) & 1u, as5 = ul & 1u;
-    const u32 nb0 = (u32)as0 - 1u, nb1 = (u32)as1 - 1u, nb2 = (u32)as2 - 1u, nb3 = (u32)as3 - 1u, nb4 = (u32)as4 - 1u, nb5 = (u32)as5 - 1u;
-    const u32 ix0 = 1u, ix1 = 2u | (ul >> 5), ix2 = 4u | (ul >> 4), ix3 = 8u | (ul >> 3), ix4 = 16u | (ul >> 2), ix5 = 32u | (ul >> 1);
-    const u32 ix6 = 64u | ul, ix7 = 128u | (ul << 1);
-    u32 low_u = 0, range_u = 0xFFFFFFFFu, code = 0;
-    u32 ip = 0, ibase = 0, window = 0, staged = 0;
-    if (wave == 0) {
-        window = (ibase + lane < in_size) ? in[ibase + lane] : 0xFFFFFFFFu;
-        for (int j = 0; j < 4; j++) {  // :438-441; bytes past the end read as -1 (:345)
-            u32 b;
-            CM_NEXT_BYTE(b);
-            code = (code << 8) + b;
-        }
-    }
-    u32 c1 = 0, c2 = 0, run = 0;
-    u32 row1 = 0, row2 = 0;  // slots of the rows of c1 and c2 (byte value 0 before the block starts: slot 0)
-    for (u32 i = 0; i < n; i++) {
-        run = (c1 == c2) ? run + 1 : 0;  // :367-372
-        const u32 f = run > 2 ? 1u : 0u;
-        // ---- every lane: probability of its node (:377-388) ---------------------------------------------------
-        const u32 a1 = row1 * 256u + node;
-        const u32 p1 = m.c1[a1];
-        const u32 p2 = m.c1[row2 * 256u + node];
-        const int p = (int)((cm_mul24(c0 + p1, 7u) + 2u * p2) >> 4);  // (c0 + p1 < 2^17)
-        const u32 ci = (2u * node + f) * CM_C2_STRIDE + (u32)(p >> 12);
-        const u32 w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[ci]));  // x1 | x2 << 16
-        {
-            const int x1 = (int)(w & 0xFFFFu), x2 = (int)(w >> 16);
-            const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);
-            ptab[node] = (u32)(ssep * 3 + p) << 14;
-        }
-        __syncthreads();
-        // ---- wave 0: the byte ------------------------------------------------------------------------------------
-        if (wave == 0) {
-            const u32 P0 = ptab[ix0], P1 = ptab[ix1], P2 = ptab[ix2], P3 = ptab[ix3], P4 = ptab[ix4], P5 = ptab[ix5], P6 = ptab[ix6];
-            const u32 P7a = ptab[ix7], P7b = ptab[ix7 + 1u];
-            u32 c;
-            u32 range = range_u, low;
-            u32 d = code - low_u;
-            const bool inside = d <= range_u;  // low <= code <= high: always, unless a truncated stream fed -1 bytes (:345)
-            u32 acc = 0;
-            bool bit6, bit7;
-            CM_FAST_SPEC(P0, nb0, as0);  // :453-489
-            CM_FAST_SPEC(P1, nb1, as1);
-            CM_FAST_SPEC(P2, nb2, as2);
-            CM_FAST_SPEC(P3, nb3, as3);
-            CM_FAST_SPEC(P4, nb4, as4);
-            CM_FAST_SPEC(P5, nb5, as5);
-            const u64 ok = __ballot(acc == ul);  // exactly one lane decoded the six bits it had assumed
-            u32 cbits = acc;
-            CM_FAST_REAL(P6, bit6);
-            const u32 P7f = bit6 ? P7b : P7a;
-            CM_FAST_REAL(P7f, bit7);
-            const int wl = __ffsll((unsigned long long)ok) - 1;
-            const u32 low_f = code - cm_readlane(d, wl), range_f = cm_readlane(range, wl);
-            if (__builtin_expect(inside && (low_f ^ (low_f + range_f)) >= (1u << 24), 1)) {
-                low_u = low_f;
-                range_u = range_f;
-                c = cm_readlane(cbits, wl);
-            } else {  // a renormalisation was due on the true path: decode this byte again, checking every level
-                low = low_u;
-                range = range_u;
-                u64 valid = ~0ull;
-                CM_SPEC_LEVEL(P0, nb0, 0xFFFFFFFF00000000ull);
-                CM_SPEC_LEVEL(P1, nb1, 0xFFFF0000FFFF0000ull);
-                CM_SPEC_LEVEL(P2, nb2, 0xFF00FF00FF00FF00ull);
-                CM_SPEC_LEVEL(P3, nb3, 0xF0F0F0F0F0F0F0F0ull);
-                CM_SPEC_LEVEL(P4, nb4, 0xCCCCCCCCCCCCCCCCull);
-                CM_SPEC_LEVEL(P5, nb5, 0xAAAAAAAAAAAAAAAAull);
-                CM_REAL_LEVEL(P6, bit6);
-                const u32 P7 = bit6 ? P7b : P7a;
-                CM_REAL_LEVEL(P7, bit7);
-                const int w2 = __ffsll((unsigned long long)valid) - 1;  // exactly one lane survives
-                low_u = cm_readlane(low, w2);
-                range_u = cm_readlane(range, w2);
-                c = cm_readlane((ul << 2) | ((u32)bit6 << 1) | (u32)bit7, w2);
-            }
-            LDS_POKE(s_byte, c);
-            if ((u32)lane == (i & 63u)) staged = c;
-            if ((i & 63u) == 63u || i + 1 == n) {
-                const u32 first = i & ~63u;
-                if (first + lane <= i) out[first + lane] = (u8)staged;
-            }
-        }
-        __syncthreads();
-        const u32 c = cm_uniform(LDS_PEEK(s_byte));
-        // ---- the 8 lanes on the decoded path: counter updates (:396-399, :411-414; branch-free, see cm_upd) ---------
-        if ((hibit | (c >> shr)) == node) {
-            const u32 mk = 0u - ((c >> bitpos) & 1u);
-            c0 = cm_upd(c0, 2, mk & 16383u);
-            m.c1[a1] = (u16)cm_upd(p1, 4, mk & 4095u);
-            reinterpret_cast<PackedU32 *>(&m.c2[ci])->v = cm_upd_pair6(w, mk & 0x03FF03FFu);
-        }
-        // ---- contexts of the next byte; its order-1 row must be resident ---------------------------------------------
-        c2 = c1;
-        c1 = c;
-        row2 = row1;
-        if (c1 != c2) {
-            u32 row = cm_uniform((u32)rc.row_of[c]);
-            if (__builtin_expect(row >= CM_ROW_SPILLED, 0)) {
-                rs.tick++;
-                if (lane == 0) rc.stamp[row2] = rs.tick;  // the row of c2 is still needed
-                wave_sync();
-                row = cm_rows_fetch<R, 1>(m, rc, rs, spill, c, row, node);
-                if (__builtin_expect(rs.misses > miss_base + (i >> miss_shift), 0)) {
-                    // the working set does not fit: give the block up (all four waves count the same misses)
-                    if (threadIdx.x == 0) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
-                    return;
-                }
-            }
-            row1 = row;
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // decode, barrier-synchronised guess-ahead ("sync"): five waves like cm_decode_block -- wave 0 walks, waves 1..4 hold one
@@ -1664,238 +1151,11 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
 #undef CM_WALK_REAL
 }
 
-// ------------------------------------------------------------------------------------------------
-// decode, single wave ("solo"): ONE wave per block, no hand-off between waves at all.
-//
-// The other decoders evaluate all 255 tree nodes of every byte (four waves), although a byte only ever uses 8 of them,
-// because the walker speculates the first six decisions across its 64 lanes and then needs the level-6 / level-7 nodes of
-// whatever prefix wins.  At three blocks per CU that evaluation is what fills the CU's issue slots
-// (profiles/r02_cm_coresidency*.txt: 2,200 cycles per byte and block for the lock-step decoder).  This decoder evaluates
-// what can be needed and nothing else:
-//   E1   lane l (1..63) evaluates node l (levels 0-5).  Its counters stay in registers from byte to byte: C0[l], and the
-//        order-1 cells C1[c1][l], C1[c2][l] (a byte that repeats its predecessor -- 60-70 % of BWT output -- needs no LDS
-//        read at all for them); the probabilities travel to the lanes that walk them by ds_bpermute, not through memory;
-//   walk lane l walks the six levels along prefix l (the same lane-speculated walk as the other decoders, same checked
-//        variant when a renormalisation falls into these levels);
-//   E2   the three nodes below the decoded prefix q (64|q, 128|2q, 128|2q+1) are evaluated by lanes 0-2;
-//   tail levels 6 and 7 are decoded on the scalar unit, with the reference's renormalisation test after each bit;
-//   update, row bookkeeping (one directory, the wave moves whole rows: four cells per lane).
-// ~190 wave-instructions per byte instead of ~380-460, one wave instead of four or five, nothing to synchronise.
-// ------------------------------------------------------------------------------------------------
-struct CmNodeEval {
-    u32 P;   // (18-bit probability) << 14
-    u32 ci;  // index of the first of the two C2 cells
-    u32 w;   // both cells, x1 | x2 << 16
-};
-template <class M>
-__device__ __forceinline__ CmNodeEval cm_evaluate_node(const M & m, u32 node, u32 c0, u32 p1, u32 p2, u32 f) {  // :377-388
-    CmNodeEval e;
-    const int p = (int)((cm_mul24(c0 + p1, 7u) + 2u * p2) >> 4);  // (c0 + p1 < 2^17)
-    e.ci = (2u * node + f) * CM_C2_STRIDE + (u32)(p >> 12);
-    e.w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[e.ci]));
-    const int x1 = (int)(e.w & 0xFFFFu), x2 = (int)(e.w >> 16);
-    const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);
-    e.P = (u32)(ssep * 3 + p) << 14;
-    return e;
-}
-
-template <int R>
-__device__ __forceinline__ void cm_decode_block_solo(const CmDecodeJob * __restrict__ jobs, CmLdsT<R> & m) {
-    static_assert(R > 0, "row-cache kernel");
-    const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
-    const u32 in_size = jobs[blockIdx.x].in_size;
-    u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
-    const u32 n = jobs[blockIdx.x].n;
-    const u32 debug = jobs[blockIdx.x].debug & 15u;  // 3: cycle counters instead of the first output bytes (profiling only)
-    __shared__ CmRowCache<R> rc;
-    cm_model_init(m);
-    if (n == 0) return;
-    const int lane = lane_id();
-    const u32 ul = (u32)lane;
-    // E1 side: lane l owns node l (lane 0: none)
-    const u32 lvl = ul ? (u32)(31 - __clz((int)ul)) : 0u;
-    const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
-    u32 c0 = 32768u;           // C0[l]
-    u32 v1 = 32768u;           // C1[c1][l]  (row1 * 256 + l)
-    u32 v2 = 32768u;           // C1[c2][l]
-    // walk side: lane l assumes bits b0..b5 = l
-    const bool as0 = (ul >> 5) & 1u, as1 = (ul >> 4) & 1u, as2 = (ul >> 3) & 1u, as3 = (ul >> 2) & 1u, as4 = (ul >> 1) & 1u, as5 = ul & 1u;
-    const u32 nb0 = (u32)as0 - 1u, nb1 = (u32)as1 - 1u, nb2 = (u32)as2 - 1u, nb3 = (u32)as3 - 1u, nb4 = (u32)as4 - 1u, nb5 = (u32)as5 - 1u;
-    const int ix1 = (int)(2u | (ul >> 5)), ix2 = (int)(4u | (ul >> 4)), ix3 = (int)(8u | (ul >> 3)), ix4 = (int)(16u | (ul >> 2)), ix5 = (int)(32u | (ul >> 1));
-    u32 low_u = 0, range_u = 0xFFFFFFFFu, code = 0;
-    u32 ip = 0, ibase = 0;
-    u32 window = (ibase + lane < in_size) ? in[ibase + lane] : 0xFFFFFFFFu;
-    for (int j = 0; j < 4; j++) {  // :438-441; bytes past the end read as -1 (:345)
-        u32 b;
-        CM_NEXT_BYTE(b);
-        code = (code << 8) + b;
-    }
-    CmRowState rs;
-    u16 * __restrict__ spill = global_ptr<u16>(jobs[blockIdx.x].spill);
-    const u32 miss_base = jobs[blockIdx.x].miss_base, miss_shift = jobs[blockIdx.x].miss_shift;
-    cm_rows_init<R>(rc);
-    u32 c1 = 0, c2 = 0, run = 0;
-    u32 row1 = 0, row2 = 0;  // slots of the rows of c1 and c2 (byte value 0 before the block starts: slot 0)
-    u32 staged = 0;
-    u64 prof_e1 = 0, prof_walk = 0, prof_e2 = 0, prof_tail = 0, prof_slow = 0;
-    for (u32 i = 0; i < n; i++) {
-        u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-        if (debug == 3) t0 = cm_clock();
-        run = (c1 == c2) ? run + 1 : 0;  // :367-372
-        const u32 f = run > 2 ? 1u : 0u;
-        // ---- E1: levels 0-5, one node per lane, counters from registers ----------------------------------------------
-        const CmNodeEval e1 = cm_evaluate_node(m, ul, c0, v1, v2, f);
-        const u32 P0 = (u32)__shfl((int)e1.P, 1), P1 = (u32)__shfl((int)e1.P, ix1), P2 = (u32)__shfl((int)e1.P, ix2), P3 = (u32)__shfl((int)e1.P, ix3),
-                  P4 = (u32)__shfl((int)e1.P, ix4), P5 = (u32)__shfl((int)e1.P, ix5);
-        if (debug == 3) t1 = cm_clock();
-        // ---- six speculated levels ----------------------------------------------------------------------------------------
-        u32 q;  // the decoded prefix b0..b5
-        {
-            u32 range = range_u, low;  // per-lane copies of the wave-uniform coder state
-            u32 d = code - low_u;
-            const bool inside = d <= range_u;  // low <= code <= high: always, unless a truncated stream fed -1 bytes (:345)
-            u32 acc = 0;
-            CM_FAST_SPEC(P0, nb0, as0);  // :453-489
-            CM_FAST_SPEC(P1, nb1, as1);
-            CM_FAST_SPEC(P2, nb2, as2);
-            CM_FAST_SPEC(P3, nb3, as3);
-            CM_FAST_SPEC(P4, nb4, as4);
-            CM_FAST_SPEC(P5, nb5, as5);
-            const u64 ok = __ballot(acc == ul);  // exactly one lane decoded the six bits it had assumed
-            const int w = __ffsll((unsigned long long)ok) - 1;
-            const u32 low_f = code - cm_readlane(d, w), range_f = cm_readlane(range, w);
-            if (__builtin_expect(inside && (low_f ^ (low_f + range_f)) >= (1u << 24), 1)) {
-                low_u = low_f;
-                range_u = range_f;
-                q = (u32)w;
-            } else {  // a renormalisation was due within these levels: walk them again, checking every level
-                prof_slow++;
-                low = low_u;
-                range = range_u;
-                u64 valid = ~0ull;
-                CM_SPEC_LEVEL(P0, nb0, 0xFFFFFFFF00000000ull);
-                CM_SPEC_LEVEL(P1, nb1, 0xFFFF0000FFFF0000ull);
-                CM_SPEC_LEVEL(P2, nb2, 0xFF00FF00FF00FF00ull);
-                CM_SPEC_LEVEL(P3, nb3, 0xF0F0F0F0F0F0F0F0ull);
-                CM_SPEC_LEVEL(P4, nb4, 0xCCCCCCCCCCCCCCCCull);
-                CM_SPEC_LEVEL(P5, nb5, 0xAAAAAAAAAAAAAAAAull);
-                const int w2 = __ffsll((unsigned long long)valid) - 1;  // exactly one lane survives
-                low_u = cm_readlane(low, w2);
-                range_u = cm_readlane(range, w2);
-                q = (u32)w2;
-            }
-        }
-        if (debug == 3) t2 = cm_clock();
-        // ---- E2: the three nodes below prefix q, lanes 0-2 (the other lanes ride along on node 64|q) ---------------------
-        const u32 child = (128u | (q << 1)) + (ul - 1u);               // lanes 1, 2: the two level-7 nodes
-        const u32 node2 = (ul - 1u) < 2u ? child : (64u | q);          // (one v_cndmask: nested selects compile to divergent branches)
-        const u32 a2 = row1 * 256u + node2;
-        const u32 c0b = m.c0[node2];
-        const u32 p1b = m.c1[a2];
-        const u32 p2b = m.c1[row2 * 256u + node2];
-        const CmNodeEval e2 = cm_evaluate_node(m, node2, c0b, p1b, p2b, f);
-        const u32 P6 = cm_readlane(e2.P, 0), P7a = cm_readlane(e2.P, 1), P7b = cm_readlane(e2.P, 2);
-        if (debug == 3) t3 = cm_clock();
-        // ---- levels 6 and 7 on the scalar unit, renormalisation test after each bit (:464-474) ----------------------------
-        u32 bit6, bit7;
-#define CM_SCALAR_LEVEL(P, BIT)                                                                       \
-        do {                                                                                          \
-            const u32 t_ = (u32)(((u64)range_u * (P)) >> 32);                                         \
-            const u32 mid_ = low_u + t_;                                                              \
-            BIT = code <= mid_ ? 1u : 0u;                                                             \
-            range_u = BIT ? t_ : range_u - t_ - 1u;                                                   \
-            low_u = BIT ? low_u : mid_ + 1u;                                                          \
-            while (__builtin_expect((low_u ^ (low_u + range_u)) < (1u << 24), 0)) {                   \
-                low_u <<= 8;                                                                          \
-                range_u = (range_u << 8) | 0xFFu;                                                     \
-                u32 b_;                                                                               \
-                CM_NEXT_BYTE(b_);                                                                     \
-                code = (code << 8) + b_;                                                              \
-            }                                                                                         \
-        } while (0)
-        CM_SCALAR_LEVEL(P6, bit6);
-        const u32 P7 = bit6 ? P7b : P7a;
-        CM_SCALAR_LEVEL(P7, bit7);
-#undef CM_SCALAR_LEVEL
-        const u32 c = (q << 2) | (bit6 << 1) | bit7;
-        // ---- counter updates (:396-399, :411-414; branch-free, see cm_upd) ------------------------------------------------
-        if ((hibit | (c >> shr)) == ul) {  // the six lanes whose node is on the path (lane 0 never matches: c >> 8 == 0, hibit == 1)
-            const u32 mk = 0u - ((c >> bitpos) & 1u);
-            c0 = cm_upd(c0, 2, mk & 16383u);
-            v1 = cm_upd(v1, 4, mk & 4095u);
-            m.c1[row1 * 256u + ul] = (u16)v1;
-            reinterpret_cast<PackedU32 *>(&m.c2[e1.ci])->v = cm_upd_pair6(e1.w, mk & 0x03FF03FFu);
-        }
-        if (ul == 0u || ul == 1u + bit6) {  // node 64|q with bit 6, node 128|2q|bit6 with bit 7
-            const u32 mk = 0u - (ul == 0u ? bit6 : bit7);
-            m.c0[node2] = (u16)cm_upd(c0b, 2, mk & 16383u);
-            m.c1[a2] = (u16)cm_upd(p1b, 4, mk & 4095u);
-            reinterpret_cast<PackedU32 *>(&m.c2[e2.ci])->v = cm_upd_pair6(e2.w, mk & 0x03FF03FFu);
-        }
-        if (ul == (i & 63u)) staged = c;
-        if ((i & 63u) == 63u || i + 1 == n) {
-            const u32 first = i & ~63u;
-            if (first + ul <= i) out[first + ul] = (u8)staged;
-        }
-        // ---- contexts of the next byte: its order-1 row must be resident; the register copies follow the rows -----------------
-        c2 = c1;
-        c1 = c;
-        row2 = row1;
-        v2 = v1;  // C1[new c2][l] = what C1[old c1][l] has just become
-        if (c1 != c2) {
-            u32 row = cm_uniform((u32)rc.row_of[c]);
-            if (__builtin_expect(row >= CM_ROW_SPILLED, 0)) {
-                rs.tick++;
-                if (lane == 0) rc.stamp[row2] = rs.tick;  // the row of c2 is still needed
-                wave_sync();
-                row = cm_rows_fetch<R, 4>(m, rc, rs, spill, c, row, ul);
-                if (__builtin_expect(rs.misses > miss_base + (i >> miss_shift), 0)) {  // the working set does not fit: give the block up
-                    if (lane == 0) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
-                    return;
-                }
-            }
-            row1 = row;
-            v1 = m.c1[row1 * 256u + ul];
-        }
-        if (debug == 3) {
-            const u64 t4 = cm_clock();
-            prof_e1 += t1 - t0;
-            prof_walk += t2 - t1;
-            prof_e2 += t3 - t2;
-            prof_tail += t4 - t3;
-        }
-    }
-    if (debug == 3 && n >= 256 && lane == 0) {  // profiling only: the first output bytes become counters
-        u64 * o = reinterpret_cast<u64 *>(out);
-        o[0] = prof_e1;
-        o[1] = prof_walk;
-        o[2] = prof_slow;
-        o[3] = prof_e2;
-        o[4] = prof_tail;
-    }
-}
 #undef CM_NEXT_BYTE
 #undef CM_RENORM
 #undef CM_SPEC_LEVEL
 #undef CM_REAL_LEVEL
-#undef CM_FAST_SPEC
-#undef CM_FAST_REAL
 
-__global__ void __launch_bounds__(320) k_cm_decode(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<0>(jobs); }
-__global__ void __launch_bounds__(320) k_cm_decode_rows(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<CM_ROWS_DEC>(jobs); }
-__global__ void __launch_bounds__(320) k_cm_decode_rows3(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<CM_ROWS3_DEC>(jobs); }
-__global__ void __launch_bounds__(256) k_cm_decode_lock3(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_lockstep<CM_ROWS3_DEC>(jobs); }
-__global__ void __launch_bounds__(256) k_cm_decode_lock2(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_lockstep<CM_ROWS_DEC>(jobs); }
-template <int R>
-__device__ __forceinline__ void cm_decode_solo_entry(const CmDecodeJob * __restrict__ jobs) {
-    BZ3_DYN_SMEM(dyn_lds);
-    cm_decode_block_solo<R>(jobs, *reinterpret_cast<CmLdsT<R> *>(dyn_lds));
-}
-__global__ void __launch_bounds__(64) k_cm_decode_solo2(const CmDecodeJob * __restrict__ jobs) { cm_decode_solo_entry<CM_ROWS_SOLO2>(jobs); }
-__global__ void __launch_bounds__(64) k_cm_decode_solo3(const CmDecodeJob * __restrict__ jobs) { cm_decode_solo_entry<CM_ROWS_SOLO3>(jobs); }
-#ifdef BZ3_EMU
-__global__ void __launch_bounds__(64) k_cm_decode_solo_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_solo_entry<CM_ROWS_TEST>(jobs); }
-#endif
 template <int R, bool PROF = false>
 __device__ __forceinline__ void cm_decode_sync_entry(const CmDecodeJob * __restrict__ jobs) {
     BZ3_DYN_SMEM(dyn_lds);
@@ -1911,32 +1171,20 @@ __global__ void __launch_bounds__(320) k_cm_decode_sync3_prof(const CmDecodeJob 
 #ifdef BZ3_EMU
 __global__ void __launch_bounds__(320) k_cm_decode_sync_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS_TEST>(jobs); }
 #endif
-#ifdef BZ3_EMU
-__global__ void __launch_bounds__(256) k_cm_decode_lock_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_block_lockstep<CM_ROWS_TEST>(jobs); }
-#endif
-#ifdef BZ3_EMU
-__global__ void __launch_bounds__(320) k_cm_decode_rows_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_block<CM_ROWS_TEST>(jobs); }
-#endif
-
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant) {
     if (!njobs) return;
 #ifdef BZ3_EMU
-    if (variant == CM_VARIANT_ROWS_TEST || variant == CM_VARIANT_LOCK_TEST || variant == CM_VARIANT_SYNC_TEST || variant == CM_VARIANT_SOLO_TEST)
-        return launch(k_cm_encode_rows_test, dim3(njobs), dim3(256), 0, s, d_jobs);
+    if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_encode_rows_test, dim3(njobs), dim3(256), 0, s, d_jobs);
 #endif
-    // the encoder has three kernels; the decoder variants pair up with the one that puts as many blocks on a CU
-    if (variant == CM_VARIANT_ROWS3 || variant == CM_VARIANT_LOCK3 || variant == CM_VARIANT_SYNC3 || variant == CM_VARIANT_SOLO3) launch(k_cm_encode_rows3, dim3(njobs), dim3(256), 0, s, d_jobs);
-    else if (variant == CM_VARIANT_ROWS || variant == CM_VARIANT_LOCK2 || variant == CM_VARIANT_SYNC2 || variant == CM_VARIANT_SOLO2) launch(k_cm_encode_rows, dim3(njobs), dim3(256), 0, s, d_jobs);
+    if (variant == CM_VARIANT_ROWS3) launch(k_cm_encode_rows3, dim3(njobs), dim3(256), 0, s, d_jobs);
+    else if (variant == CM_VARIANT_ROWS) launch(k_cm_encode_rows, dim3(njobs), dim3(256), 0, s, d_jobs);
     else launch(k_cm_encode, dim3(njobs), dim3(256), 0, s, d_jobs);
 }
 
 void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant, bool prof) {
     if (!njobs) return;
 #ifdef BZ3_EMU
-    if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_decode_rows_test, dim3(njobs), dim3(320), 0, s, d_jobs);
-    if (variant == CM_VARIANT_LOCK_TEST) return launch(k_cm_decode_lock_test, dim3(njobs), dim3(256), 0, s, d_jobs);
-    if (variant == CM_VARIANT_SYNC_TEST) return launch(k_cm_decode_sync_test, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS_TEST>), s, d_jobs);
-    if (variant == CM_VARIANT_SOLO_TEST) return launch(k_cm_decode_solo_test, dim3(njobs), dim3(64), sizeof(CmLdsT<CM_ROWS_TEST>), s, d_jobs);
+    if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_decode_sync_test, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS_TEST>), s, d_jobs);
 #else
     {  // dynamic LDS beyond 64 KB has to be asked for, once per kernel AND per device (a batch may span several GPUs of one process)
         static std::atomic<u64> prepared[4] = {{0}, {0}, {0}, {0}};  // one bit per device ordinal (up to 256)
@@ -1945,7 +1193,6 @@ void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int v
         const u64 bit = 1ull << (dev & 63);
         std::atomic<u64> & word = prepared[(dev >> 6) & 3];
         if (!(word.load() & bit)) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_solo2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<CM_ROWS_SOLO2>)));
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_sync), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<0>)));
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_sync2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<CM_ROWS_DEC>)));
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_sync_prof), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<0>)));
@@ -1954,16 +1201,9 @@ void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int v
         }
     }
 #endif
-    if (variant == CM_VARIANT_SOLO3) launch(k_cm_decode_solo3, dim3(njobs), dim3(64), sizeof(CmLdsT<CM_ROWS_SOLO3>), s, d_jobs);
-    else if (variant == CM_VARIANT_SOLO2) launch(k_cm_decode_solo2, dim3(njobs), dim3(64), sizeof(CmLdsT<CM_ROWS_SOLO2>), s, d_jobs);
-    else if (variant == CM_VARIANT_SYNC) launch(prof ? k_cm_decode_sync_prof : k_cm_decode_sync, dim3(njobs), dim3(320), sizeof(CmLdsT<0>), s, d_jobs);
-    else if (variant == CM_VARIANT_SYNC2) launch(prof ? k_cm_decode_sync2_prof : k_cm_decode_sync2, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS_DEC>), s, d_jobs);
-    else if (variant == CM_VARIANT_SYNC3) launch(prof ? k_cm_decode_sync3_prof : k_cm_decode_sync3, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS3_DEC>), s, d_jobs);
-    else if (variant == CM_VARIANT_LOCK3) launch(k_cm_decode_lock3, dim3(njobs), dim3(256), 0, s, d_jobs);
-    else if (variant == CM_VARIANT_LOCK2) launch(k_cm_decode_lock2, dim3(njobs), dim3(256), 0, s, d_jobs);
-    else if (variant == CM_VARIANT_ROWS3) launch(k_cm_decode_rows3, dim3(njobs), dim3(320), 0, s, d_jobs);
-    else if (variant == CM_VARIANT_ROWS) launch(k_cm_decode_rows, dim3(njobs), dim3(320), 0, s, d_jobs);
-    else launch(k_cm_decode, dim3(njobs), dim3(320), 0, s, d_jobs);
+    if (variant == CM_VARIANT_ROWS3) launch(prof ? k_cm_decode_sync3_prof : k_cm_decode_sync3, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS3_DEC>), s, d_jobs);
+    else if (variant == CM_VARIANT_ROWS) launch(prof ? k_cm_decode_sync2_prof : k_cm_decode_sync2, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS_DEC>), s, d_jobs);
+    else launch(prof ? k_cm_decode_sync_prof : k_cm_decode_sync, dim3(njobs), dim3(320), sizeof(CmLdsT<0>), s, d_jobs);
 }
 
 }  // namespace bz3

@@ -115,24 +115,17 @@ struct CmDecodeJob {
     u64 out;
     u32 in_size;
     u32 n;
-    u32 debug;     // 0 = normal; profiling only (output invalid): 1 = coder work only, 2 = model work only
+    u32 debug;     // 0 = normal; 3 = the cycle-counter build's job (profiling only: counters replace the first output bytes); bits 4.. = experiments
     u32 pad;
     u64 spill = 0, status = 0;  // as above
     u32 miss_base = 0, miss_shift = 0;
 };
-// Kernel variants: the whole 145.5 KiB model in LDS (one workgroup per CU), or the row-cache kernels (order-1 rows
-// cached in LDS: two or three workgroups per CU; they may give a block up, see status).
-// CM_VARIANT_LOCK3: row-cache encoder as ROWS3, but the lock-step decoder (cm.hip), three blocks per CU.
-// CM_VARIANT_LOCK2: the same pair with the 96-row caches, two blocks per CU.
-// CM_VARIANT_SOLO2 / SOLO3: the single-wave decoder (cm.hip: one wave per block, evaluates only the nodes a byte can need) with 112 / 64
-// rows in LDS (two / three blocks per CU), paired with the rows / rows3 encoder.
-// CM_VARIANT_SYNC / SYNC2 / SYNC3: the barrier-synchronised guess-ahead decoder (cm.hip) with the whole model / 96 rows / 56 rows
-// in LDS (one / two / three blocks per CU), paired with the full-model / rows / rows3 encoder.
-enum { CM_VARIANT_FULL = 0, CM_VARIANT_ROWS = 1, CM_VARIANT_ROWS3 = 2, CM_VARIANT_LOCK3 = 3, CM_VARIANT_LOCK2 = 4,
-       CM_VARIANT_SYNC = 5, CM_VARIANT_SYNC2 = 6, CM_VARIANT_SYNC3 = 7, CM_VARIANT_SOLO2 = 8, CM_VARIANT_SOLO3 = 12,
-       CM_VARIANT_ROWS_TEST = 9, CM_VARIANT_LOCK_TEST = 10, CM_VARIANT_SYNC_TEST = 11, CM_VARIANT_SOLO_TEST = 13 /* emulator builds only: tiny cache */ };
-inline bool cm_variant_has_rows(int v) { return v != CM_VARIANT_FULL && v != CM_VARIANT_SYNC; }
-inline bool cm_variant_is_test(int v) { return v == CM_VARIANT_ROWS_TEST || v == CM_VARIANT_LOCK_TEST || v == CM_VARIANT_SYNC_TEST || v == CM_VARIANT_SOLO_TEST; }
+// Kernel variants: the whole 145.5 KiB model in LDS (one workgroup per CU: k_cm_encode / k_cm_decode_sync), or the row-cache
+// kernels (order-1 rows cached in LDS; they may give a block up, see status): ROWS = 96 rows, two workgroups per CU
+// (k_cm_encode_rows / k_cm_decode_sync2), ROWS3 = 44 / 56 rows, three per CU (k_cm_encode_rows3 / k_cm_decode_sync3).
+enum { CM_VARIANT_FULL = 0, CM_VARIANT_ROWS = 1, CM_VARIANT_ROWS3 = 2, CM_VARIANT_ROWS_TEST = 9 /* emulator builds only: tiny cache */ };
+inline bool cm_variant_has_rows(int v) { return v != CM_VARIANT_FULL; }
+inline bool cm_variant_is_test(int v) { return v == CM_VARIANT_ROWS_TEST; }
 constexpr size_t CM_SPILL_BYTES = 256 * 256 * 2;
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL);
 void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL, bool prof = false);  // prof: the sync decoders' cycle-counter build

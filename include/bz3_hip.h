@@ -34,15 +34,9 @@ BZIP3_API int bz3_hip_state_device(struct bz3_state * state);
 /* CM kernel variant (process-wide).  0 = the whole 145.5 KiB model in LDS, one block per CU; 1 / 2 = row-cache
  * kernels (the order-1 rows a block uses are cached in LDS -- 96 or 44/56 of them --, the others spill to HBM:
  * two / three blocks per CU; a block whose working set does not fit is handed back to variant 0 automatically);
- * 3 / 4 = as 2 / 1 with the lock-step decoder (barriers instead of polling: loses little when several blocks share a CU);
- * 100 = by batch size as measured (row-cache encoder beyond one block per CU, row-cache decoder beyond two);
- * 5 / 6 / 7 = the barrier-synchronised guess-ahead decoder (speculative table beside the walk, barriers instead of polled mailboxes) with
- *      the whole model / 96 rows / 56 rows in LDS, paired with the encoder of variant 0 / 1 / 2;
- * 8 / 12 = the single-wave decoder (one wave per block, evaluates only the nodes a byte can need) with 112 / 64 rows;
- * -1 = automatic (default), by batch size: up to one block per CU variant 5, up to two per CU variant 6, beyond that variant 7
- *      (measured on MI355X: profiles/r02_cm_coresidency*.txt).
- * Environment BZ3_HIP_CM_MODE=auto|full|rows|rows3|lock3|lock2|sync|sync2|sync3|solo2|solo3|measured has the same effect.  Output bytes do not depend on
- * the variant.  Returns 0, or -1 for an invalid mode. */
+ * -1 = automatic (default), by batch size: up to one block per CU variant 0, up to two per CU variant 1, beyond that variant 2.
+ * Environment BZ3_HIP_CM_MODE=auto|full|rows|rows3 has the same effect.  Output bytes do not depend on the variant.
+ * Returns 0, or -1 for an invalid mode. */
 BZIP3_API int bz3_hip_set_cm_mode(int mode);
 /* Number of blocks the row-cache kernels have handed back to the full-model kernels so far (statistics). */
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void);

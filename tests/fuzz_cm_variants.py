@@ -1,5 +1,4 @@
-"""Differential fuzzer (CPU, emulator): every CM kernel variant (row caches of 96 / 44 / 56 / 40 slots, guess-ahead and
-lock-step decoders) against the oracle on random sources (Zipf alphabets of 2-255 symbols, BWT output of text, runs, noise),
+"""Differential fuzzer (CPU, emulator): every CM kernel variant (whole model, row caches of 96 / 44 / 56 / 40 slots) against the oracle on random sources (Zipf alphabets of 2-255 symbols, BWT output of text, runs, noise),
 truncated streams included, plus block round trips with classic and lean states.  Not collected by pytest:
     python tests/fuzz_cm_variants.py <seed> <seconds>
 Round 1: seeds 1-3 x 2400 s = 2,389 stage iterations + 341 block round trips, 0 mismatches.
@@ -34,7 +33,7 @@ while time.time() - t0 < budget:
     else:
         d = bytes(rng.integers(0, 256, size=n, dtype=np.uint8))
     if not d: continue
-    mode = int(rng.choice([9, 10, 11, 13, 13, 13, 1, 2, 3, 4, 5, 6, 7, 8, 12]))
+    mode = int(rng.choice([9, 9, 9, 0, 1, 2]))  # tiny cache (recycles slots all the time), whole model, the shipped caches
     lib.bz3_hip_set_cm_mode(mode)
     c = o.cm_encode(d)
     e = g.cm_encode(d); dd = g.cm_decode(c, len(d))

@@ -605,16 +605,16 @@ def test_lean_states_on_gpu(gpu_lib, oracle, text):
 
 
 def test_zz_three_blocks_per_cu_variants_on_gpu(gpu_lib, oracle, text):
-    """Last on purpose: the 44/56-row kernels (mode 2) and the lock-step row-cache decoder (mode 3, written after the
-    round-1 GPU budget was spent: emulator-verified only so far).  Same bytes as the oracle on text, a source that
-    recycles slots, random bytes (given up, recoded by the full-model kernel) and a truncated stream."""
+    """The 44/56-row kernels (mode 2: three blocks per CU), the 96-row pair (1) and the whole-model pair (0) through the stage hooks:
+    same bytes as the oracle on text, a source that recycles slots, random bytes (given up, recoded by the full-model kernel) and a
+    truncated stream."""
     g = bzip3_amd.StageApi(gpu_lib)
     rng = np.random.default_rng(13)
     p = 1.0 / np.arange(1, 91) ** 2.0
     wide = bytes(rng.permutation(256)[:90].astype(np.uint8)[rng.choice(90, size=300000, p=p / p.sum())])
     inputs = {"text": oracle.bwt(text[3000000 : 3000000 + (1 << 20)])[1], "wide90": wide, "rand": datagen.random_bytes(150000, seed=4), "tiny": b"abracadabra"}
     try:
-        for mode in (2, 3, 4):  # rows3, lock3, lock2
+        for mode in (2, 1, 0):
             assert gpu_lib.bz3_hip_set_cm_mode(mode) == 0
             for name, d in inputs.items():
                 c = oracle.cm_encode(d)

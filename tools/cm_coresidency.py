@@ -1,6 +1,6 @@
 """How do CM decoder variants behave when several blocks share a CU?  (GPU box, no torch import.)
     python tools/cm_coresidency.py [MiB=2] [copies ...=256 512 768] [--cycles] [--only=a,b] [--lib=path]
-For every variant (full, rows, rows3, lock2, lock3) and every number of identical blocks: ONE launch of the CM decoder over
+For every decoder (sync = whole model, sync2 / sync3 = row caches for two / three blocks per CU) and every number of identical blocks: ONE launch of the CM decoder over
 `copies` copies of the same coded block (bz3_hip_stage_cm_decode_many), launch time by HIP events, ns per byte and block,
 aggregate MiB/s.  --cycles additionally runs the guess-ahead variants with BZ3_CM_DEBUG=3 and prints the decoder's phase
 counters (cycles per byte: walker walk / wait, model wave speculate / wait / redo; shares of slow-path bytes and wrong
@@ -17,7 +17,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import bzip3_amd  # noqa: E402
 import datagen  # noqa: E402
 
-MODES = {"full": 0, "rows": 1, "rows3": 2, "lock2": 4, "lock3": 3, "sync": 5, "sync2": 6, "sync3": 7, "solo2": 8, "solo3": 12}
+MODES = {"auto": -1, "full": 0, "rows": 1, "rows3": 2, "sync": 0, "sync2": 1, "sync3": 2}  # (sync* = the decoders' kernel names: the same variants)
 
 
 def main():
@@ -37,7 +37,7 @@ def main():
     out = (C.c_uint8 * n)()
     only = [a[len("--only="):].split(",") for a in sys.argv if a.startswith("--only=")]
     for name, mode in MODES.items():
-        if only and name not in only[0]:
+        if (only and name not in only[0]) or (not only and not name.startswith("sync")):
             continue
         assert lib.bz3_hip_set_cm_mode(mode) == 0
         for k in copies:

@@ -15,7 +15,7 @@ import bzip3_amd  # noqa: E402
 import datagen  # noqa: E402
 
 copies = int(sys.argv[1]) if len(sys.argv) > 1 else 768
-mode = {"sync": 5, "sync2": 6, "sync3": 7}[sys.argv[2] if len(sys.argv) > 2 else "sync3"]
+mode = {"sync": 0, "sync2": 1, "sync3": 2}[sys.argv[2] if len(sys.argv) > 2 else "sync3"]
 n = 2 << 20
 lib = bzip3_amd.load()
 g = bzip3_amd.StageApi(lib)
