@@ -273,8 +273,6 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
             jobs[i].miss_shift = cm_variant_is_test(variant) ? 3u : 8u;  // give up beyond 0.4 % misses (test variants: 12.5 %)
         }
     }
-    if (const char * t = getenv("BZ3_CM_TUNE"))  // kernel experiments (cm.hip `tune`); no effect on the output bytes
-        for (Job & j : jobs) j.debug |= (u32)atoi(t) << 4;
     float ms = 0.f, ms2 = 0.f;
     HIP_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipEventRecord(ev0, s));
@@ -1929,8 +1927,7 @@ BZIP3_API float bz3_hip_stage_cm_decode_many(const uint8_t * in, int32_t in_size
         const size_t stride = ((size_t)n + 64 + 255) & ~(size_t)255;
         u8 * o = e.dev(stride * (size_t)copies);
         const char * dbg = getenv("BZ3_CM_DEBUG");
-        const char * tune = getenv("BZ3_CM_TUNE");
-        const u32 debug = (dbg ? (u32)atoi(dbg) : 0u) | ((tune ? (u32)atoi(tune) : 0u) << 4);
+        const u32 debug = dbg ? (u32)atoi(dbg) : 0u;
         const int variant = cm_variant_for(e.ctx, (size_t)copies, false);
         u8 * spill = cm_variant_has_rows(variant) ? e.dev(CM_SPILL_BYTES * (size_t)copies) : nullptr;
         u32 * status = (u32 *)e.dev(4 * (size_t)copies + 64);
@@ -1984,8 +1981,7 @@ BZIP3_API float bz3_hip_stage_cm_encode_many(const uint8_t * in, int32_t n, uint
         u8 * o = e.dev(stride * (size_t)copies);
         u32 * w = (u32 *)e.dev(16 * (size_t)copies + 64);
         const char * dbg = getenv("BZ3_CM_DEBUG");
-        const char * tune = getenv("BZ3_CM_TUNE");
-        const u32 debug = (dbg ? (u32)atoi(dbg) : 0u) | ((tune ? (u32)atoi(tune) : 0u) << 4);
+        const u32 debug = dbg ? (u32)atoi(dbg) : 0u;
         const int variant = cm_variant_for(e.ctx, (size_t)copies, true);
         u8 * spill = cm_variant_has_rows(variant) ? e.dev(CM_SPILL_BYTES * (size_t)copies) : nullptr;
         u32 * status = (u32 *)e.dev(4 * (size_t)copies + 64);

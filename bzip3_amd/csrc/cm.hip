@@ -473,7 +473,6 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
     u32 * __restrict__ out_size = global_ptr<u32>(jobs[blockIdx.x].out_size);
     const u32 debug = jobs[blockIdx.x].debug & 15u;
-    const u32 tune = jobs[blockIdx.x].debug >> 4;  // experiments: bit 3 = do NOT raise the coder wave's issue priority
     __shared__ CmLdsT<R> m;
     __shared__ __attribute__((aligned(16))) CmRing ring;
     __shared__ CmEvent ev_a[6 * CM_CHUNK], ev_b[CM_CHUNK], ev_c[CM_CHUNK];
@@ -576,7 +575,7 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     }
     // ---- coder wave: ONE active lane (an LDS read then returns 16 bytes, not 64 x 16) ------------------------
     if (debug == 2 || lane != 0) return;
-    if (!(tune & 8u)) cm_raise_priority();  // the coder is the critical path of its block (measured at three per CU: -9 .. -14 % launch time; BZ3_CM_TUNE bit 3 = off)
+    cm_raise_priority();  // the coder is the critical path of its block (measured at three per CU: -9 .. -14 % launch time, profiles/r02_cm_priority.txt)
     u32 vzero;
 #ifdef BZ3_EMU
     vzero = 0;
@@ -990,8 +989,8 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
     }
     // ---- walker ---------------------------------------------------------------------------------------------
     // The walker is the critical path of its block: highest issue priority among the waves of its SIMD.  Measured with three blocks
-    // per CU (the other blocks' model waves share the SIMD): 918 -> 805 ns per byte and block (profiles/r02_cm_priority.txt);
-    // BZ3_CM_TUNE bit 3 switches it off.
+    // per CU (the other blocks' model waves share the SIMD): 918 -> 805 ns per byte and block in round 2 (profiles/r02_cm_priority.txt),
+    // 762 -> 737 in round 3 (profiles/r03_cm_decoder_steps.txt).
     //
     // A single wave issues one instruction every 5-8 cycles whatever it is, so the walker's instruction count per byte IS its time
     // (round 3: the loop the compiler made of the first version spent 165 instructions on a byte, 40 of them scalar moves between the
@@ -1004,7 +1003,7 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
     //  * two bytes per loop trip, so that the table buffer, the s_done word and the LDS offsets of a byte are compile-time constants;
     //  * every lane stores the decoded byte to the same address (one instruction; its offset is a vector counter);
     //  * the cycle counters are a separate kernel instantiation (PROF).
-    if (!((jobs[blockIdx.x].debug >> 4) & 8u)) cm_raise_priority();
+    cm_raise_priority();
     const u32 ul = (u32)lane;
     const bool as0 = (ul >> 5) & 1u, as1 = (ul >> 4) & 1u, as2 = (ul >> 3) & 1u, as3 = (ul >> 2) & 1u, as4 = (ul >> 1) & 1u, as5 = ul & 1u;
     const u32 nb0 = (u32)as0 - 1u, nb1 = (u32)as1 - 1u, nb2 = (u32)as2 - 1u, nb3 = (u32)as3 - 1u, nb4 = (u32)as4 - 1u, nb5 = (u32)as5 - 1u;

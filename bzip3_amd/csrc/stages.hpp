@@ -115,7 +115,7 @@ struct CmDecodeJob {
     u64 out;
     u32 in_size;
     u32 n;
-    u32 debug;     // 0 = normal; 3 = the cycle-counter build's job (profiling only: counters replace the first output bytes); bits 4.. = experiments
+    u32 debug;     // 0 = normal; 3 = the cycle-counter build's job (profiling only: counters replace the first output bytes)
     u32 pad;
     u64 spill = 0, status = 0;  // as above
     u32 miss_base = 0, miss_shift = 0;

@@ -1,5 +1,5 @@
 """CM kernel variants side by side on the GPU box (no torch import):
-    python tools/cm_rows_probe.py [block MiB=16] [cfg ...]      cfg = <mode>:<blocks>[:<tune>], mode = full | rows | rows3 | lock3 | measured | auto, tune = BZ3_CM_TUNE bits
+    python tools/cm_rows_probe.py [block MiB=16] [cfg ...]      cfg = <mode>:<blocks>, mode = full | rows | rows3 | auto
 For every configuration: bz3_encode_blocks + bz3_decode_blocks on host buffers (text blocks, 64 KiB pieces of one
 Markov text in a block-specific order), round trip verified, CM launch times from the library's HIP events.
 Prints one JSON line per configuration."""
@@ -38,9 +38,8 @@ def main():
     npieces = n // piece
     cap = lib.bz3_bound(n) + 64
     for cfg in cfgs:
-        mode, nblk, *tune = cfg.split(":")
+        mode, nblk = cfg.split(":")[:2]
         nblk = int(nblk)
-        os.environ["BZ3_CM_TUNE"] = tune[0] if tune else "0"
         assert lib.bz3_hip_set_cm_mode(MODES[mode]) == 0
         rng = np.random.default_rng(17)
         bufs, plain = [], []
