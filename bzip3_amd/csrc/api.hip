@@ -56,15 +56,15 @@ struct DeviceCtx {
     // whole-GPU stages of the neighbouring windows on the group's stream (encode_group and decode_group: one side stream per slot
     // of their rings, so that the serial kernels of consecutive windows overlap)
     static constexpr int AUX = 4;
-    hipStream_t aux[AUX] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_prep = nullptr, ev_d0[AUX] = {nullptr, nullptr, nullptr, nullptr}, ev_d1[AUX] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t aux[AUX] = {};
+    hipEvent_t ev_prep = nullptr, ev_d0[AUX] = {}, ev_d1[AUX] = {};
     bool aux_ready = false;
     void ensure_aux() {  // caller holds mu
         if (aux_ready) return;
         // built into locals and committed only when everything exists: a failure half way must not leave a context whose first
         // stream is there and whose events are not (every later call would record on null events)
-        hipStream_t st[AUX] = {nullptr, nullptr, nullptr, nullptr};
-        hipEvent_t e0[AUX] = {nullptr, nullptr, nullptr, nullptr}, e1[AUX] = {nullptr, nullptr, nullptr, nullptr}, ep = nullptr;
+        hipStream_t st[AUX] = {};
+        hipEvent_t e0[AUX] = {}, e1[AUX] = {}, ep = nullptr;
         try {
             HIP_CHECK(hipEventCreate(&ep));
             for (int k = 0; k < AUX; k++) {
@@ -940,7 +940,8 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     // BWTs of the next windows and the mRLE / CRC stages of the previous ones on the group's stream.  Lean states hold a borrowed
     // swap buffer while their window is in flight: 64 buffers at most either way -- two slots of 32 blocks for small batches, four
     // slots of 16 for large ones (a window's decoders then hide behind three other windows' whole-GPU work: 1 s / 48 blocks
-    // instead of 1 s / 32, which starts to matter once the inverse BWT of a block takes less than ~30 ms).
+    // instead of 1 s / 32, which starts to matter once the inverse BWT of a block takes less than ~30 ms).  Round 3 tried eight slots
+    // of 8 on a 128-block batch (profiles/r03_gaps_128x256MiB.txt): no gain there, where the pool's first allocations set the pace.
     s32 tail_slots = n >= 128 ? 4 : 2;
     s32 tail_window = tail_slots == 4 ? 16 : 32;
     if (const char * e = getenv("BZ3_HIP_TAIL_PIPE")) {  // "window,slots": tests / experiments

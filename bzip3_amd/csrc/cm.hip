@@ -253,23 +253,6 @@ struct CmByteEvents {      // the events of one byte in registers
     uint2 k[8];
     u32 m[8];
 };
-__device__ __forceinline__ void cm_load_events(const CmRing & ring, u32 i, CmByteEvents & e) {
-    const u32 slot = (i & (CM_RING - 1)) * 8;
-    const uint4 * __restrict__ pk = reinterpret_cast<const uint4 *>(&ring.k[slot]);
-    const uint4 * __restrict__ pm = reinterpret_cast<const uint4 *>(&ring.m[slot]);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint4 q = pk[j];
-        e.k[2 * j] = make_uint2(q.x, q.y);
-        e.k[2 * j + 1] = make_uint2(q.z, q.w);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const uint4 q = pm[j];
-        e.m[4 * j] = q.x; e.m[4 * j + 1] = q.y; e.m[4 * j + 2] = q.z; e.m[4 * j + 3] = q.w;
-    }
-}
-
 struct CmEvent {  // what the chain loop leaves for the event loop
     u32 px1;      // p | x1 << 16
     u32 x2b;      // x2 | bit << 16
@@ -369,13 +352,12 @@ __device__ __forceinline__ void cm_model_chunk(M & m, CmEvent * __restrict__ ev,
     }
 }
 
-// Coder steps K0 .. K0+CNT-1 of one byte without renormalisation.  Returns true when the result must not be used:
-// the final interval lies within one 2^24 bucket (=> a renormalisation was due after one of the bits, :390), or the
-// interval shrank to a single value on the way (a renormalisation was due there, and a 0 bit coded from that state
-// wraps the range, after which the intervals are no longer nested).
+// Coder steps K0 .. K0+CNT-1 of one byte without renormalisation and without any test.  The result must not be used when the final
+// interval lies within one 2^24 bucket (=> a renormalisation was due after one of the bits, :390), or when the interval shrank to a
+// single value on the way (a renormalisation was due there, and a 0 bit coded from that state wraps the range, after which the
+// intervals are no longer nested): rmin follows the smallest range on the way for the caller's test.
 template <int K0, int CNT>
-__device__ __forceinline__ bool cm_code_bits(const CmByteEvents & ev, u32 & r, u32 & l) {
-    u32 rmin = 0xFFFFFFFFu;
+__device__ __forceinline__ void cm_code_bits_raw(const CmByteEvents & ev, u32 & r, u32 & l, u32 & rmin) {
 #pragma unroll
     for (int kk = K0; kk < K0 + CNT; kk++) {
         const uint2 ek = ev.k[kk];  // (-s, -s) and M: see the header comment
@@ -385,7 +367,6 @@ __device__ __forceinline__ bool cm_code_bits(const CmByteEvents & ev, u32 & r, u
         r = r2;
         rmin = r < rmin ? r : rmin;
     }
-    return (l ^ (l + r)) < (1u << 24) || rmin == 0u;
 }
 // Where the coded bytes go.  Normally `out`, a buffer of its own.  In-place coding (gap != CM_NO_GAP): `out` lies
 // `gap` bytes BELOW the input inside the same buffer, so a byte may only be stored below the input bytes that every
@@ -586,8 +567,13 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     CmSink sink{out, global_ptr<u8>(jobs[blockIdx.x].side), jobs[blockIdx.x].gap, jobs[blockIdx.x].side_cap, n};
     // Fast path: all 8 bits of the byte without a single test.  While nothing is renormalised the intervals are
     // nested, so "a renormalisation was due after some bit" is equivalent to "the final interval lies within one
-    // 2^24 bucket" (:390): one test per byte.  If it fires (about one byte in four) the byte is coded again in two
-    // halves of 4 bits, each first without tests and only then, if its own test fires, bit by bit.
+    // 2^24 bucket" (:390): one test per byte (plus the guard against a range that reached zero on the way).  If it fires
+    // (about one byte in four) the byte is coded again in two halves of 4 bits, each first without tests and only then,
+    // if its own test fires, bit by bit.
+    // The lone live lane issues an instruction every 5-8 cycles whatever it is, so the instruction count of a byte IS the
+    // encoder's time (round 3 took ~15 of ~75 out: no test after the first half, a running ring offset in a vector register
+    // instead of seven instructions of address arithmetic per fetch, bytes coded in published groups so that the checks
+    // "is the next byte there" / "tell the model waves" run once per pair, the result committed before the single-armed test).
     // Branches are on wave-uniform conditions (ballot of the single live lane -> s_cbranch_vccnz): a divergent
     // `if` would save/restore EXEC, and every EXEC write stalls the following VALU op.  __builtin_expect keeps
     // the slow paths out of line: the common case must FALL THROUGH (a taken branch costs ~40 cycles on a lone wave).
@@ -596,33 +582,54 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     // are there already (the model waves run a chunk of 32 bytes ahead), so their LDS latency hides behind bits 4-7 and
     // nothing is waited for when byte i+1 starts.  (Issued at the top of a byte, the compiler's wait for the current byte's
     // registers also waits for the loads just issued; the scheduling barriers keep the fetch where it is written.)
+    u32 koff = vzero;  // byte offset of the NEXT byte's events in ring.k (64 bytes per byte; ring.m: half of it), a vector register
+    auto fetch = [&](CmByteEvents & e) __attribute__((always_inline)) {
+        const uint4 * __restrict__ pk = reinterpret_cast<const uint4 *>(reinterpret_cast<const u8 *>(ring.k) + koff);
+        const uint4 * __restrict__ pm = reinterpret_cast<const uint4 *>(reinterpret_cast<const u8 *>(ring.m) + (koff >> 1));
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint4 q = pk[j];
+            e.k[2 * j] = make_uint2(q.x, q.y);
+            e.k[2 * j + 1] = make_uint2(q.z, q.w);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint4 q = pm[j];
+            e.m[4 * j] = q.x; e.m[4 * j + 1] = q.y; e.m[4 * j + 2] = q.z; e.m[4 * j + 3] = q.w;
+        }
+    };
+    auto bucket_or_zero = [](u32 l, u32 r, u32 rmin) __attribute__((always_inline)) -> bool { return (l ^ (l + r)) < (1u << 24) || rmin == 0u; };
     auto code_byte = [&](const CmByteEvents & ev, CmByteEvents & next, const u32 i) __attribute__((always_inline)) {
-        u32 r = range, l = low;
-        const bool bad_half = cm_code_bits<0, 4>(ev, r, l);
+        u32 r = range, l = low, rmin = 0xFFFFFFFFu;
+        cm_code_bits_raw<0, 4>(ev, r, l, rmin);
         cm_sched_fence();
-        cm_load_events(ring, i + 1u, next);  // unconditional (a branch here would let the compiler move the fetch to the top of the byte): if byte i+1
-        cm_sched_fence();                     // is not there yet the slot still holds an older byte and the caller fetches again after waiting
-        const u32 r4 = r, l4 = l;
-        const bool bad = cm_code_bits<4, 4>(ev, r, l) || bad_half;  // (the half's own bucket test is implied by the final one; its range-reached-zero guard is not)
-        if (__builtin_expect(__ballot(bad) == 0ull, 1)) {
-            range = r;
-            low = l;
-        } else {
-            if (__ballot(bad_half) == 0ull) {
+        koff = (koff + 64u) & (CM_RING * 64u - 1u);
+        fetch(next);           // unconditional (a branch here would let the compiler move the fetch to the top of the byte): if byte i+1 is not
+        cm_sched_fence();      // there yet the slot still holds an older byte and the caller fetches again after waiting
+        const u32 r4 = r, l4 = l, rmin4 = rmin;
+        cm_code_bits_raw<4, 4>(ev, r, l, rmin);
+        const bool bad = bucket_or_zero(l, r, rmin);
+        const u32 range_old = range, low_old = low;
+        range = r;  // committed before the test: an `if` with one arm (cf. the decoder's walker)
+        low = l;
+        if (__builtin_expect(__ballot(bad) != 0ull, 0)) {
+            range = range_old;
+            low = low_old;
+            if (__ballot(bucket_or_zero(l4, r4, rmin4)) == 0ull) {  // (the half's own bucket test is implied by the final one; its range-reached-zero guard is not)
                 range = r4;
                 low = l4;
             } else {
                 cm_code_bits_checked<0, 4>(ev, range, low, sink, i);
             }
-            r = range, l = low;
-            if (__ballot(cm_code_bits<4, 4>(ev, r, l)) == 0ull) {
+            r = range, l = low, rmin = 0xFFFFFFFFu;
+            cm_code_bits_raw<4, 4>(ev, r, l, rmin);
+            if (__ballot(bucket_or_zero(l, r, rmin)) == 0ull) {
                 range = r;
                 low = l;
             } else {
                 cm_code_bits_checked<4, 4>(ev, range, low, sink, i);
             }
         }
-        if ((i & 15u) == 15u) LDS_POKE(s_cons, i + 1);
     };
     // Waits until the model waves have published byte i (false: they gave the block up).
     auto wait_for = [&](const u32 i) __attribute__((always_inline)) -> bool {
@@ -636,21 +643,21 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
         return true;
     };
     CmByteEvents eva, evb;
-    if (!wait_for(0)) return;
-    cm_load_events(ring, 0, eva);
-    for (u32 i = 0; i < n; i += 2) {
-        bool have = i + 1 < n && prod_seen > i + 1;
-        code_byte(eva, evb, i);
-        if (i + 1 >= n) break;
-        if (!have) {
-            if (!wait_for(i + 1)) return;
-            cm_load_events(ring, i + 1, evb);
+    for (u32 i = 0; i < n;) {
+        // the bytes below lim are published (whole chunks of 32, the block's last one apart): coded in pairs, the two register sets
+        // alternating.  koff points at byte i; the fetch inside code_byte moves it on.
+        if (!wait_for(i)) return;
+        fetch(eva);  // (again, if the fetch behind the previous pair came too early)
+        const u32 lim = prod_seen < n ? prod_seen : n;
+        while (i + 2u <= lim) {
+            code_byte(eva, evb, i);
+            code_byte(evb, eva, i + 1u);
+            i += 2u;
+            if ((i & 15u) == 0u) LDS_POKE(s_cons, i);
         }
-        have = i + 2 < n && prod_seen > i + 2;
-        code_byte(evb, eva, i + 1);
-        if (i + 2 < n && !have) {
-            if (!wait_for(i + 2)) return;
-            cm_load_events(ring, i + 2, eva);
+        if (i + 1u == lim) {  // one published byte left: the last byte of a block of odd length (lim == n)
+            code_byte(eva, evb, i);
+            i++;
         }
     }
     for (int j = 0; j < 4; j++) {  // flush (:425-432)

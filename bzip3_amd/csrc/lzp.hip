@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const LzpDecodeJob * __re
     const u32 max_out = jobs[blockIdx.x].max_out;
     u32 * __restrict__ lut = global_ptr<u32>(jobs[blockIdx.x].lut);
     s32 * __restrict__ result = global_ptr<s32>(jobs[blockIdx.x].result);
-    __shared__ u8 stage[LZD_CHUNK + 16];  // [0..3] = the 4 output bytes before the chunk, [4..] = input bytes
+    __shared__ __attribute__((aligned(16))) u8 stage[LZD_CHUNK + 32];  // [12..15] = the 4 output bytes before the chunk, [16..] = input bytes
     __shared__ u32 red[LZ_DRV / WAVE + 1];
     __shared__ u32 s_ip, s_op, s_copy_src, s_copy_cnt, s_fail;
     const u32 tid = threadIdx.x;
@@ -518,31 +518,49 @@ __global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const LzpDecodeJob * __re
         const u32 ip = s_ip, op = s_op;
         if (s_fail || ip >= n || op >= max_out) break;
         const u32 chunk = (n - ip > (u32)LZD_CHUNK) ? (u32)LZD_CHUNK : n - ip;
-        // stage the chunk (16 consecutive bytes per lane) and the 4 bytes of output context
-        u8 mine[16];
+        // stage the chunk (16 consecutive bytes per lane: ONE 16-byte load at any alignment; byte by byte only in the last, ragged
+        // lane of the block) and the 4 bytes of output context
         const u32 j0 = tid * 16u;
-#pragma unroll
-        for (int k = 0; k < 16; k++) mine[k] = (j0 + k < chunk) ? in[ip + j0 + k] : (u8)0;
-        if (tid < 4) stage[tid] = out[op - 4 + tid];
-#pragma unroll
-        for (int k = 0; k < 16; k++) stage[4 + j0 + k] = mine[k];
+        u32 w[4] = {0u, 0u, 0u, 0u};  // bytes j0 .. j0+15, little endian
+        if (j0 + 16u <= chunk) {
+            const PackedU128 q = *reinterpret_cast<const PackedU128 *>(in + ip + j0);
+            w[0] = q.v[0]; w[1] = q.v[1]; w[2] = q.v[2]; w[3] = q.v[3];
+        } else {
+            for (u32 k = 0; k < 16u; k++)
+                if (j0 + k < chunk) w[k >> 2] |= (u32)in[ip + j0 + k] << (8u * (k & 3u));
+        }
+        if (tid < 4) stage[12 + tid] = out[op - 4 + tid];
+        *reinterpret_cast<uint4 *>(&stage[16 + j0]) = make_uint4(w[0], w[1], w[2], w[3]);
+        // first 0xF2 of the lane's 16 bytes: a zero byte of (word ^ 0xF2F2F2F2), lowest first
         u32 first = 0xFFFFFFFFu;
 #pragma unroll
-        for (int k = 15; k >= 0; k--)
-            if (j0 + k < chunk && mine[k] == LZ_ESC) first = j0 + (u32)k;
+        for (int k = 3; k >= 0; k--) {
+            const u32 x = w[k] ^ (0x01010101u * (u32)LZ_ESC);
+            const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;  // bit 7 of a byte is set if that byte of x is zero (exact for the lowest such byte)
+            if (z) first = j0 + 4u * (u32)k + ((u32)__ffs((int)z) - 1u) / 8u;
+        }
+        if (first != 0xFFFFFFFFu && first >= chunk) first = 0xFFFFFFFFu;  // (the zero padding of a ragged lane holds no 0xF2, but be exact)
         first = block_min<LZ_DRV>(first, red);  // (also orders the LDS staging)
         const bool hit = first != 0xFFFFFFFFu;
         u32 lit = hit ? first : chunk;
         bool room = true;
         if (lit > max_out - op) { lit = max_out - op; room = false; }
-        // bulk literals: copy out and insert every (visited) output position into the table
-#pragma unroll 4
-        for (int k = 0; k < 16; k++) {
-            const u32 j = j0 + (u32)k;
-            if (j < lit) {
-                out[op + j] = mine[k];
-                const u32 ctx = ((u32)stage[j] << 24) | ((u32)stage[j + 1] << 16) | ((u32)stage[j + 2] << 8) | (u32)stage[j + 3];
-                atomicMax(&lut[lz_hash(ctx)], op + j);
+        // bulk literals: copy out and insert every (visited) output position into the table.  The context of position j is the 4 bytes
+        // before it: the lane's own bytes and the 4 bytes before them (one LDS word), as a sliding window in registers.
+        if (j0 < lit) {
+            u32 before = *reinterpret_cast<const u32 *>(&stage[12 + j0]);  // bytes j0-4 .. j0-1, little endian
+            if (j0 + 16u <= lit) {
+                PackedU128 q;
+                q.v[0] = w[0]; q.v[1] = w[1]; q.v[2] = w[2]; q.v[3] = w[3];
+                *reinterpret_cast<PackedU128 *>(out + op + j0) = q;
+            } else {
+                for (u32 k = 0; j0 + k < lit; k++) out[op + j0 + k] = (u8)(w[k >> 2] >> (8u * (k & 3u)));
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const u32 j = j0 + (u32)k;
+                if (j < lit) atomicMax(&lut[lz_hash(__builtin_bswap32(before))], op + j);  // (ctx = the 4 bytes, oldest in the top byte)
+                before = (before >> 8) | (((w[k >> 2] >> (8 * (k & 3))) & 0xFFu) << 24);
             }
         }
         __threadfence_block();
@@ -552,7 +570,7 @@ __global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const LzpDecodeJob * __re
             s_copy_cnt = 0;
             if (hit && room && o2 < max_out) {
                 // hash context of o2: the 4 bytes before it are stage[lit .. lit+3]
-                const u32 ctx = ((u32)stage[lit] << 24) | ((u32)stage[lit + 1] << 16) | ((u32)stage[lit + 2] << 8) | (u32)stage[lit + 3];
+                const u32 ctx = ((u32)stage[12 + lit] << 24) | ((u32)stage[13 + lit] << 16) | ((u32)stage[14 + lit] << 8) | (u32)stage[15 + lit];
                 const u32 cand = atomicExch(&lut[lz_hash(ctx)], o2);  // read the slot (at L2, where the atomics landed) and visit o2
                 if (cand > 0) {
                     i2++;

@@ -200,6 +200,7 @@ inline u64 dev_addr(const void * p) { return (u64)reinterpret_cast<uintptr_t>(p)
 
 // One 32-bit load at any byte address (gfx950 global/LDS accesses need no natural alignment).
 struct __attribute__((packed)) PackedU32 { u32 v; };
+struct __attribute__((packed)) PackedU128 { u32 v[4]; };  // one 128-bit access at any byte address
 __device__ __forceinline__ u32 load_u32_any(const u8 * p) { return reinterpret_cast<const PackedU32 *>(p)->v; }
 
 __device__ __forceinline__ u32 load_le32(const u8 * p) {
