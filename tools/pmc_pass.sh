@@ -18,3 +18,4 @@ python "$REPO/tools/rocpd_summary.py" --pmc "$F" "rocprofv3 --kernel-trace --pmc
 python "$REPO/tools/rocpd_summary.py" --pmc "$W" "rocprofv3 --kernel-trace --pmc WRITE_SIZE -- python bench.py $ARGS" > "$OUT/pmc_write.txt"
 python "$REPO/tools/pmc_traffic.py" "$F" "$W" "$OUT/bench_FETCH_SIZE.json" "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- python bench.py $ARGS; MI355X, ROCm 7.2"
 cp "$REPO/profiles/pmc_traffic.json" "$OUT/pmc_traffic.json"
+rm -rf "$OUT/FETCH_SIZE" "$OUT/WRITE_SIZE"  # the databases stay on the box: gpurun brings back 64 MiB at most
