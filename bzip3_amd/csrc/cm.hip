@@ -126,16 +126,13 @@ __device__ __forceinline__ void cm_model_init(M & m) {  // begin(): :350-358
 }
 
 // ------------------------------------------------------------------------------------------------
-// encode: four waves.
+// encode: two waves.
 //
-// The model factorises exactly by tree node: C0[node], C1[*][node] and the two C2 rows of a node are touched
-// only by the coded bits that pass through that node, and the encoder knows every byte up front.  So the three
-// "model" waves give every tree node its own lane (wave 1: levels 0-5 = nodes 1..63, wave 2: level 6 = nodes
-// 64..127, wave 3: level 7 = nodes 128..255, two per lane) and walk the block in chunks of 32 bytes:
-//   chain loop : for each byte of the chunk, the lanes whose node lies on that byte's path (one per level)
-//                read their counters, form p, read the two C2 cells, update all four counters, and leave
-//                (p, x1, x2, bit) in a per-wave LDS event array.  Only counter traffic is on this serial path;
-//                a counter that is hit again right away is forwarded in registers (BWT output is run-heavy);
+// The model factorises exactly by tree node: C0[node], C1[*][node] and the two C2 rows of a node are touched only by the coded bits
+// that pass through that node, and the encoder knows every byte up front.  So the "model" wave walks the block in chunks of 32 bytes:
+//   chain loop : lanes 0..7 take one tree LEVEL each; for every byte of the chunk a lane reads the three counters of its level's node
+//                on the byte's path, forms p, reads the two C2 cells, updates all four counters, and leaves (p, x1, x2, bit) in an
+//                LDS event array.  Only counter traffic is on this serial path, and the LDS keeps it in order;
 //   event loop : one lane per event finishes the interpolation (ssep, 18-bit probability) and writes the
 //                16-byte coder event into the LDS ring.
 // Wave 0 ("coder") drains the ring and runs the serial range recurrence.
@@ -151,6 +148,11 @@ __device__ __forceinline__ void cm_model_init(M & m) {  // begin(): :350-358
 // them to the scalar unit would cost a v_readfirstlane per operand.  A single wave issues one instruction every ~5.4
 // cycles (8.5 when dependent; profiles/r01_ubench_single_wave.txt), so instruction count is the currency.
 // ------------------------------------------------------------------------------------------------
+#ifdef BZ3_EMU
+constexpr u32 CM_ENC_SWAP_SHIFT = 0;
+#else
+constexpr u32 CM_ENC_SWAP_SHIFT = 9;
+#endif
 constexpr u32 CM_RING = 64;   // bytes of look-ahead between the model waves and the coder wave (8 KiB of LDS)
 constexpr u32 CM_CHUNK = 32;  // bytes per model-wave chunk
 
@@ -258,15 +260,6 @@ struct CmEvent {  // what the chain loop leaves for the event loop
     u32 x2b;      // x2 | bit << 16
 };
 
-// Per-lane constants of a model lane: LDS byte offsets are precomputed so that the chain body is branch-free.
-struct CmLane {
-    u32 node;      // first node of this lane (second one, if any, is node + 64)
-    u32 lvl;       // tree level of the node(s)
-    u32 hibit;     // 1 << lvl
-    u32 shr;       // 8 - lvl
-    u32 bitpos;    // 7 - lvl
-};
-
 // Counter updates without a branch on the bit (:347-348).  For a 16-bit counter x and shift s,
 //   bit = 1:  x + ((x ^ 65535) >> s)  ==  x - (x >> s) + (65535 >> s)      bit = 0:  x - (x >> s)
 // so every update is "x - (x >> s) + K" with K = bit ? (65535 >> s) : 0; the two C2 cells (s = 6) are done as one
@@ -277,68 +270,51 @@ __device__ __forceinline__ u32 cm_upd_pair6(u32 w, u32 k2) {
     return w - sh + k2;                     // no borrow/carry crosses the halves: each half stays within [0, 65535]
 }
 
-// One byte of the chain: wave-uniform (c, c1 << 8, c2 << 8, f) and the lanes of this wave whose node is on the path.
-template <int NSLOT, class M>
-__device__ __forceinline__ void cm_chain_step(M & m, CmEvent * __restrict__ ev_row, const CmLane & L, u32 c, u32 c1s, u32 c2s, u32 f,
-                                              u32 (&c0)[NSLOT]) {
-    const u32 path = L.hibit | (c >> L.shr);  // the node of this lane's level on this byte's path
-    bool hit = path == L.node;
-    if (NSLOT == 2) hit = hit || path == L.node + 64u;
-    if (hit) {
-        const u32 bit = (c >> L.bitpos) & 1u;
-        const u32 mk = 0u - bit;                        // all ones when the bit is 1
-        u32 p0 = c0[0];
-        if (NSLOT == 2) p0 = (path == L.node) ? c0[0] : c0[NSLOT - 1];
-        const u32 a1 = c1s + path, a2 = c2s + path;     // C1 indices (c1 * 256 + node)
-        const u32 p1 = m.c1[a1];
-        const u32 p2 = m.c1[a2];
-        const u32 p = (cm_mul24(p0 + p1, 7u) + 2u * p2) >> 4;  // :380 (p0 + p1 < 2^17)
-        const u32 ci = (2u * path + f) * CM_C2_STRIDE + (p >> 12);
-        const u32 w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[ci]));  // x1 | x2 << 16 (cells j, j+1)
-        const u32 na = cm_upd(p0, 2, mk & 16383u);      // :396-399 / :411-414
-        const u32 nb = cm_upd(p1, 4, mk & 4095u);
-        const u32 nw = cm_upd_pair6(w, mk & 0x03FF03FFu);
-        if (NSLOT == 2) {
-            c0[0] = (path == L.node) ? na : c0[0];
-            c0[NSLOT - 1] = (path == L.node) ? c0[NSLOT - 1] : na;
-        } else {
-            c0[0] = na;
-        }
-        m.c1[a1] = (u16)nb;
-        reinterpret_cast<PackedU32 *>(&m.c2[ci])->v = nw;
-        CmEvent e;
-        e.px1 = p | (bit << 16);
-        e.x2b = w;
-        *ev_row = e;
-    }
+// One byte of the chain, for the lane of one tree level: wave-uniform (c, c1 << 8, c2 << 8, f); the level's node on the byte's path.
+template <class M>
+__device__ __forceinline__ void cm_chain_step(M & m, CmEvent * __restrict__ ev_row, u32 hibit, u32 shr, u32 bitpos, u32 c, u32 c1s, u32 c2s, u32 f) {
+    const u32 node = hibit | (c >> shr);
+    const u32 bit = (c >> bitpos) & 1u;
+    const u32 mk = 0u - bit;                        // all ones when the bit is 1
+    const u32 a1 = c1s + node, a2 = c2s + node;     // C1 indices (c1 * 256 + node)
+    const u32 p0 = m.c0[node];
+    const u32 p1 = m.c1[a1];
+    const u32 p2 = m.c1[a2];
+    const u32 p = cm_mad24(p0 + p1, 7u, 2u * p2) >> 4;  // :380 (p0 + p1 < 2^17)
+    const u32 ci = (2u * node + f) * CM_C2_STRIDE + (p >> 12);
+    const u32 w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[ci]));  // x1 | x2 << 16 (cells j, j+1)
+    m.c0[node] = (u16)cm_upd(p0, 2, mk & 16383u);   // :396-399 / :411-414
+    m.c1[a1] = (u16)cm_upd(p1, 4, mk & 4095u);
+    reinterpret_cast<PackedU32 *>(&m.c2[ci])->v = cm_upd_pair6(w, mk & 0x03FF03FFu);
+    CmEvent e;
+    e.px1 = p | (bit << 16);
+    e.x2b = w;
+    *ev_row = e;
 }
 
-// One chunk of one model wave.  NSLOT = nodes per lane (1 or 2).  lvl_lo / nlvl = tree levels this wave owns.
-template <int NSLOT, bool FULL, class M>
-__device__ __forceinline__ void cm_model_chunk(M & m, CmEvent * __restrict__ ev, CmRing & ring, const u32 packed, const u32 fmask,
-                                               const u32 cnt, const u32 base, const CmLane & L, const u32 lvl_lo, const u32 nlvl, u32 (&c0)[NSLOT]) {
+// One chunk of the model wave: the chain (lanes 0..7, one tree level each, serial over the bytes), then the events (all lanes).
+template <bool FULL, class M>
+__device__ __forceinline__ void cm_model_chunk(M & m, CmEvent * __restrict__ ev, CmRing & ring, const u32 packed, const u32 fmask, const u32 cnt, const u32 base,
+                                               const bool chain_lane, const u32 hibit, const u32 shr, const u32 bitpos, const u32 lvl) {
     const int lane = lane_id();
-    CmEvent * __restrict__ ev_lvl = ev + (L.lvl - lvl_lo) * CM_CHUNK;
-    // ---- chain loop: serial in time, parallel over the nodes of this wave ------------------------------
-    if (FULL) {
+    CmEvent * __restrict__ ev_lvl = ev + lvl * CM_CHUNK;
+    // ---- chain loop: serial in time, parallel over the levels ------------------------------------------
+    u32 wv[CM_CHUNK];  // byte r | row of byte r-1 << 8 | row of byte r-2 << 16   (wave-uniform; row = byte value when R = 0)
+#pragma unroll
+    for (int r = 0; r < (int)CM_CHUNK; r++) wv[r] = cm_readlane(packed, r);
+    if (chain_lane) {
 #pragma unroll
         for (int r = 0; r < (int)CM_CHUNK; r++) {
-            const u32 w = cm_readlane(packed, r);  // byte r | row of byte r-1 << 8 | row of byte r-2 << 16   (wave-uniform; row = byte value when R = 0)
-            cm_chain_step<NSLOT>(m, ev_lvl + r, L, w & 0xFFu, w & 0xFF00u, (w >> 8) & 0xFF00u, (fmask >> r) & 1u, c0);
-        }
-    } else {
-        for (u32 r = 0; r < cnt; r++) {
-            const u32 w = cm_readlane(packed, (int)r);
-            cm_chain_step<NSLOT>(m, ev_lvl + r, L, w & 0xFFu, w & 0xFF00u, (w >> 8) & 0xFF00u, (fmask >> r) & 1u, c0);
+            if (FULL || (u32)r < cnt) cm_chain_step(m, ev_lvl + r, hibit, shr, bitpos, wv[r] & 0xFFu, wv[r] & 0xFF00u, (wv[r] >> 8) & 0xFF00u, (fmask >> r) & 1u);
         }
     }
     wave_sync();
     // ---- event loop: one lane per event, 18-bit probability -> coder event ----------------------------
-    const u32 nev = nlvl * CM_CHUNK;
+    const u32 nev = 8u * CM_CHUNK;
     for (u32 e0 = 0; e0 < nev; e0 += WAVE) {
         const u32 e = e0 + (u32)lane;
-        const u32 r = e % CM_CHUNK, k = lvl_lo + e / CM_CHUNK;
-        if (e < nev && r < cnt) {
+        const u32 r = e % CM_CHUNK, k = e / CM_CHUNK;
+        if (r < cnt) {
             const CmEvent q = ev[e];
             const int p = (int)(q.px1 & 0xFFFFu), x1 = (int)(q.x2b & 0xFFFFu), x2 = (int)(q.x2b >> 16);
             const u32 bit = q.px1 >> 16;
@@ -456,11 +432,11 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     const u32 debug = jobs[blockIdx.x].debug & 15u;
     __shared__ CmLdsT<R> m;
     __shared__ __attribute__((aligned(16))) CmRing ring;
-    __shared__ CmEvent ev_a[6 * CM_CHUNK], ev_b[CM_CHUNK], ev_c[CM_CHUNK];
-    __shared__ u32 s_prod[3], s_cons;
-    __shared__ CmRowCache<R> rcs[R ? 3 : 1];  // R > 0: one private directory per model wave
-    if (threadIdx.x < 3) s_prod[threadIdx.x] = 0;
-    if (threadIdx.x == 3) s_cons = 0;
+    __shared__ CmEvent ev[8 * CM_CHUNK];
+    __shared__ u32 s_prod, s_cons;
+    __shared__ CmRowCache<R> rc;  // R > 0: the directory of the row cache
+    if (threadIdx.x == 0) s_prod = 0;
+    if (threadIdx.x == 1) s_cons = 0;
     if (debug == 1)  // profiling only: a ring full of p = 1/2 events, so the lone coder emits exactly one byte per input byte
         for (u32 t = threadIdx.x; t < CM_RING * 8; t += blockDim.x) {
             ring.k[t] = make_uint2(0u, 0u);
@@ -468,24 +444,25 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
         }
     cm_model_init(m);
     const int lane = lane_id();
-    const u32 role = cm_uniform((u32)wave_id());
+    // Which of the two waves codes.  The hardware deals the waves of the workgroups of a CU round the four SIMDs in turn, so with two
+    // waves per workgroup the first and the third workgroup of a CU land on the same pair of SIMDs; a launch of three blocks per CU puts
+    // blocks k, k + 256 and k + 512 on one CU (tools/cm_wave_placement.py shows both for the decoder).  The third one swaps its roles,
+    // so that no two coder waves -- the critical path of their blocks -- share a SIMD.  (The emulator swaps every other block instead:
+    // its batches are small.)
+    const u32 role = cm_uniform((u32)wave_id()) ^ ((blockIdx.x >> CM_ENC_SWAP_SHIFT) & 1u);
     if (role != 0) {
         if (debug == 1) return;
-        // ---- model waves -----------------------------------------------------------------------------
-        const u32 lvl_lo = role == 1 ? 0u : role == 2 ? 6u : 7u;
-        const u32 nlvl = role == 1 ? 6u : 1u;
-        CmLane L;
-        L.node = role == 1 ? (u32)lane : role == 2 ? 64u + (u32)lane : 128u + (u32)lane;
-        L.lvl = role == 1 ? (lane ? (u32)(31 - __clz(lane)) : 0u) : lvl_lo;  // lane 0 of wave 1 owns no node (node 0 never matches)
-        L.hibit = 1u << L.lvl;
-        L.shr = 8u - L.lvl;
-        L.bitpos = 7u - L.lvl;
-        CmEvent * ev = role == 1 ? ev_a : role == 2 ? ev_b : ev_c;
-        u32 c0a[1] = {32768u}, c0b[2] = {32768u, 32768u};  // C0 of this lane's node(s) lives in registers
+        // ---- model wave ------------------------------------------------------------------------------
+        // Lanes 0..7 walk the counter chain, one tree LEVEL each: the node of a level is picked by the byte (hibit | byte >> shr), its
+        // three counters are read from LDS, updated and written back in program order -- the LDS serves a wave's requests in order,
+        // so a counter that is hit again by the next byte needs no forwarding.  (Rounds 1-2 gave every NODE a lane and C0 a
+        // register, which took three waves of which 8 lanes were busy; at three blocks per CU those ~125 wave instructions per
+        // byte, not the coder's ~60, were what the SIMDs ran out of: round 3.)
+        const u32 lvl = (u32)lane & 7u;
+        const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
+        const bool chain_lane = lane < 8;
         u32 cons_seen = 0;
         u32 hist = 0;  // the 4 bytes before the chunk, oldest in the top byte (zeros before the block starts)
-        // R > 0: row cache of this wave
-        CmRowCache<R> & rc = rcs[R ? role - 1 : 0];
         CmRowState rs;
         u16 * __restrict__ spill = global_ptr<u16>(jobs[blockIdx.x].spill);
         const u32 miss_base = jobs[blockIdx.x].miss_base, miss_shift = jobs[blockIdx.x].miss_shift;
@@ -505,12 +482,11 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
             const u32 mine = ((u32)lane < cnt) ? in[base + lane] : 0u;
             u32 rowv = 0;
             if (R) {
-                rowv = role == 3 ? cm_rows_chunk<R, 2>(m, rc, rs, spill, mine, cnt, hrow1, hrow2, L.node)
-                                 : cm_rows_chunk<R, 1>(m, rc, rs, spill, mine, cnt, hrow1, hrow2, L.node);
+                rowv = cm_rows_chunk<R, 4>(m, rc, rs, spill, mine, cnt, hrow1, hrow2, (u32)lane);  // (the wave moves whole rows: four cells per lane)
                 if (__builtin_expect(rs.misses > miss_base + (base >> miss_shift) && base < abort_limit, 0)) {
-                    // the working set does not fit: give the block up (every model wave gets here at the same chunk)
-                    if (role == 1 && lane == 0) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
-                    LDS_POKE(s_prod[role - 1], CM_ABORT_MARK);
+                    // the working set does not fit: give the block up
+                    if (lane == 0) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
+                    LDS_POKE(s_prod, CM_ABORT_MARK);
                     return;
                 }
             }
@@ -533,13 +509,8 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
             const u32 i = base + (u32)lane;
             const bool fr = (u32)lane < cnt && i >= 2 && (prev4 & 0xFFu) == ((prev4 >> 8) & 0xFFu) && (prev4 & 0xFFFFu) == (prev4 >> 16);
             const u32 fmask = (u32)__ballot(fr);
-            if (role == 3) {
-                if (cnt == CM_CHUNK) cm_model_chunk<2, true>(m, ev, ring, packed, fmask, cnt, base, L, lvl_lo, nlvl, c0b);
-                else cm_model_chunk<2, false>(m, ev, ring, packed, fmask, cnt, base, L, lvl_lo, nlvl, c0b);
-            } else {
-                if (cnt == CM_CHUNK) cm_model_chunk<1, true>(m, ev, ring, packed, fmask, cnt, base, L, lvl_lo, nlvl, c0a);
-                else cm_model_chunk<1, false>(m, ev, ring, packed, fmask, cnt, base, L, lvl_lo, nlvl, c0a);
-            }
+            if (cnt == CM_CHUNK) cm_model_chunk<true>(m, ev, ring, packed, fmask, cnt, base, chain_lane, hibit, shr, bitpos, lvl);
+            else cm_model_chunk<false>(m, ev, ring, packed, fmask, cnt, base, chain_lane, hibit, shr, bitpos, lvl);
             // history for the next chunk (only needed after a full chunk): byte -d of the next chunk = byte cnt-d of this one
             if (cnt == CM_CHUNK) {
                 hist = cm_readlane(mine, (int)CM_CHUNK - 1) | (cm_readlane(mine, (int)CM_CHUNK - 2) << 8) | (cm_readlane(mine, (int)CM_CHUNK - 3) << 16) |
@@ -550,7 +521,7 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
                 }
             }
             lds_release();
-            if (lane == 0) LDS_POKE(s_prod[role - 1], base + cnt);
+            if (lane == 0) LDS_POKE(s_prod, base + cnt);
         }
         return;
     }
@@ -634,10 +605,9 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     // Waits until the model waves have published byte i (false: they gave the block up).
     auto wait_for = [&](const u32 i) __attribute__((always_inline)) -> bool {
         while (prod_seen <= i) {
-            const u32 a = LDS_PEEK(s_prod[0]), b = LDS_PEEK(s_prod[1]), c = LDS_PEEK(s_prod[2]);
-            prod_seen = a < b ? (a < c ? a : c) : (b < c ? b : c);
+            prod_seen = LDS_PEEK(s_prod);
             if (prod_seen <= i) BZ3_SPIN_PAUSE();
-            if (R && prod_seen == CM_ABORT_MARK) return false;  // all three model waves gave the block up; nothing of it is coded past their last chunk
+            if (R && prod_seen == CM_ABORT_MARK) return false;  // the model wave gave the block up; nothing of it is coded past its last chunk
         }
         lds_acquire();
         return true;
@@ -676,11 +646,11 @@ constexpr int CM_ROWS3_DEC = 56;  // 28 KiB of C1 rows: 50.8 KB of LDS per workg
 constexpr int CM_ROWS_TEST = 40;  // emulator tests: small enough that short inputs recycle slots all the time
 #endif
 
-__global__ void __launch_bounds__(256) k_cm_encode(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<0>(jobs); }
-__global__ void __launch_bounds__(256) k_cm_encode_rows(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<CM_ROWS_ENC>(jobs); }
-__global__ void __launch_bounds__(256) k_cm_encode_rows3(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<CM_ROWS3_ENC>(jobs); }
+__global__ void __launch_bounds__(128) k_cm_encode(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<0>(jobs); }
+__global__ void __launch_bounds__(128) k_cm_encode_rows(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<CM_ROWS_ENC>(jobs); }
+__global__ void __launch_bounds__(128) k_cm_encode_rows3(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<CM_ROWS3_ENC>(jobs); }
 #ifdef BZ3_EMU
-__global__ void __launch_bounds__(256) k_cm_encode_rows_test(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<CM_ROWS_TEST>(jobs); }
+__global__ void __launch_bounds__(128) k_cm_encode_rows_test(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<CM_ROWS_TEST>(jobs); }
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -1180,11 +1150,11 @@ __global__ void __launch_bounds__(320) k_cm_decode_sync_test(const CmDecodeJob *
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant) {
     if (!njobs) return;
 #ifdef BZ3_EMU
-    if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_encode_rows_test, dim3(njobs), dim3(256), 0, s, d_jobs);
+    if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_encode_rows_test, dim3(njobs), dim3(128), 0, s, d_jobs);
 #endif
-    if (variant == CM_VARIANT_ROWS3) launch(k_cm_encode_rows3, dim3(njobs), dim3(256), 0, s, d_jobs);
-    else if (variant == CM_VARIANT_ROWS) launch(k_cm_encode_rows, dim3(njobs), dim3(256), 0, s, d_jobs);
-    else launch(k_cm_encode, dim3(njobs), dim3(256), 0, s, d_jobs);
+    if (variant == CM_VARIANT_ROWS3) launch(k_cm_encode_rows3, dim3(njobs), dim3(128), 0, s, d_jobs);
+    else if (variant == CM_VARIANT_ROWS) launch(k_cm_encode_rows, dim3(njobs), dim3(128), 0, s, d_jobs);
+    else launch(k_cm_encode, dim3(njobs), dim3(128), 0, s, d_jobs);
 }
 
 void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant, bool prof) {
