@@ -826,3 +826,44 @@ def test_cm_decoder_fast_walk_rarely_falls_back(emu, oracle, cm_mode, monkeypatc
     assert 0.5 * len(coded) / n < slow <= len(coded) / n + 0.01, (slow, len(coded) / n)
     rep = float((np.frombuffer(plain, dtype=np.uint8)[1:] == np.frombuffer(plain, dtype=np.uint8)[:-1]).mean())
     assert abs(wrong - (1.0 - rep)) < 0.01, (wrong, rep)  # wrong guesses = bytes that do not repeat their predecessor
+
+
+def test_lzp_decoder_chunks_alignments_and_caps(emu, oracle):
+    """k_lzp_decode works in trips of 16 KiB with one 16-byte access per lane each way (lzp.hip): several trips, 0xF2 bytes at every
+    alignment inside the 16 bytes of a lane, a ragged last lane, outputs capped at awkward places (the decoder stops AT the cap,
+    :211), and streams that are not LZP output at all -- always the oracle's (count, bytes)."""
+    g = bzip3_amd.StageApi(emu)
+    rng = np.random.default_rng(17)
+    t = datagen.shakespeare()
+    body = bytearray((t[20000:26000] * 4 + t[40000:52000] + t[20000:23000]) * 2)  # repeats: LZP applies
+    for k in rng.integers(0, len(body), size=400):
+        body[int(k)] = 0xF2  # escapes all over, at every offset modulo 16
+    data = bytes(body)
+    nlz, lz = oracle.lzp_encode(data)
+    assert 0 < nlz == len(lz) < len(data) - 8
+    for cap in (len(data) + 100, len(data), len(data) - 1, 32768 + 7, 16384 + 3, 16384, 16383, 4000, 17, 5):
+        assert g.lzp_decode(lz, cap) == oracle.lzp_decode(lz, cap), cap
+    for cut in (len(lz) - 1, len(lz) // 2, 16384 + 5, 4):  # truncated streams
+        assert g.lzp_decode(lz[:cut], len(data) + 100) == oracle.lzp_decode(lz[:cut], len(data) + 100), cut
+    for seed in range(3):  # arbitrary bytes with many escapes: matches into garbage, lengths running past the cap
+        r2 = np.random.default_rng(100 + seed)
+        junk = bytes(r2.choice(np.frombuffer(b"ab\xf2\xf2\xff\xfe\x00q", dtype=np.uint8), size=40000))
+        for cap in (60000, 33000, 1000):
+            assert g.lzp_decode(junk, cap) == oracle.lzp_decode(junk, cap), (seed, cap)
+
+
+def test_unbwt_single_walk_with_strided_splitters(emu, oracle):
+    """Blocks of more than 2^17 rows cut the psi chain at hashed splitter rows (one in 2, 4, 8 ... rows: unbwt.hip); every splitter
+    walks its segment once, parks the bytes in a slab of 4 x the mean segment length and leaves the rest of a longer segment to
+    k_ub_walk_long.  Genuine transforms come back as the text; arbitrary (bytes, index) pairs as what the reference makes of them."""
+    g = bzip3_amd.StageApi(emu)
+    rng = np.random.default_rng(23)
+    t = datagen.shakespeare()
+    for n in (140000, 300000, 600000):  # one splitter per 1 / 2 / 4 rows
+        src = t[1000 : 1000 + n]
+        idx, u = oracle.bwt(src)
+        assert g.unbwt(u, idx) == (0, src), n
+        junk = bytes(rng.integers(0, 5, size=n, dtype=np.uint8))
+        jidx = int(rng.integers(1, n + 1))
+        assert g.unbwt(junk, jidx) == oracle.unbwt(junk, jidx), n
+        assert g.unbwt(u, jidx) == oracle.unbwt(u, jidx), n
