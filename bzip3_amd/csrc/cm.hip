@@ -70,16 +70,7 @@ __device__ __forceinline__ u32 cm_uniform(u32 v) {
 #endif
 }
 
-// a * b for operands below 2^24: one full-rate v_mul_u32_u24 / v_mad_u32_u24 (a 32-bit v_mul_lo_u32 runs at quarter rate)
-__device__ __forceinline__ u32 cm_mul24(u32 a, u32 b) {
-#ifdef BZ3_EMU
-    return a * b;
-#else
-    return __umul24(a, b);
-#endif
-}
-
-// a * b + c for a, b below 2^24, as the one full-rate instruction it is (left to the compiler, `cm_mul24(a, b) + c` becomes a
+// a * b + c for a, b below 2^24, as the one full-rate instruction it is (left to the compiler, `__umul24(a, b) + c` becomes a
 // quarter-rate v_mul_lo_u32 or v_mad_u64_u32 whenever it cannot prove the operand ranges itself)
 __device__ __forceinline__ u32 cm_mad24(u32 a, u32 b, u32 c) {
 #ifdef BZ3_EMU
@@ -528,12 +519,7 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     // ---- coder wave: ONE active lane (an LDS read then returns 16 bytes, not 64 x 16) ------------------------
     if (debug == 2 || lane != 0) return;
     cm_raise_priority();  // the coder is the critical path of its block (measured at three per CU: -9 .. -14 % launch time, profiles/r02_cm_priority.txt)
-    u32 vzero;
-#ifdef BZ3_EMU
-    vzero = 0;
-#else
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));  // opaque zero: keeps the recurrence on the vector ALU
-#endif
+    const u32 vzero = cm_opaque_zero();  // keeps the recurrence on the vector ALU
     u32 range = 0xFFFFFFFFu ^ vzero, low = vzero, prod_seen = debug == 1 ? 0xFFFFFFFFu : 0u;
     CmSink sink{out, global_ptr<u8>(jobs[blockIdx.x].side), jobs[blockIdx.x].gap, jobs[blockIdx.x].side_cap, n};
     // Fast path: all 8 bits of the byte without a single test.  While nothing is renormalised the intervals are
@@ -848,7 +834,7 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         };
         // byte 0: nothing to guess (c1 = c2 = 0, run = 1, :367-372)
         const u32 first = *c1col;
-        CmEvalP prev = evaluate(ptab0, c1col, first, cm_mul24(c0 + first, 7u) + 2u * first, c2row0);
+        CmEvalP prev = evaluate(ptab0, c1col, first, cm_mad24(c0 + first, 7u, 2u * first), c2row0);
         u32 k1 = 0;        // newest confirmed byte (byte i-2 inside the loop; the initial c1 = 0 before the block starts)
         u32 run_prev = 1;  // run counter the evaluation of byte i-1 was made with
         CM_LDS u16 * c2row = c2row0;  // the C2 row for the run flag of the NEXT speculative evaluation (flag = run_prev + 1 > 2)

@@ -247,7 +247,12 @@ __global__ void __launch_bounds__(UB_BLOCK) k_ub_tail(const u8 * __restrict__ in
     if (gid == 0) out[n - 1] = (u8)lastc;
 }
 
-size_t unbwt_workspace_bytes(u64 n) { return (n + 64) * 8 + radix_temp_bytes(n) + scan_temp_words(n + 1) * 4 + ((n >> 8) + 4096) * 40 + (n + (n >> 3) + (1u << 20)) * 4 + (1u << 20); }  // psi, ids, sorter, scans, splitter arrays, slabs (4 bytes per row + 12 %)
+// psi, splitter ids, the sorter's and the scans' scratch, seven splitter arrays, the slabs (4 bytes per row and a margin).  Splitters:
+// every row below 2^17 rows, between 2^17 and 2^18 of them up to 2^25 rows, one row in 256 beyond (hashed: a few per cent either way).
+size_t unbwt_workspace_bytes(u64 n) {
+    const u64 splitters = n + 1 < 300000 ? n + 1 : 300000 + (n >> 7);
+    return (n + 64) * 8 + radix_temp_bytes(n) + scan_temp_words(n + 1) * 4 + (splitters + 4096) * 32 + (n + (n >> 3)) * 4 + (8u << 20);
+}
 
 void bwt_inverse(const u8 * d_in, u32 n, u32 idx, u8 * d_out, Arena & tmp, hipStream_t s) {
     if (n == 0) return;
