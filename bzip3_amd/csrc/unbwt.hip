@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(UB_BLOCK) k_ub_tail(const u8 * __restrict__ in
 // every row below 2^17 rows, between 2^17 and 2^18 of them up to 2^25 rows, one row in 256 beyond (hashed: a few per cent either way).
 size_t unbwt_workspace_bytes(u64 n) {
     const u64 splitters = n + 1 < 300000 ? n + 1 : 300000 + (n >> 7);
-    return (n + 64) * 8 + radix_temp_bytes(n) + scan_temp_words(n + 1) * 4 + (splitters + 4096) * 32 + (n + (n >> 3)) * 4 + (8u << 20);
+    return (n + 64) * 8 + radix_temp_bytes(n) + scan_temp_words(n + 1) * 4 + (splitters + 4096) * 32 + (n + (n >> 3)) * 4 + (1u << 20);
 }
 
 void bwt_inverse(const u8 * d_in, u32 n, u32 idx, u8 * d_out, Arena & tmp, hipStream_t s) {
