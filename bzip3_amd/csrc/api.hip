@@ -55,7 +55,8 @@ struct DeviceCtx {
     // side streams of the device: the serial LZP drivers of a window of blocks run there while the calling thread drives the
     // whole-GPU stages of the neighbouring windows on the group's stream (encode_group and decode_group: one side stream per slot
     // of their rings, so that the serial kernels of consecutive windows overlap)
-    static constexpr int AUX = 4;
+    static constexpr int AUX = 8;           // side streams / ring slots available; the rings use four unless a test or an experiment asks for more
+    static constexpr int RING_SLOTS = 4;
     hipStream_t aux[AUX] = {};
     hipEvent_t ev_prep = nullptr, ev_d0[AUX] = {}, ev_d1[AUX] = {};
     bool aux_ready = false;
@@ -578,14 +579,14 @@ void encode_finish(bz3_state * st, float cm_ms) {
 }
 
 // Shape of the encoder's front-end pipeline: `contexts` LZP contexts fit into the memory budget, the batch has n blocks.
-// ns context slots (2..DeviceCtx::AUX) of `window` blocks each.  A window's drivers hide behind the whole-GPU work of ns-1 other
+// ns context slots (2..DeviceCtx::RING_SLOTS; up to DeviceCtx::AUX when forced) of `window` blocks each.  A window's drivers hide behind the whole-GPU work of ns-1 other
 // windows, so the drivers' share of the pace is T_driver / ((ns-1) * window) per block: more slots of fewer blocks get more out
 // of the same memory (4 x 4 hides as much as 2 x 12).  Small batches keep the two-slot form (nothing to overlap with anyway).
 // BZ3_HIP_LZP_PIPE="window,slots" overrides (tests / experiments).
 void pipeline_shape(s32 contexts, s32 n, s32 & window, s32 & ns) {
     if (contexts < 2) contexts = 2;
     ns = 2;
-    for (s32 cand = DeviceCtx::AUX; cand > 2; cand--)
+    for (s32 cand = DeviceCtx::RING_SLOTS; cand > 2; cand--)
         if (contexts / cand >= 3 && n >= cand * 3) {
             ns = cand;
             break;
