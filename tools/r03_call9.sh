@@ -4,7 +4,7 @@ OUT=$(realpath -m "$1")
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$OUT"
 cd "$REPO"
-OLD=bzip3_amd/lib/ab/libbzip3_f98d2d6.so
+OLD=bzip3_amd/lib/ab/libbzip3_f98d2d6.so  # built beforehand (not in git): git worktree add /tmp/wt f98d2d6 && (cd /tmp/wt && python bzip3_amd/build.py) && cp /tmp/wt/bzip3_amd/lib/libbzip3.so $OLD
 echo "== parity (subset of the GPU suite)"
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "stage_parity or block_parity or cm_ or lean or rings or mutated or golden or batch_api or three_blocks" > "$OUT/parity.log" 2>&1
 tail -3 "$OUT/parity.log"
