@@ -16,35 +16,52 @@ requested ones.  A watchdog thread prints the line with whatever has been measur
 deadline (--deadline-s) is reached while an optional extra leg is still running.
 
 Two timed steps when the budget allows (both reported, with their spread; the first includes the first-call effects:
-workspace allocation).  "cpu_baseline": the REAL reference (oracle/_ref) through its own bz3_encode_blocks /
-bz3_decode_blocks on min(cores, 64) host threads x 256 MiB blocks -- the same blocks the GPU coded, and the reference's
-coded bytes are compared with the GPU's (bit-exact parity at the metric's block size).  It runs on the host WHILE the GPU
-runs its second timed step (a step is one blocking C call that leaves the host's cores idle).  64 threads because the
+workspace allocation).  NOTHING else runs on the host or the GPU during the timed steps (round 3 ran the CPU baseline as
+threads of this process during the second step, which slowed that step's front end 2.6x: profiles/r04_host_contention.json).
+
+"cpu_baseline": the REAL reference (oracle/_ref) through its own bz3_encode_blocks / bz3_decode_blocks on min(cores, 64)
+host threads x 256 MiB blocks -- the same blocks the GPU coded, and the reference's coded bytes are compared with the GPU's
+(bit-exact parity at the metric's block size).  It runs AFTER the timed steps in a PROCESS OF ITS OWN (this file with
+--cpu-worker; no torch, no HIP runtime), pinned to cores this process does not use, the blocks handed over in anonymous
+shared memory (memfd); meanwhile this process only runs GPU legs that need no host cores.  64 threads because the
 reference's own CLI caps -j at 64 (src/main.c:213) and its batch API is documented for 2-16 blocks (libbz3.h:202).
 
+Workload: "enwik-style" text = the word-bigram Markov chain over shakespeare.txt tokens of SURVEY.md 8d with 3.5 % of its
+tokens replaced by random [a-z0-9] strings (tests/datagen.py ENWIK_NOISE: the fraction at which 100,000,000 B compress to
+enwik8's 4.41 : 1 at the reference's default -b 16, etc/BENCHMARKS.md:45-47).  Eight independent 256 MiB texts are
+generated; block k is text k mod 8 with its 64 KiB pieces in a block-specific order.
+
 Extra legs after the timed region (rank 0, N=1 only, each only while the budget lasts), all in "configs":
+  random      768 incompressible blocks (LZP and RLE decline, the coder emits ~1.004 bytes per byte), reference beside it;
+  mixed       text, binary and incompressible blocks in ONE batch (the single CM launch lasts as long as its slowest
+              block, and blocks the row-cache kernels give up are coded again: cm_blocks_given_up is reported);
+  cfg5_unbwt  BASELINE.json configs[4]'s stage: the inverse BWT of one 511 MiB block (the maximum block size) of a
+              skewed order-1 Markov source over 16 symbols, GB/s against the stage's 11 B per byte;
   cfg3        BASELINE.json configs[2]: 1,000,000,000 B of text at -b 256 = 4 blocks on one GPU, with the
               reference's -j 4 path timed on the host beside it;
   cfg2        BASELINE.json configs[1]: 100,000,000 B at -b 32 = 3 blocks, with -j 3 beside it;
-  cfg5_unbwt  BASELINE.json configs[4]'s stage: the inverse BWT of one 511 MiB block (the maximum block size) of a
-              skewed order-1 Markov source over 16 symbols, GB/s against the stage's 11 B per byte;
-  mixed       text, binary and incompressible blocks in ONE batch (the single CM launch lasts as long as its slowest
-              block, and blocks the row-cache kernels give up are coded again: cm_blocks_given_up is reported);
-  random      incompressible blocks (LZP and RLE decline, the coder emits ~1 byte per byte).
+  host_api    SURVEY.md 8d's timing boundary: a GPU-filling batch through bz3_encode_blocks / bz3_decode_blocks on malloc'ed
+              HOST buffers (H2D / D2H included), and the same batch device-resident: the PCIe-inclusive ratio.
+`--leg cfg5` (not part of the default run: a 511 MiB block's CM launches take twice as long as a 256 MiB block's) times a
+GPU-filling batch of 511 MiB blocks of the 16-symbol source.
 
 Multi-GPU: blocks are independent, so each rank owns `--blocks` blocks on its own GPU (weak
 scaling), there is NO data-path collective; torch.distributed (RCCL) is used only for the barrier and the
-max-over-ranks timing the contract asks for.
+max-over-ranks timing the contract asks for.  `python bench.py --gpus N` with no WORLD_SIZE in the environment starts its
+own N ranks (torch.distributed.run on 127.0.0.1); under torch.distributed.run it is one of the ranks:
 
   python bench.py                       # N=1, default workload
+  python bench.py --gpus 8 --steps 1 --warmup 0          # spawns 8 ranks itself
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
-         bench.py --gpus 8 --steps 1 --warmup 0
+         bench.py --gpus 8 --steps 1 --warmup 0          # the driver's form
 """
 import argparse
 import ctypes as C
 import json
 import os
 import signal
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -92,9 +109,25 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=64)
     ap.add_argument("--cpu-block-mib", type=float, default=0.0, help="CPU baseline block size (0 = the bench's block size)")
     ap.add_argument("--cfg3-bytes", type=int, default=CFG3_BYTES, help="size of the cfg3 leg (only BASELINE's 1,000,000,000 B at 256 MiB blocks is reported as cfg3)")
-    ap.add_argument("--random-block-mib", type=float, default=32.0)
-    ap.add_argument("--random-blocks", type=int, default=64)
+    ap.add_argument("--random-block-mib", type=float, default=8.0)
+    ap.add_argument("--random-blocks", type=int, default=0, help="blocks of the random leg (0 = as many as the timed batch)")
+    ap.add_argument("--host-api-block-mib", type=float, default=32.0, help="block size of the host_api leg (0 = skip the leg)")
+    ap.add_argument("--noise", type=float, default=-1.0, help="fraction of noise tokens in the text (-1 = tests/datagen.py ENWIK_NOISE, the enwik8 calibration)")
+    ap.add_argument("--text-bases", type=int, default=8, help="independent texts the blocks are drawn from")
+    ap.add_argument("--leg", default="", choices=["", "cfg5"], help="run ONE optional leg instead of the default workload (cfg5: a GPU-filling batch of 511 MiB blocks)")
+    ap.add_argument("--emu", action="store_true", help="TESTS ONLY: the CPU emulator build of the kernels (tests/emu) and gloo instead of a GPU and RCCL; checks the control flow, measures nothing")
+    ap.add_argument("--cpu-worker", default="", help="internal: run the reference on the blocks described by this JSON file (the cpu_baseline process)")
     return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """`--gpus N` without torch.distributed.run around it: start the N ranks ourselves (one process per GPU, 127.0.0.1 rendezvous)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def elapsed():
@@ -161,20 +194,21 @@ def start_watchdog(deadline_s):
 
 
 # ---- synthetic data ------------------------------------------------------------------------------------------------
-def gen_text_device(torch, nbytes, seed, device, piece=32 << 20):
+def gen_text_device(torch, nbytes, seed, device, piece=32 << 20, noise=0.0):
     """`nbytes` of synthetic text, generated in pieces of at most 32 MiB (bounded temporaries), each piece its own seed."""
     parts = []
     done = 0
     while done < nbytes:
         m = min(piece, nbytes - done)
-        parts.append(gen_text_piece(torch, m, seed * 1000 + len(parts), device))
+        parts.append(gen_text_piece(torch, m, seed * 1000 + len(parts), device, noise))
         done += m
     return parts[0] if len(parts) == 1 else torch.cat(parts)
 
 
-def gen_text_piece(torch, nbytes, seed, device):
+def gen_text_piece(torch, nbytes, seed, device, noise=0.0):
     """Word-bigram Markov text over shakespeare.txt tokens (tests/datagen.py), generated on the GPU:
-    `chains` independent chains advance in lockstep; their words are laid out chain after chain."""
+    `chains` independent chains advance in lockstep; their words are laid out chain after chain.  `noise`: fraction of the tokens
+    whose letters are replaced by random [a-z0-9] (datagen.text's noise: the enwik8 calibration)."""
     import datagen
 
     t = datagen.bigram_tables()
@@ -182,6 +216,8 @@ def gen_text_piece(torch, nbytes, seed, device):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     chains = 1 << 16
+    while chains > 16 and nbytes < chains * 64:  # (tiny pieces: fewer chains, so that every chain still emits a few words)
+        chains >>= 1
     avg = float(t["lens"][t["succ"]].mean())  # frequency-weighted word length (+1 space)
     steps = int(nbytes / (avg * chains) * 1.15) + 16
     state = torch.randint(0, t["nvocab"], (chains,), generator=g, device=device)
@@ -200,8 +236,13 @@ def gen_text_piece(torch, nbytes, seed, device):
     assert total >= nbytes, "generator came up short"
     tok_of_byte = torch.repeat_interleave(torch.arange(keep, device=device), lens)
     within = torch.arange(total, device=device) - (ends - lens)[tok_of_byte]
-    out = dev["blob"][dev["off"][toks[tok_of_byte]] + within][:nbytes].contiguous()
-    return out
+    out = dev["blob"][dev["off"][toks[tok_of_byte]] + within]
+    if noise > 0:
+        noisy = torch.rand((keep,), generator=g, device=device) < noise
+        mask = noisy[tok_of_byte] & (within < lens[tok_of_byte] - 1)  # the token's letters, not its space
+        alphabet = torch.as_tensor(datagen.NOISE_ALPHABET.copy(), device=device)
+        out = torch.where(mask, alphabet[torch.randint(0, alphabet.numel(), (total,), generator=g, device=device)], out)
+    return out[:nbytes].contiguous()
 
 
 def seed_text_source(lib):
@@ -366,8 +407,114 @@ def reference_round_trip(sample_blocks, block_size, keep_encoded=False, lib_path
             "sample": "one 4 MiB text block through oracle/bz3_oracle.c (oracle/_ref absent)", "host_cpu": model, "host_cores": ncpu}, None
 
 
+# ---- the reference in a process of its own ------------------------------------------------------------------------------
+class SharedBlocks:
+    """Blocks in anonymous shared memory (memfd: no /dev/shm size limit, no file), filled here, mapped read-only by the worker."""
+
+    def __init__(self, name, sizes):
+        import mmap
+
+        self.sizes = list(sizes)
+        self.offsets, off = [], 0
+        for n in self.sizes:
+            self.offsets.append(off)
+            off += (n + 4095) & ~4095
+        self.total = max(off, 4096)
+        self.fd = os.memfd_create(name)
+        os.ftruncate(self.fd, self.total)
+        self.mm = mmap.mmap(self.fd, self.total)
+
+    def put_tensor(self, torch, k, t):  # device -> shared memory, no intermediate host copy
+        torch.frombuffer(self.mm, dtype=torch.uint8, count=self.sizes[k], offset=self.offsets[k]).copy_(t[: self.sizes[k]])
+
+    def meta(self, sel=None, sizes=None):
+        sel = range(len(self.sizes)) if sel is None else sel
+        return {"fd": self.fd, "total": self.total, "blocks": [[self.offsets[k], (sizes[j] if sizes else self.sizes[k])] for j, k in enumerate(sel)]}
+
+    def close(self):
+        try:
+            self.mm.close()
+        except BufferError:
+            pass
+        os.close(self.fd)
+
+
+def worker_cpus():
+    """Cores for the reference process: all but the first ones this process may run on (the thread that drives the GPU stays there)."""
+    try:
+        mine = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return []
+    keep = 16 if len(mine) >= 96 else (2 if len(mine) >= 8 else 0)
+    return mine[keep:]
+
+
+class RefWorker:
+    """`python bench.py --cpu-worker <json>`: the reference's batch API on blocks in shared memory, in a process without torch or HIP."""
+
+    def __init__(self, plain, block_size, coded=None, ref_path=None, ref_label=None, probe=False):
+        import tempfile
+
+        fds = [plain["fd"]] + ([coded["fd"]] if coded else [])
+        job = {"plain": plain, "coded": coded, "block_size": block_size, "cpus": worker_cpus(), "ref_path": ref_path, "ref_label": ref_label, "probe": probe}
+        f = tempfile.NamedTemporaryFile("w", suffix=".json", prefix="bz3_ref_job_", delete=False)
+        json.dump(job, f)
+        f.close()
+        self.job_file = f.name
+        self.t0 = time.perf_counter()
+        self.proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", f.name], pass_fds=fds, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+    def result(self):
+        out, err = self.proc.communicate()
+        try:
+            os.unlink(self.job_file)
+        except OSError:
+            pass
+        if self.proc.returncode != 0:
+            return {"err": f"reference process failed ({self.proc.returncode}): {err.strip()[-300:]}"}
+        rec = json.loads(out.strip().splitlines()[-1])
+        rec["process_wall_s"] = round(time.perf_counter() - self.t0, 1)
+        return rec
+
+
+def cpu_worker(job_file):
+    """The cpu_baseline process.  Nothing of the product is loaded here."""
+    import mmap
+
+    import numpy as np
+
+    with open(job_file) as fh:
+        job = json.load(fh)
+    if job.get("cpus"):
+        try:
+            os.sched_setaffinity(0, set(job["cpus"]))
+        except OSError:
+            pass
+
+    def views(m):
+        mm = mmap.mmap(m["fd"], m["total"], prot=mmap.PROT_READ)
+        return [np.frombuffer(mm, dtype=np.uint8, count=n, offset=off) for off, n in m["blocks"]]
+
+    plain = views(job["plain"])
+    coded = views(job["coded"]) if job.get("coded") else None
+    label, path, probe = job.get("ref_label"), job.get("ref_path"), {}
+    if job.get("probe") or not path:
+        label, path, probe = fastest_reference(plain[0][: 8 << 20].tobytes())
+        label = label or "gcc -O2"
+    rec, enc = reference_round_trip(plain, max(job["block_size"], 65 * 1024), keep_encoded=coded is not None, lib_path=path, label=label)
+    out = {"rec": rec, "ref_label": label, "ref_path": path, "probe": probe, "pinned_to_cpus": len(job.get("cpus") or [])}
+    if enc is not None and coded is not None:
+        same = sum(1 for x, y in zip(enc, coded) if len(x) == len(y) and x == y.tobytes())
+        out["parity_same"], out["parity_of"] = same, len(enc)
+    sys.stdout.write(json.dumps(out) + "\n")
+
+
 def main():
     a = parse()
+    if a.cpu_worker:
+        return cpu_worker(a.cpu_worker)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
     start_watchdog(a.deadline_s)
     import torch  # first: the HIP runtime of the process must be torch's (see bzip3_amd._share_hip_runtime_with_torch)
     import torch.distributed as dist
@@ -376,46 +523,94 @@ def main():
 
     world, rank = WORLD, RANK
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}, or without it (bench.py starts the ranks itself)"
+    cuda = not a.emu
+    if cuda:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if cuda:
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="gloo")
 
-    lib = bzip3_amd.load()
-    if a.lib:
-        lib = bzip3_amd.load(a.lib)
+    def dev_sync():
+        if cuda:
+            torch.cuda.synchronize()
+
+    if a.emu:  # tests only: the kernels compiled for the CPU emulator; every rank "owns" emulated device 0
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        from build_emu import build as build_emu
+
+        lib = bzip3_amd.load(build_emu())
+        local_dev = 0
+    else:
+        lib = bzip3_amd.load()
+        if a.lib:
+            lib = bzip3_amd.load(a.lib)
+        local_dev = local_rank
     assert lib.bz3_hip_device_count() > 0, "no HIP device"
-    assert lib.bz3_hip_bind_device(local_rank) == 0
+    assert lib.bz3_hip_bind_device(local_dev) == 0
     assert lib.bz3_hip_set_cm_mode(CM_MODES[a.cm_mode]) == 0
     per_cu = {"rows": 2, "rows3": 3, "auto": 3, "full": 1}[a.cm_mode]  # blocks per CU the mode is made for
-    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    cus = torch.cuda.get_device_properties(device).multi_processor_count if cuda else 4
     nblk = a.blocks if a.blocks > 0 else cus * per_cu
+    block_size = int(a.block_mib * (1 << 20))
+    if a.leg == "cfg5":
+        block_size = 511 << 20
+        if a.blocks <= 0:
+            nblk = cus  # 256 x 511 MiB + workspace is what fits beside the swap-buffer pool
     lean = a.lean == 1 or (a.lean < 0 and nblk > cus)
     assert lib.bz3_hip_set_lean_states(1 if lean else 0) == 0
-
-    block_size = int(a.block_mib * (1 << 20))
     cap = lib.bz3_bound(block_size) + 4096
-    if a.kind == "text":
+    noise = a.noise
+    if a.kind == "text" or a.leg:
         seed_text_source(lib)
+        import datagen
+
+        if noise < 0:
+            noise = datagen.ENWIK_NOISE
+
+    def markov16(n, seed):
+        """cfg5's source: a skewed order-1 Markov chain over 16 symbols, repeat units < 40 B (LZP / RLE decline)."""
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        chains = 1 << 16
+        steps5 = (n + chains - 1) // chains
+        probs = 1.0 / torch.arange(1, 17, device=device, dtype=torch.float64) ** 1.6
+        rows = torch.stack([probs[torch.randperm(16, generator=g, device=device)] for _ in range(16)])
+        cdf = torch.cumsum(rows / rows.sum(1, keepdim=True), 1).to(torch.float32)
+        st5 = torch.randint(0, 16, (chains,), generator=g, device=device)
+        out5 = torch.empty((steps5, chains), dtype=torch.uint8, device=device)
+        for t_ in range(steps5):
+            r = torch.rand((chains,), generator=g, device=device)
+            st5 = (cdf[st5] < r[:, None]).sum(1).clamp_(max=15)
+            out5[t_] = (st5 + 97).to(torch.uint8)
+        return out5.t().reshape(-1)[:n].contiguous()
 
     # ---- synthetic input, resident in HBM ----------------------------------------------------------------
     t_gen = time.perf_counter()
-    if a.kind == "text":
-        base = gen_text_device(torch, block_size, seed=1 + rank, device=device)
+    nbase = max(1, min(a.text_bases, nblk))
+    if a.leg == "cfg5":
+        bases = [markov16(block_size, 50 + rank)]
+    elif a.kind == "text":
+        bases = [gen_text_device(torch, block_size, seed=1 + rank + 100 * j, device=device, noise=noise) for j in range(nbase)]
     else:
         g = torch.Generator(device=device)
         g.manual_seed(2 + rank)
-        base = torch.randint(0, 256, (block_size,), dtype=torch.uint8, generator=g, device=device)
+        bases = [torch.randint(0, 256, (block_size,), dtype=torch.uint8, generator=g, device=device)]
     bufs, prints = [], []
     chunk = 1 << 16
     nchunks = block_size // chunk
     for k in range(nblk):
         buf = torch.empty(cap, dtype=torch.uint8, device=device)
-        if k == 0 or nchunks < 2:
+        base = bases[k % len(bases)]
+        if k < len(bases) or nchunks < 2:
             buf[:block_size] = base
-        else:  # every further block: the same text with its 64 KiB pieces in a block-specific order
+        else:  # every further block: one of the texts with its 64 KiB pieces in a block-specific order
             g = torch.Generator(device=device)
             g.manual_seed(1000 * (rank + 1) + k)
             perm = torch.randperm(nchunks, generator=g, device=device)
@@ -426,9 +621,10 @@ def main():
     # full copies of a few blocks, kept out of the codec's reach, for a byte-for-byte comparison after the round trip
     n_keep = min(4, nblk) if not lean else min(2, nblk)
     kept = [bufs[k][:block_size].clone() for k in range(n_keep)]
-    del base
-    torch.cuda.synchronize()
-    torch.cuda.empty_cache()  # hand the generator's temporaries back: the codec workspace is hipMalloc'ed outside torch
+    del bases, base
+    dev_sync()
+    if cuda:
+        torch.cuda.empty_cache()  # hand the generator's temporaries back: the codec workspace is hipMalloc'ed outside torch
     t_gen = time.perf_counter() - t_gen
     progress(f"{nblk} x {block_size} B input blocks resident in HBM ({t_gen:.1f}s)")
 
@@ -440,10 +636,10 @@ def main():
     orig = (C.c_int32 * nblk)(*[block_size] * nblk)
 
     def barrier():
-        torch.cuda.synchronize()
+        dev_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
 
     def agree(x):
         """Rank 0's value of a number, on every rank (all ranks must take the same budget decisions)."""
@@ -463,11 +659,11 @@ def main():
     comp_sizes = [0] * nblk
     stage = {}
     # CPU parity / baseline sample: coded bytes of the first blocks, copied aside (device to device) before the in-place decode
-    want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline
+    want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline and not a.emu and not a.leg
     cpu_block = int((a.cpu_block_mib or a.block_mib) * (1 << 20))
     cpu_n = 0
     if want_cpu:
-        per_thread = 6.5 * cpu_block + (64 << 20)  # reference state (~5.1 x block) + buffer + our copies
+        per_thread = 7.5 * cpu_block + (64 << 20)  # reference state (~5.1 x block) + buffer + the shared copies
         cpu_n = int(max(1, min(os.cpu_count() or 1, a.cpu_threads, nblk, host_mem_available() * 0.8 // per_thread)))
     coded_kept = []
 
@@ -505,9 +701,10 @@ def main():
             stage["t_enc_s"] = round(t1 - t0, 3)
             stage["t_dec_s"] = round(t3 - t2, 3)
 
-    # ---- steps under the wall budget ---------------------------------------------------------------------------------
-    extras_wanted = rank == 0 and world == 1 and not a.no_extras
-    reserve = (40.0 if want_cpu else 0.0) + (420.0 if extras_wanted else 0.0) + 30.0  # host copies, extra legs, verification
+    # ---- steps under the wall budget: nothing else runs on the host or the GPU meanwhile ---------------------------------
+    extras_wanted = rank == 0 and world == 1 and not a.no_extras and not a.emu and not a.leg
+    cpu_need = 2.6 * cpu_block / (4.5 * (1 << 20)) if want_cpu else 0.0  # ~4.5 MiB/s per thread and direction at 256 MiB blocks (BASELINE.md), with margin
+    reserve = (cpu_need + 40.0 if want_cpu else 0.0) + (330.0 if extras_wanted else 0.0) + 30.0  # reference process, legs that follow it, verification
     step_s = []
     barrier()
     t0 = time.perf_counter()
@@ -523,42 +720,8 @@ def main():
             assert torch.equal(bufs[k][:block_size], kept[k]), f"block {k}: round trip changed the data"
 
     verify_round_trip()
-    # host copies for the reference legs: plaintext of blocks 0..cpu_n-1 (verified above) and the GPU's coded bytes of the same blocks
-    host_plain, host_coded = [], []
-    if want_cpu:
-        host_plain = [bufs[i][: min(cpu_block, block_size)].cpu().numpy() for i in range(cpu_n)] if cpu_block == block_size else \
-                     [bufs[0][:cpu_block].cpu().numpy()] * cpu_n
-        host_coded = [c.cpu().numpy().tobytes() for c in coded_kept]
-        coded_kept.clear()
-        progress(f"host copies of {cpu_n} blocks for the reference legs")
-    ref_choice = {"label": "gcc -O2", "path": None, "probe": {}}
-    cpu_result = {}
-    cpu_need = 2.6 * cpu_block / (4.5 * (1 << 20)) if want_cpu else 0.0  # ~4.5 MiB/s per thread and direction at 256 MiB blocks (BASELINE.md), with margin
-
-    def cpu_baseline_leg():
-        """The reference on the host's cores -- runs in a thread of its own while the GPU does its second timed step."""
-        try:
-            label, path, probe = fastest_reference(host_plain[0][: 8 << 20].tobytes())
-            if label is not None:
-                ref_choice.update(label=label, path=path, probe=probe)
-            progress(f"cpu_baseline: {cpu_n} threads x {cpu_block >> 20} MiB blocks, {ref_choice['label']} (one-thread probe, MiB/s: {probe}; estimated {cpu_need:.0f}s)")
-            rec, enc = reference_round_trip(host_plain, max(cpu_block, 65 * 1024), keep_encoded=bool(host_coded), lib_path=ref_choice["path"], label=ref_choice["label"])
-            rec["build_probe_1_thread_8MiB_MiBps"] = probe
-            rec["threads_note"] = "64 threads: the reference's CLI caps -j at 64 (src/main.c:213); one thread per block as in bz3_encode_blocks (src/libbz3.c:845-856)"
-            if enc is not None and host_coded:
-                same = sum(1 for x, y in zip(enc, host_coded) if x == y)
-                rec["parity"] = f"{same} of {len(enc)} blocks of {cpu_block >> 20} MiB: the GPU's coded bytes are identical to the reference's"
-                cpu_result["parity_ok"] = same == len(enc)
-            cpu_result["rec"] = rec
-        except Exception as e:  # the baseline is reported, never required
-            cpu_result["err"] = str(e)
-
     left = agree(a.budget_s - elapsed()) - reserve
     second = (a.steps >= 2 or a.warmup > 0) and left > step_s[0] * 1.03
-    cpu_thread = None
-    if want_cpu and a.deadline_s - 20.0 - elapsed() > cpu_need:
-        cpu_thread = threading.Thread(target=cpu_baseline_leg)
-        cpu_thread.start()
     if second:
         barrier()
         t0 = time.perf_counter()
@@ -580,10 +743,10 @@ def main():
         # side and its coded bytes on the other (CM 1R + cW / cR + 1W); launch time from HIP events on the
         # launching stream (api.hip run_cm_jobs).
         dec_dominant = cm_dec_ms >= cm_enc_ms
-        dom_ms = cm_dec_ms if dec_dominant else cm_enc_ms
+        dom_ms = max(cm_dec_ms if dec_dominant else cm_enc_ms, 1e-6)
         enc_names = {0: "k_cm_encode", 1: "k_cm_encode_rows", 2: "k_cm_encode_rows3"}
         dec_names = {0: "k_cm_decode_sync", 1: "k_cm_decode_sync2", 2: "k_cm_decode_sync3"}
-        kern = (dec_names if dec_dominant else enc_names)[lib.bz3_hip_cm_variant_for(local_rank, nblk, 0 if dec_dominant else 1)]
+        kern = (dec_names if dec_dominant else enc_names).get(lib.bz3_hip_cm_variant_for(local_dev, nblk, 0 if dec_dominant else 1), "k_cm_decode_sync")
         cm_bytes = n_dec * nblk + comp_total
         # HBM traffic of the dominant kernel from the PMC pass (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs,
         # corrected as MI355X_MICROARCH.md prescribes), recorded per byte and scaled to this launch.
@@ -610,8 +773,9 @@ def main():
             repeat_rate = round(float((u_[1:] == u_[:-1]).mean()), 4)
         except Exception as e:
             progress(f"repeat-rate sample failed: {e}")
+        what = {"": f"synthetic enwik-style {a.kind}", "cfg5": "16-symbol order-1 Markov (BASELINE.json configs[4] stand-in)"}[a.leg]
         out = {
-            "metric": "MiB/s encode+decode round-trip, 256 MiB blocks",
+            "metric": "MiB/s encode+decode round-trip, 256 MiB blocks" if not a.leg else f"MiB/s encode+decode round-trip, {block_size >> 20} MiB blocks (leg {a.leg})",
             "value": round(value, 3),
             "unit": "MiB/s",
             "n_gpus": world,
@@ -627,11 +791,12 @@ def main():
             "data": "synthetic",
             "requested": {"steps": a.steps, "warmup": a.warmup, "budget_s": a.budget_s,
                           "note": "steps/warmup clamped to the wall budget: one step codes and decodes a GPU-filling batch of 256 MiB blocks; both steps are timed, "
-                                  "the first one includes the first-call effects (workspace allocation)"},
+                                  "the first one includes the first-call effects (workspace allocation); nothing else runs on the host or the GPU during the timed steps"},
             "config": {
-                "workload": f"{nblk} x {a.block_mib:g} MiB synthetic enwik-style {a.kind} blocks per GPU (word-bigram Markov over shakespeare.txt tokens; "
-                            f"blocks 2.. are 64 KiB-piece permutations of block 1), resident in HBM, "
-                            f"bz3_hip_encode_blocks_device + bz3_hip_decode_blocks_device",
+                "workload": f"{nblk} x {block_size / 2 ** 20:g} MiB {what} blocks per GPU"
+                            + (f" (word-bigram Markov over shakespeare.txt tokens, {noise * 100:g} % noise tokens = enwik8's 4.41 : 1 at -b 16; {nbase} independent texts, "
+                               f"block k = text k mod {nbase} with its 64 KiB pieces in a block-specific order)" if a.kind == "text" and not a.leg else "")
+                            + ", resident in HBM, bz3_hip_encode_blocks_device + bz3_hip_decode_blocks_device",
                 "block_bytes": block_size,
                 "blocks_per_gpu": nblk,
                 "parallelism": f"blocks sharded over {world} GPU(s), no collective",
@@ -661,15 +826,15 @@ def main():
             },
             "bwt_roofline": {
                 "stage": "bwt_forward (one 56-bit code-window radix sort + in-LDS group resolution), one block",
-                "achieved": round(ALG_BYTES_BWT * block_size / (bwt_ms * 1e-3) / 1e9, 3),
+                "achieved": round(ALG_BYTES_BWT * block_size / (max(bwt_ms, 1e-6) * 1e-3) / 1e9, 3),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ALG_BYTES_BWT * block_size / (bwt_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
+                "frac": round(ALG_BYTES_BWT * block_size / (max(bwt_ms, 1e-6) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
                 "ms": bwt_ms, **stage.get("bwt", {}),
             },
             "stages": stage,
             "gen_s": round(t_gen, 1),
             "configs": {},
-            "cpu_baseline": {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": "not run (budget or --no-cpu-baseline)"},
+            "cpu_baseline": {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": "not run (budget, --no-cpu-baseline, --leg or N > 1)"},
         }
         RESULT["line"] = out
 
@@ -677,53 +842,175 @@ def main():
     def left_s():
         return a.budget_s - elapsed()
 
-    def round_trip(sel, sizes_in):
-        """encode + decode of blocks `sel` of the batch (device pointers); returns (t_enc, t_dec, coded sizes)."""
+    def round_trip(sel, sizes_in, host=None):
+        """encode + decode of blocks `sel` of the batch (device pointers; host: a list of host buffers instead, through
+        bz3_encode_blocks / bz3_decode_blocks); returns (t_enc, t_dec, coded sizes)."""
         n = len(sel)
         S = (C.c_void_p * n)(*[states[k] for k in sel])
-        P = (C.c_void_p * n)(*[bufs[k].data_ptr() for k in sel])
+        P = (C.c_void_p * n)(*([C.addressof(h) for h in host] if host else [bufs[k].data_ptr() for k in sel]))
         sz = (C.c_int32 * n)(*sizes_in)
-        torch.cuda.synchronize()
+        enc_fn, dec_fn = (lib.bz3_encode_blocks, lib.bz3_decode_blocks) if host else (lib.bz3_hip_encode_blocks_device, lib.bz3_hip_decode_blocks_device)
+        dev_sync()
         t0 = time.perf_counter()
-        lib.bz3_hip_encode_blocks_device(S, P, sz, n)
+        enc_fn(S, P, sz, n)
         t1 = time.perf_counter()
         assert all(sz[i] > 0 and lib.bz3_last_error(S[i]) == 0 for i in range(n)), "encode failed"
         coded = list(sz)
         B = (C.c_size_t * n)(*[cap] * n)
         O = (C.c_int32 * n)(*sizes_in)
-        lib.bz3_hip_decode_blocks_device(S, P, B, sz, O, n)
+        dec_fn(S, P, B, sz, O, n)
         t2 = time.perf_counter()
         assert all(lib.bz3_last_error(S[i]) == 0 for i in range(n)), "decode failed"
         return t1 - t0, t2 - t1, coded
 
-    # ---- cpu_baseline: started before the second step, collected here
-    if want_cpu:
-        if cpu_thread is not None:
-            cpu_thread.join()
-        if "rec" in cpu_result:
-            rec = cpu_result["rec"]
+    ref_choice = {"label": "gcc -O2", "path": None}
+    shared_plain = None
+    cpu_worker_proc = None
+    if want_cpu and a.deadline_s - 30.0 - elapsed() > cpu_need:
+        # plaintext of blocks 0..cpu_n-1 (verified above) and the GPU's coded bytes of the same blocks, in shared memory for the reference process
+        bs_cpu = min(cpu_block, block_size)
+        shared_plain = SharedBlocks("bz3_bench_plain", [bs_cpu] * cpu_n)
+        for i in range(cpu_n):
+            shared_plain.put_tensor(torch, i, bufs[i if cpu_block == block_size else 0])
+        shared_coded = None
+        if coded_kept:
+            shared_coded = SharedBlocks("bz3_bench_coded", [int(c.numel()) for c in coded_kept])
+            for i, c in enumerate(coded_kept):
+                shared_coded.put_tensor(torch, i, c)
+            coded_kept.clear()
+        progress(f"cpu_baseline: {cpu_n} threads x {bs_cpu >> 20} MiB blocks in a process of its own (estimated {cpu_need:.0f}s); GPU-only legs meanwhile")
+        cpu_worker_proc = RefWorker(shared_plain.meta(), max(bs_cpu, 65 * 1024), coded=shared_coded.meta() if shared_coded else None, probe=True)
+    elif want_cpu:
+        RESULT["line"]["cpu_baseline"]["sample"] = f"not run: needs ~{cpu_need:.0f}s, {a.deadline_s - elapsed():.0f}s to the deadline"
+
+    def free_most_of_the_batch():
+        """room for the legs below: most of the batch's buffers and the big workspace are not needed any more"""
+        keep_n = min(nblk, 160)
+        for s_ in states[keep_n:]:
+            lib.bz3_free(s_)
+        del bufs[keep_n:]
+        lib.bz3_hip_release_cached_memory()
+        if cuda:
+            torch.cuda.empty_cache()
+        return keep_n
+
+    live_states = nblk
+    random_host = None
+    if extras_wanted and a.kind == "text" and left_s() > 200.0:
+        # ---- random: incompressible blocks, as many as the timed batch had (LZP and RLE decline, model 0, ~1.004 bytes per byte) ----
+        rb = int(a.random_block_mib * (1 << 20))
+        nr = a.random_blocks if a.random_blocks > 0 else nblk
+        nr = max(1, min(nr, nblk))
+        if rb <= block_size:
+            progress(f"random: {nr} x {a.random_block_mib:g} MiB")
+            g = torch.Generator(device=device)
+            g.manual_seed(2)
+            fpr = []
+            rsel = list(range(nblk - nr, nblk))  # (their text is not needed any more, except blocks 0..cpu_n-1's: those are in shared memory already)
+            for k in rsel:
+                bufs[k][:rb] = torch.randint(0, 256, (rb,), dtype=torch.uint8, generator=g, device=device)
+                fpr.append(fingerprint(torch, bufs[k][:rb]))
+            n_ref = min(nr, a.cpu_threads, os.cpu_count() or 1)
+            if want_cpu:
+                random_host = SharedBlocks("bz3_bench_random", [rb] * n_ref)
+                for j in range(n_ref):
+                    random_host.put_tensor(torch, j, bufs[rsel[j]])
+            te, td, coded = round_trip(rsel, [rb] * nr)
+            assert all(fingerprint(torch, bufs[k][:rb]) == f for k, f in zip(rsel, fpr)), "random: round trip changed the data"
+            RESULT["line"]["configs"]["random"] = {
+                "workload": f"{nr} x {a.random_block_mib:g} MiB uniformly random blocks on one GPU (states of {a.block_mib:g} MiB)",
+                "value": round(nr * rb / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
+                "compressed_ratio": round(nr * rb / sum(coded), 4),
+                "cm_blocks_given_up": "all (256 live order-1 rows: the row-cache kernels hand every block to the whole-model kernels, up to one per CU at a time)"}
+            progress(f"random: {RESULT['line']['configs']['random']['value']} MiB/s")
+
+    if extras_wanted and a.kind == "text" and nblk > 160 and left_s() > 60.0:
+        live_states = free_most_of_the_batch()
+
+    if extras_wanted and a.kind == "text" and live_states >= 96 and block_size >= (32 << 20) and left_s() > 200.0:
+        # mixed batch: text, binary and incompressible blocks through ONE pair of batch calls
+        mb = 32 << 20
+        per = 32
+        g = torch.Generator(device=device)
+        g.manual_seed(7)
+        sel = list(range(64, 64 + 3 * per))  # (blocks 0..63 keep their text for the legs below)
+        for j in range(per):  # the first 32 keep their text; then binary (little-endian words of a random walk); then random
+            k = sel[per + j]
+            walk = torch.cumsum(torch.randint(-3, 4, (mb // 4,), generator=g, device=device, dtype=torch.int32), 0).to(torch.int32)
+            bufs[k][:mb] = walk.view(torch.uint8)
+            bufs[sel[2 * per + j]][:mb] = torch.randint(0, 256, (mb,), dtype=torch.uint8, generator=g, device=device)
+        fpm = [fingerprint(torch, bufs[k][:mb]) for k in sel]
+        before = int(lib.bz3_hip_cm_blocks_given_up())
+        te, td, coded = round_trip(sel, [mb] * len(sel))
+        assert all(fingerprint(torch, bufs[k][:mb]) == f for k, f in zip(sel, fpm)), "mixed: round trip changed the data"
+        RESULT["line"]["configs"]["mixed"] = {
+            "workload": f"{3 * per} x 32 MiB blocks in one batch on one GPU: {per} text, {per} binary (32-bit words of a random walk), {per} uniformly random",
+            "value": round(len(sel) * mb / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
+            "compressed_ratio": {"text": round(per * mb / sum(coded[:per]), 3), "binary": round(per * mb / sum(coded[per : 2 * per]), 3),
+                                 "random": round(per * mb / sum(coded[2 * per :]), 4)},
+            "cm_blocks_given_up": int(lib.bz3_hip_cm_blocks_given_up()) - before}
+        progress(f"mixed: {RESULT['line']['configs']['mixed']['value']} MiB/s, {RESULT['line']['configs']['mixed']['cm_blocks_given_up']} blocks given up by the row-cache kernels")
+
+    if extras_wanted and a.kind == "text" and left_s() > 200.0:
+        # cfg5's stage (BASELINE.json configs[4]: "-b 511 max block ... decode-path unBWT throughput"): the inverse BWT of one block of the
+        # maximum size.  Verbatim long repeats would be collapsed by LZP (SURVEY.md 8d), so the source is a skewed order-1 Markov chain
+        # over 16 symbols (repeat units < 40 B: LZP / RLE decline, the BWT stage sees all n bytes).
+        try:
+            n5 = 511 << 20
+            src5 = markov16(n5, 5).cpu().numpy().tobytes()
+            if cuda:
+                torch.cuda.empty_cache()
+            gs = bzip3_amd.StageApi(lib)
+            idx5, u5 = gs.bwt(src5)
+            ms_fwd = float(lib.bz3_hip_stage_last_ms())
+            rc5, back5 = gs.unbwt(u5, idx5)
+            ms_inv = float(lib.bz3_hip_stage_last_ms())
+            assert rc5 == 0 and back5 == src5, "cfg5_unbwt: the inverse BWT did not return the block"
+            RESULT["line"]["configs"]["cfg5_unbwt"] = {
+                "workload": "BASELINE.json configs[4]'s stage on one GPU: inverse BWT of ONE 511 MiB block (535,822,336 B, the maximum block size) of a skewed "
+                            "order-1 Markov source over 16 symbols (bz3_hip_stage_unbwt; transform alone, PCIe copies of the hook excluded); "
+                            "the whole-pipeline round trip of a batch of such blocks is `bench.py --leg cfg5` (profiles/)",
+                "value": round(ALG_BYTES_BWT * n5 / (ms_inv * 1e-3) / 1e9, 3), "unit": "GB/s (11 algorithmic bytes per byte, SURVEY.md 8d)",
+                "ms": round(ms_inv, 2), "MiBps": round(511.0 / (ms_inv * 1e-3), 1), "frac_of_hbm_peak": round(ALG_BYTES_BWT * n5 / (ms_inv * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                "forward_bwt_ms": round(ms_fwd, 2), "forward_bwt_GBps": round(ALG_BYTES_BWT * n5 / (ms_fwd * 1e-3) / 1e9, 3)}
+            progress(f"cfg5_unbwt: inverse BWT of a 511 MiB block in {ms_inv:.1f} ms (forward {ms_fwd:.1f} ms)")
+            del src5, u5, back5
+            lib.bz3_hip_release_cached_memory()
+        except Exception as e:
+            RESULT["line"]["configs"]["cfg5_unbwt"] = {"skipped": f"failed: {e}"}
+
+    # ---- cpu_baseline: started after the timed steps, collected here (the legs above used the GPU only) ----------------
+    if cpu_worker_proc is not None:
+        res = cpu_worker_proc.result()
+        if "rec" in res:
+            rec = res["rec"]
+            ref_choice.update(label=res.get("ref_label") or "gcc -O2", path=res.get("ref_path"))
+            rec["build_probe_1_thread_8MiB_MiBps"] = res.get("probe", {})
+            rec["threads_note"] = "64 threads: the reference's CLI caps -j at 64 (src/main.c:213); one thread per block as in bz3_encode_blocks (src/libbz3.c:845-856)"
+            rec["process"] = f"a process of its own (no torch, no HIP runtime), pinned to {res.get('pinned_to_cpus', 0)} cores; started after the timed steps, while the GPU ran legs that use no host cores"
             rec["gpu_over_cpu"] = round(RESULT["line"]["value"] / rec["value"], 3) if rec.get("value") else None
-            rec["timed_while"] = "the GPU ran its second timed step" if second else "the GPU was idle"
+            if "parity_same" in res:
+                rec["parity"] = f"{res['parity_same']} of {res['parity_of']} blocks of {cpu_block >> 20} MiB: the GPU's coded bytes are identical to the reference's"
             RESULT["line"]["cpu_baseline"] = rec
             progress(f"cpu_baseline: {rec['value']} MiB/s on {rec['cores']} threads ({ref_choice['label']}); {rec.get('parity', '')}")
-            assert cpu_result.get("parity_ok", True), "GPU output differs from the reference: " + rec.get("parity", "")
+            assert res.get("parity_same") == res.get("parity_of"), "GPU output differs from the reference: " + rec.get("parity", "")
         else:
-            why = cpu_result.get("err", f"needs ~{cpu_need:.0f}s, {a.deadline_s - elapsed():.0f}s to the deadline")
-            RESULT["line"]["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": f"not run: {why}"}
+            RESULT["line"]["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": "not run: " + res.get("err", "?")}
 
-    def ref_beside(blocks, bs, tag):
-        """the reference's -j N on the same blocks, on the host, in a thread of its own while the GPU codes them"""
-        box = {}
+    def ref_beside(meta, bs):
+        """the reference's -j N on the same blocks, in a process of its own while the GPU codes them"""
+        return RefWorker(meta, max(bs, 65 * 1024), ref_path=ref_choice["path"], ref_label=ref_choice["label"])
 
-        def run():
-            try:
-                box["rec"], _ = reference_round_trip(blocks, bs, lib_path=ref_choice["path"], label=ref_choice["label"])
-            except Exception as e:
-                box["err"] = str(e)
-
-        th = threading.Thread(target=run)
-        th.start()
-        return th, box
+    if random_host is not None and "random" in RESULT["line"]["configs"] and left_s() > 60.0:
+        res = ref_beside(random_host.meta(), int(a.random_block_mib * (1 << 20))).result()
+        rec = RESULT["line"]["configs"]["random"]
+        if "rec" in res:
+            rec["cpu"] = res["rec"]
+            rec["vs_cpu"] = round(rec["value"] / res["rec"]["value"], 3)
+            progress(f"random: reference on {res['rec']['cores']} threads: {res['rec']['value']} MiB/s")
+        else:
+            rec["cpu"] = {"value": None, "sample": "failed: " + res.get("err", "?")}
+        random_host.close()
 
     def small_config(name, total_bytes_, bs, what):
         """BASELINE configs of a few blocks: `total_bytes_` of the batch's text at block size bs on one GPU, the reference's -j N beside it."""
@@ -731,9 +1018,9 @@ def main():
         sizes_ = [bs] * (nb - 1) + [total_bytes_ - (nb - 1) * bs]
         sel = list(range(nb))
         fp = [fingerprint(torch, bufs[k][: sizes_[k]]) for k in sel]
-        th, box = (None, {})
-        if want_cpu and cpu_n >= nb and cpu_block == block_size:
-            th, box = ref_beside([host_plain[k][: sizes_[k]] for k in sel], max(bs, 65 * 1024), name)
+        w = None
+        if shared_plain is not None and cpu_n >= nb and cpu_block == block_size:
+            w = ref_beside(shared_plain.meta(sel, sizes_), bs)
         te, td, coded = round_trip(sel, sizes_)
         assert all(fingerprint(torch, bufs[k][: sizes_[k]]) == fp[k] for k in sel), f"{name}: round trip changed the data"
         rec = {"workload": f"{what}: {total_bytes_} B of synthetic text, -b {bs / 2 ** 20:g} -> {nb} blocks ({nb - 1} x {bs} + {sizes_[-1]}) on one GPU",
@@ -741,16 +1028,16 @@ def main():
                "compressed_ratio": round(total_bytes_ / sum(coded), 3)}
         RESULT["line"]["configs"][name] = rec
         progress(f"{name}: {rec['value']} MiB/s (enc {te:.1f}s dec {td:.1f}s)")
-        if th is not None:
-            th.join()
-            if "rec" in box:
-                r = box["rec"]
-                r["sample"] = f"reference -j {nb} ({ref_choice['label']}): bz3_encode_blocks + bz3_decode_blocks on the same {nb} blocks, {nb} host threads, timed while the GPU coded them"
+        if w is not None:
+            res = w.result()
+            if "rec" in res:
+                r = res["rec"]
+                r["sample"] = f"reference -j {nb} ({ref_choice['label']}): bz3_encode_blocks + bz3_decode_blocks on the same {nb} blocks, {nb} threads of a process of its own, timed while the GPU coded them"
                 rec[f"cpu_j{nb}"] = r
                 rec[f"vs_cpu_j{nb}"] = round(rec["value"] / r["value"], 3)
                 progress(f"{name}: reference -j {nb} on the host: {r['value']} MiB/s")
             else:
-                rec[f"cpu_j{nb}"] = {"value": None, "sample": "failed: " + box.get("err", "?")}
+                rec[f"cpu_j{nb}"] = {"value": None, "sample": "failed: " + res.get("err", "?")}
 
     n3 = (a.cfg3_bytes + block_size - 1) // block_size  # blocks of the cfg3 leg: full blocks + one partial
     if extras_wanted and a.kind == "text" and nblk >= n3:
@@ -769,110 +1056,42 @@ def main():
             small_config("cfg2", 100_000_000, 32 << 20, "BASELINE.json configs[1] stand-in")
         else:
             RESULT["line"]["configs"]["cfg2"] = {"skipped": f"{left_s():.0f}s of the budget left"}
-    host_plain, host_coded = [], []
 
-    if extras_wanted and a.kind == "text" and nblk > 160 and left_s() > 60.0:
-        # ---- room for the legs below: most of the batch's buffers and the big workspace are not needed any more
-        keep_n = 160
-        for s_ in states[keep_n:]:
-            lib.bz3_free(s_)
-        live_states = keep_n
-        del bufs[keep_n:]
-        lib.bz3_hip_release_cached_memory()
-        torch.cuda.empty_cache()
-    else:
-        live_states = nblk
-
-    if extras_wanted and a.kind == "text" and left_s() > 60.0:
-        # cfg5's stage (BASELINE.json configs[4]: "-b 511 max block ... decode-path unBWT throughput"): the inverse BWT of one block of the
-        # maximum size.  Verbatim long repeats would be collapsed by LZP, so the source is a skewed order-1 Markov chain
-        # over 16 symbols (repeat units < 40 B: LZP / RLE decline, the BWT stage sees all n bytes).
-        try:
-            n5 = 511 << 20
-            g = torch.Generator(device=device)
-            g.manual_seed(5)
-            chains = 1 << 16
-            steps5 = (n5 + chains - 1) // chains
-            probs = 1.0 / torch.arange(1, 17, device=device, dtype=torch.float64) ** 1.6
-            rows = torch.stack([probs[torch.randperm(16, generator=g, device=device)] for _ in range(16)])
-            cdf = torch.cumsum(rows / rows.sum(1, keepdim=True), 1).to(torch.float32)
-            state5 = torch.randint(0, 16, (chains,), generator=g, device=device)
-            out5 = torch.empty((steps5, chains), dtype=torch.uint8, device=device)
-            for t_ in range(steps5):
-                r = torch.rand((chains,), generator=g, device=device)
-                state5 = (cdf[state5] < r[:, None]).sum(1).clamp_(max=15)
-                out5[t_] = (state5 + 97).to(torch.uint8)
-            src5 = out5.t().reshape(-1)[:n5].contiguous().cpu().numpy().tobytes()
-            del out5
-            torch.cuda.empty_cache()
-            gs = bzip3_amd.StageApi(lib)
-            idx5, u5 = gs.bwt(src5)
-            ms_fwd = float(lib.bz3_hip_stage_last_ms())
-            rc5, back5 = gs.unbwt(u5, idx5)
-            ms_inv = float(lib.bz3_hip_stage_last_ms())
-            assert rc5 == 0 and back5 == src5, "cfg5_unbwt: the inverse BWT did not return the block"
-            RESULT["line"]["configs"]["cfg5_unbwt"] = {
-                "workload": "BASELINE.json configs[4]'s stage on one GPU: inverse BWT of ONE 511 MiB block (535,822,336 B, the maximum block size) of a skewed "
-                            "order-1 Markov source over 16 symbols (bz3_hip_stage_unbwt; transform alone, PCIe copies of the hook excluded)",
-                "value": round(ALG_BYTES_BWT * n5 / (ms_inv * 1e-3) / 1e9, 3), "unit": "GB/s (11 algorithmic bytes per byte, SURVEY.md 8d)",
-                "ms": round(ms_inv, 2), "MiBps": round(511.0 / (ms_inv * 1e-3), 1), "frac_of_hbm_peak": round(ALG_BYTES_BWT * n5 / (ms_inv * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                "forward_bwt_ms": round(ms_fwd, 2), "forward_bwt_GBps": round(ALG_BYTES_BWT * n5 / (ms_fwd * 1e-3) / 1e9, 3)}
-            progress(f"cfg5_unbwt: inverse BWT of a 511 MiB block in {ms_inv:.1f} ms (forward {ms_fwd:.1f} ms)")
-            del src5, u5, back5
-            lib.bz3_hip_release_cached_memory()
-        except Exception as e:
-            RESULT["line"]["configs"]["cfg5_unbwt"] = {"skipped": f"failed: {e}"}
-
-    if extras_wanted and a.kind == "text" and live_states >= 96 and block_size >= (32 << 20) and left_s() > 100.0:
-        # mixed batch: text, binary and incompressible blocks through ONE pair of batch calls
-        mb = 32 << 20
-        per = 32
-        g = torch.Generator(device=device)
-        g.manual_seed(7)
-        sel = list(range(3 * per))
-        for j in range(per):  # blocks 0..31 keep their text; 32..63 binary (little-endian words of a random walk); 64..95 random
-            k = per + j
-            walk = torch.cumsum(torch.randint(-3, 4, (mb // 4,), generator=g, device=device, dtype=torch.int32), 0).to(torch.int32)
-            bufs[k][:mb] = walk.view(torch.uint8)
-            bufs[2 * per + j][:mb] = torch.randint(0, 256, (mb,), dtype=torch.uint8, generator=g, device=device)
-        fpm = [fingerprint(torch, bufs[k][:mb]) for k in sel]
-        before = int(lib.bz3_hip_cm_blocks_given_up())
-        te, td, coded = round_trip(sel, [mb] * len(sel))
-        assert all(fingerprint(torch, bufs[k][:mb]) == f for k, f in zip(sel, fpm)), "mixed: round trip changed the data"
-        RESULT["line"]["configs"]["mixed"] = {
-            "workload": f"{3 * per} x 32 MiB blocks in one batch on one GPU: {per} text, {per} binary (32-bit words of a random walk), {per} uniformly random",
-            "value": round(len(sel) * mb / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
-            "compressed_ratio": {"text": round(per * mb / sum(coded[:per]), 3), "binary": round(per * mb / sum(coded[per : 2 * per]), 3),
-                                 "random": round(per * mb / sum(coded[2 * per :]), 4)},
-            "cm_blocks_given_up": int(lib.bz3_hip_cm_blocks_given_up()) - before}
-        progress(f"mixed: {RESULT['line']['configs']['mixed']['value']} MiB/s, {RESULT['line']['configs']['mixed']['cm_blocks_given_up']} blocks given up by the row-cache kernels")
-
-    if extras_wanted and a.kind == "text":
-        # incompressible blocks: LZP and RLE decline (model 0), the coder emits ~1.004 bytes per byte
-        rb = int(a.random_block_mib * (1 << 20))
-        nr = max(1, min(a.random_blocks, live_states, cus))
-        if rb <= block_size and left_s() > 90.0:
-            progress(f"random: {nr} x {a.random_block_mib:g} MiB")
-            g = torch.Generator(device=device)
-            g.manual_seed(2)
-            fpr = []
-            rsel = list(range(live_states - nr, live_states))  # the last blocks still alive (their text is not needed any more)
-            for k in rsel:
-                bufs[k][:rb] = torch.randint(0, 256, (rb,), dtype=torch.uint8, generator=g, device=device)
-                fpr.append(fingerprint(torch, bufs[k][:rb]))
-            te, td, coded = round_trip(rsel, [rb] * nr)
-            assert all(fingerprint(torch, bufs[k][:rb]) == f for k, f in zip(rsel, fpr)), "random: round trip changed the data"
-            RESULT["line"]["configs"]["random"] = {
-                "workload": f"{nr} x {a.random_block_mib:g} MiB uniformly random blocks on one GPU (states of {a.block_mib:g} MiB)",
-                "value": round(nr * rb / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
-                "compressed_ratio": round(nr * rb / sum(coded), 4)}
-            progress(f"random: {RESULT['line']['configs']['random']['value']} MiB/s")
+    hb = int(a.host_api_block_mib * (1 << 20))
+    if extras_wanted and a.kind == "text" and hb > 0 and hb <= block_size and live_states >= 8:
+        # ---- host_api: SURVEY.md 8d's timing boundary -- bz3_encode_blocks / bz3_decode_blocks on malloc'ed HOST buffers (H2D / D2H inside the
+        # timed calls) against the same batch device-resident.  Blocks of hb bytes, one per state still alive.
+        nh = live_states
+        est = 2.2 * (stage["enc"]["cm"] + stage["dec"]["cm"]) * 1e-3 * hb / block_size * (1.0 if nh > 2 * cus else 0.8) + 30.0
+        if left_s() > est and host_mem_available() > nh * (hb + hb // 40 + 8192) * 1.3:
+            progress(f"host_api: {nh} x {a.host_api_block_mib:g} MiB through host buffers (estimated {est:.0f}s)")
+            sel = list(range(nh))
+            hcap = lib.bz3_bound(hb) + 64
+            fph = [fingerprint(torch, bufs[k][:hb]) for k in sel]
+            te_d, td_d, coded_d = round_trip(sel, [hb] * nh)
+            host = [(C.c_uint8 * hcap)() for _ in sel]
+            for k in sel:
+                torch.frombuffer(host[k], dtype=torch.uint8, count=hb).copy_(bufs[k][:hb])
+            cap_saved = cap
+            cap = hcap  # (round_trip passes `cap` as the buffer size of the decode call)
+            te_h, td_h, coded_h = round_trip(sel, [hb] * nh, host=host)
+            cap = cap_saved
+            ok = coded_h == coded_d and all(fingerprint(torch, torch.frombuffer(host[k], dtype=torch.uint8, count=hb).to(device)) == fph[k] for k in sel[:8])
+            assert ok, "host_api: the host-buffer round trip differs from the device-resident one"
+            RESULT["line"]["configs"]["host_api"] = {
+                "workload": f"{nh} x {a.host_api_block_mib:g} MiB text blocks through bz3_encode_blocks + bz3_decode_blocks on malloc'ed host buffers (H2D / D2H inside the timed calls: "
+                            f"SURVEY.md 8d's boundary, include/libbz3.h:206-213), and the same batch device-resident",
+                "value": round(nh * hb / 2 ** 20 / (te_h + td_h), 3), "unit": "MiB/s", "t_enc_s": round(te_h, 2), "t_dec_s": round(td_h, 2),
+                "device_resident": {"value": round(nh * hb / 2 ** 20 / (te_d + td_d), 3), "t_enc_s": round(te_d, 2), "t_dec_s": round(td_d, 2)},
+                "pcie_inclusive_over_device_resident": round((te_d + td_d) / (te_h + td_h), 4)}
+            progress(f"host_api: {RESULT['line']['configs']['host_api']['value']} MiB/s through host buffers, x{RESULT['line']['configs']['host_api']['pcie_inclusive_over_device_resident']} of device-resident")
+            del host
         else:
-            RESULT["line"]["configs"]["random"] = {"skipped": f"{left_s():.0f}s of the budget left"}
+            RESULT["line"]["configs"]["host_api"] = {"skipped": f"needs ~{est:.0f}s, {left_s():.0f}s of the budget left"}
 
     if rank == 0:
         emit_line(final=True)
-    for s in states[: (live_states if rank == 0 and world == 1 and not a.no_extras else nblk)]:
+    for s in states[:live_states]:
         lib.bz3_free(s)
     if world > 1:
         dist.barrier()

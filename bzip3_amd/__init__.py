@@ -26,7 +26,7 @@ T_NAMES = ["crc", "rle", "lzp", "bwt", "cm", "copy", "_6", "_7"]
 _lib = None
 
 
-def _declare(L):
+def _declare(L, strict=True):
     vp, i32, u32, sz = C.c_void_p, C.c_int32, C.c_uint32, C.c_size_t
     sig = {
         "bz3_version": (C.c_char_p, []),
@@ -49,6 +49,7 @@ def _declare(L):
         "bz3_hip_state_device": (C.c_int, [vp]),
         "bz3_hip_set_cm_mode": (C.c_int, [C.c_int]),
         "bz3_hip_cm_blocks_given_up": (C.c_uint, []),
+        "bz3_hip_debug_cm_experiment": (None, [C.c_int]),
         "bz3_hip_debug_peak_concurrent_groups": (C.c_int, [C.c_int]),
         "bz3_hip_debug_front_end_ring": (C.c_int, []),
         "bz3_hip_cm_variant_for": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -78,6 +79,8 @@ def _declare(L):
         "bz3_hip_decode_stream": (C.c_int, [C.c_int, C.c_int, i32]),
     }
     for name, (res, args) in sig.items():
+        if not strict and not hasattr(L, name):  # an OLDER build loaded for a same-box A/B (load(path)): symbols added since are absent
+            continue
         fn = getattr(L, name)  # AttributeError here = the library does not export what include/*.h declares
         fn.restype = res
         fn.argtypes = args
@@ -120,7 +123,7 @@ def load(path=None):
             f"{p} is missing: the HIP extension has not been built (python -m bzip3_amd.build). "
             "bzip3_amd has no CPU or PyTorch fallback by design."
         )
-    L = _declare(C.CDLL(p))
+    L = _declare(C.CDLL(p), strict=path is None)
     if path is None:
         _lib = L
     return L

@@ -1627,6 +1627,8 @@ BZIP3_API int bz3_hip_set_cm_mode(int mode) {
 
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void) { return g_cm_given_up.load(); }
 
+BZIP3_API void bz3_hip_debug_cm_experiment(int x) { cm_set_experiment(x); }
+
 BZIP3_API int bz3_hip_cm_variant_for(int device, int blocks, int encode) {
     DeviceCtx * c = get_ctx(device);
     return (c && blocks > 0) ? cm_variant_for(c, (size_t)blocks, encode != 0) : -1;

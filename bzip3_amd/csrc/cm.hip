@@ -341,19 +341,45 @@ __device__ __forceinline__ void cm_code_bits_raw(const CmByteEvents & ev, u32 & 
 // holds i.  Compressed output trails its input by construction; should it ever catch up (the prefix coded so far
 // expands by more than the buffer's slack, the n/50 + 32 bytes bz3_bound adds) the sink switches, for the rest of
 // the block, to the side buffer, and the host appends that part once the input is dead.
+// The bytes are collected in LDS (put) and leave as four 16-byte stores per full group of 64 (flush_groups, called once behind a byte's
+// checked coding: a byte emits a handful of bytes at most, the stage holds 128) -- round 3: byte-granular stores cost 3.2 bytes of
+// HBM write traffic per coded byte, profiles/pmc_traffic.json.  A store that happens later than its put is still below the loaded
+// input, which only grows.
 struct CmSink {
     u8 * __restrict__ out;
     u8 * __restrict__ side;
     u32 gap, side_cap, n;
+    u8 * stage;                // 128 bytes of LDS (16-byte aligned): bytes [flushed, op) of the output, not stored yet
     u32 op = 0;                // bytes coded so far
     u32 sw = 0xFFFFFFFFu;      // first byte that went to the side buffer
     u32 failed = 0;            // side buffer exhausted
+    u32 flushed = 0;           // bytes stored so far (a multiple of 64 until the block ends)
+    __device__ __forceinline__ void flush_groups() {  // the full groups of 64 among the staged bytes (those that go to `out`: below sw)
+        const u32 lim = sw == 0xFFFFFFFFu ? op : sw;
+        while (lim - flushed >= 64u) {
+            const uint4 * __restrict__ src = reinterpret_cast<const uint4 *>(stage + (flushed & 127u));
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint4 q = src[k];
+                PackedU128 w;
+                w.v[0] = q.x; w.v[1] = q.y; w.v[2] = q.z; w.v[3] = q.w;
+                *reinterpret_cast<PackedU128 *>(out + flushed + 16u * (u32)k) = w;
+            }
+            flushed += 64u;
+        }
+    }
+    __device__ __forceinline__ void finish() {  // end of the block: the last, partial group one byte at a time
+        flush_groups();
+        const u32 lim = sw == 0xFFFFFFFFu ? op : sw;
+        for (u32 k = flushed; k < lim; k++) out[k] = stage[k & 127u];
+        flushed = lim;
+    }
     __device__ __forceinline__ void put(u32 byte, u32 i) {
         if (sw == 0xFFFFFFFFu && gap != CM_NO_GAP) {
             const u32 loaded = (i | (CM_CHUNK - 1u)) + 1u;  // input bytes below this index are in registers
-            if ((u64)op >= (u64)gap + (loaded < n ? loaded : n)) sw = op;
+            if ((u64)op >= (u64)gap + (loaded < n ? loaded : n)) sw = op;  // (what is staged stays staged: it belongs below sw)
         }
-        if (sw == 0xFFFFFFFFu) out[op] = (u8)byte;
+        if (sw == 0xFFFFFFFFu) stage[op & 127u] = (u8)byte;
         else if (op - sw < side_cap) side[op - sw] = (u8)byte;
         else failed = 1;
         op++;
@@ -424,6 +450,7 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     __shared__ CmLdsT<R> m;
     __shared__ __attribute__((aligned(16))) CmRing ring;
     __shared__ CmEvent ev[8 * CM_CHUNK];
+    __shared__ __attribute__((aligned(16))) u8 s_stage[128];  // the coder's output groups (CmSink)
     __shared__ u32 s_prod, s_cons;
     __shared__ CmRowCache<R> rc;  // R > 0: the directory of the row cache
     if (threadIdx.x == 0) s_prod = 0;
@@ -521,7 +548,7 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     cm_raise_priority();  // the coder is the critical path of its block (measured at three per CU: -9 .. -14 % launch time, profiles/r02_cm_priority.txt)
     const u32 vzero = cm_opaque_zero();  // keeps the recurrence on the vector ALU
     u32 range = 0xFFFFFFFFu ^ vzero, low = vzero, prod_seen = debug == 1 ? 0xFFFFFFFFu : 0u;
-    CmSink sink{out, global_ptr<u8>(jobs[blockIdx.x].side), jobs[blockIdx.x].gap, jobs[blockIdx.x].side_cap, n};
+    CmSink sink{out, global_ptr<u8>(jobs[blockIdx.x].side), jobs[blockIdx.x].gap, jobs[blockIdx.x].side_cap, n, s_stage};
     // Fast path: all 8 bits of the byte without a single test.  While nothing is renormalised the intervals are
     // nested, so "a renormalisation was due after some bit" is equivalent to "the final interval lies within one
     // 2^24 bucket" (:390): one test per byte (plus the guard against a range that reached zero on the way).  If it fires
@@ -586,6 +613,7 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
             } else {
                 cm_code_bits_checked<4, 4>(ev, range, low, sink, i);
             }
+            sink.flush_groups();
         }
     };
     // Waits until the model waves have published byte i (false: they gave the block up).
@@ -620,6 +648,7 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
         sink.put(low >> 24, n - 1u);
         low <<= 8;
     }
+    sink.finish();
     out_size[0] = sink.failed ? 0xFFFFFFFFu : sink.op;
     out_size[1] = sink.sw;
 }
@@ -769,7 +798,9 @@ struct CmEvalP {              // CmEval with the cells remembered by address
     u32 w;                    // both cells, x1 | x2 << 16
 };
 
-template <int R, bool PROF>  // PROF: cycle counters instead of the first output bytes (profiling only, BZ3_CM_DEBUG=3)
+// X: experiment bits (round 4).  1 = the model waves own SUBTREES instead of consecutive nodes (see "node of a lane" below);
+//    2 = lanes whose node is not on the guessed byte's path skip what cannot have changed (see "what a right guess leaves to do").
+template <int R, bool PROF, int X>  // PROF: cycle counters instead of the first output bytes (profiling only, BZ3_CM_DEBUG=3)
 __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restrict__ jobs, CmLdsT<R> & m) {
     const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 in_size = jobs[blockIdx.x].in_size;
@@ -800,7 +831,22 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         // hide.  Hence: LDS cells are remembered as address-space-3 POINTERS (the address that read a cell also writes it back: no index
         // arithmetic), the two C2 rows of the node (run flag 0 / 1) are pointers that only change when the flag does, both order-1
         // counters of the speculative table are the same cell (7 c0 + 9 cell), and two bytes are unrolled per loop trip.
-        const u32 node = threadIdx.x - 64u;
+        // Node of a lane.  Plain form: node = lane number among the 256 model lanes (breadth-first order; lane 0 owns no node).
+        // Subtree form (X & 1): model wave w owns the 63 nodes below the level-2 node 4 + w, i.e. levels 2..7 of every byte whose
+        // two top bits are w, and one spare lane each takes the root, the two level-1 nodes and nothing.  A byte's path then lies
+        // in ONE wave plus the spare lanes: with the root and node 2 (top bit 0) in wave 1 -- its leaf for 0x7E / 0x7F moves to
+        // wave 3's spare lane to make room -- the bytes 0x40 .. 0x7D (the letters of text) touch wave 1 only.
+        u32 node = threadIdx.x - 64u;
+        if (X & 1) {
+            const u32 w = node >> 6, l = node & 63u;
+            if (l == 0u) {
+                node = w == 0u ? 0u : (w == 1u ? 1u : (w == 2u ? 3u : 191u));
+            } else {
+                const u32 d = (u32)(31 - __clz((int)l));
+                node = ((4u + w) << d) | (l - (1u << d));
+            }
+            if (w == 1u && l == 63u) node = 2u;  // (its own leaf 191 is wave 3's spare)
+        }
         const u32 lvl = node ? (u32)(31 - __clz((int)node)) : 0u;
         const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
         const u32 nodelow = node ^ hibit;  // the bits of a byte that lead to this node, i.e. byte >> shr (lane 0 of wave 1 owns no node: nodelow = 1 > byte >> 8)
@@ -811,6 +857,7 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         CM_LDS u32 * const ptab0 = (CM_LDS u32 *)&ptab[0][node];
         CM_LDS u32 * const ptab1 = (CM_LDS u32 *)&ptab[1][node];
         // Probability of the node (:377-388) into *pt, given 16 p = (c0 + p1) * 7 + 2 * p2 and the node's C2 row for the run flag.
+        u32 lastval = 0;  // what this lane wrote into the table last (X & 2)
         auto evaluate = [&](CM_LDS u32 * pt, CM_LDS u16 * a1, u32 p1, u32 p16, CM_LDS u16 * c2row) __attribute__((always_inline)) -> CmEvalP {
             CmEvalP e;
             e.a1 = a1;
@@ -829,7 +876,8 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
             const int p = (int)(p16 >> 4);
             const int x1 = (int)(e.w & 0xFFFFu), x2 = (int)(e.w >> 16);
             const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);
-            *pt = cm_mad24((u32)ssep, 3u, (u32)p) << 14;       // (ssep < 2^16)
+            lastval = cm_mad24((u32)ssep, 3u, (u32)p) << 14;   // (ssep < 2^16)
+            *pt = lastval;
             return e;
         };
         // byte 0: nothing to guess (c1 = c2 = 0, run = 1, :367-372)
@@ -872,7 +920,22 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
             // ... and the table of byte i with c1 = g, c2 = k1: both order-1 counters are `cell`, the run counter goes up
             run_prev++;
             if (__builtin_expect(run_prev == 3u, 0)) c2row = c2row1;
-            cur = evaluate(pt, prev.a1, cell, cm_mad24(cell, 9u, cm_mad24(c0, 7u, 0u)), c2row);
+            // What a right guess leaves to do (X & 2).  The table of byte i is made with c1 = c2 = g and the run flag of run_prev.  A node
+            // that is NOT on g's path has seen no update since the last table, so once the context stands still its entry is the one
+            // it wrote before: run_prev = 1 (new c1 row) and 3 (the flag turns) evaluate everywhere; 2 and 4 repeat the previous step's
+            // value into this step's buffer; from 5 on the buffer already holds it (it was written two steps ago with the same
+            // context).  Whole waves without a node on the path then fall through the evaluation (cf. the subtree form above).
+            // (X & 4: the same decision per WAVE -- a wave that holds a node of the path evaluates all its lanes, so that the wave the
+            // others wait for runs one arm only.)
+            bool full = true;
+            if (X & 4) full = __ballot(on_g) != 0ull || run_prev == 1u || run_prev == 3u;
+            else if (X & 2) full = on_g || run_prev == 1u || run_prev == 3u;
+            if (full) {
+                cur = evaluate(pt, prev.a1, cell, cm_mad24(cell, 9u, cm_mad24(c0, 7u, 0u)), c2row);
+            } else {
+                cur = prev;
+                if (run_prev < 5u) *pt = lastval;
+            }
             if (PROF) m1 = cm_clock();
             __syncthreads();  // barrier 1: the walker has decoded byte i-1
             const u32 c = cm_uniform(LDS_PEEK(s_done[BUF ^ 1u]));
@@ -1118,10 +1181,10 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
 #undef CM_SPEC_LEVEL
 #undef CM_REAL_LEVEL
 
-template <int R, bool PROF = false>
+template <int R, bool PROF = false, int X = 0>
 __device__ __forceinline__ void cm_decode_sync_entry(const CmDecodeJob * __restrict__ jobs) {
     BZ3_DYN_SMEM(dyn_lds);
-    cm_decode_block_sync<R, PROF>(jobs, *reinterpret_cast<CmLdsT<R> *>(dyn_lds));
+    cm_decode_block_sync<R, PROF, X>(jobs, *reinterpret_cast<CmLdsT<R> *>(dyn_lds));
 }
 __global__ void __launch_bounds__(320) k_cm_decode_sync(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<0>(jobs); }
 __global__ void __launch_bounds__(320) k_cm_decode_sync2(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS_DEC>(jobs); }
@@ -1130,6 +1193,9 @@ __global__ void __launch_bounds__(320) k_cm_decode_sync3(const CmDecodeJob * __r
 __global__ void __launch_bounds__(320) k_cm_decode_sync_prof(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<0, true>(jobs); }
 __global__ void __launch_bounds__(320) k_cm_decode_sync2_prof(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS_DEC, true>(jobs); }
 __global__ void __launch_bounds__(320) k_cm_decode_sync3_prof(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS3_DEC, true>(jobs); }
+// round-4 experiments (cm_decode_block_sync's X), selected by bz3_hip_debug_cm_experiment()
+template <int R, bool PROF, int X>
+__global__ void __launch_bounds__(320) k_cm_decode_x(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<R, PROF, X>(jobs); }
 #ifdef BZ3_EMU
 __global__ void __launch_bounds__(320) k_cm_decode_sync_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS_TEST>(jobs); }
 #endif
@@ -1143,10 +1209,39 @@ void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int v
     else launch(k_cm_encode, dim3(njobs), dim3(128), 0, s, d_jobs);
 }
 
+static std::atomic<int> g_cm_experiment{0};
+void cm_set_experiment(int x) { g_cm_experiment.store(x); }
+
+template <int R, bool PROF, int X>
+static void cm_launch_x(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s) {
+#ifndef BZ3_EMU
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_x<R, PROF, X>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<R>)));
+#endif
+    launch(k_cm_decode_x<R, PROF, X>, dim3(njobs), dim3(320), sizeof(CmLdsT<R>), s, d_jobs);
+}
+template <int R>
+static bool cm_launch_experiment(int x, bool prof, const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s) {
+    switch (x * 2 + (prof ? 1 : 0)) {
+        case 2: cm_launch_x<R, false, 1>(d_jobs, njobs, s); return true;
+        case 3: cm_launch_x<R, true, 1>(d_jobs, njobs, s); return true;
+        case 4: cm_launch_x<R, false, 2>(d_jobs, njobs, s); return true;
+        case 5: cm_launch_x<R, true, 2>(d_jobs, njobs, s); return true;
+        case 6: cm_launch_x<R, false, 3>(d_jobs, njobs, s); return true;
+        case 7: cm_launch_x<R, true, 3>(d_jobs, njobs, s); return true;
+        case 10: cm_launch_x<R, false, 5>(d_jobs, njobs, s); return true;
+        case 11: cm_launch_x<R, true, 5>(d_jobs, njobs, s); return true;
+        default: return false;
+    }
+}
+
 void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant, bool prof) {
     if (!njobs) return;
+    const int x = g_cm_experiment.load();
 #ifdef BZ3_EMU
-    if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_decode_sync_test, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS_TEST>), s, d_jobs);
+    if (variant == CM_VARIANT_ROWS_TEST) {
+        if (x && cm_launch_experiment<CM_ROWS_TEST>(x, false, d_jobs, njobs, s)) return;
+        return launch(k_cm_decode_sync_test, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS_TEST>), s, d_jobs);
+    }
 #else
     {  // dynamic LDS beyond 64 KB has to be asked for, once per kernel AND per device (a batch may span several GPUs of one process)
         static std::atomic<u64> prepared[4] = {{0}, {0}, {0}, {0}};  // one bit per device ordinal (up to 256)
@@ -1163,6 +1258,10 @@ void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int v
         }
     }
 #endif
+    if (x) {
+        if (variant == CM_VARIANT_ROWS3 && cm_launch_experiment<CM_ROWS3_DEC>(x, prof, d_jobs, njobs, s)) return;
+        if (variant == CM_VARIANT_FULL && cm_launch_experiment<0>(x, prof, d_jobs, njobs, s)) return;
+    }
     if (variant == CM_VARIANT_ROWS3) launch(prof ? k_cm_decode_sync3_prof : k_cm_decode_sync3, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS3_DEC>), s, d_jobs);
     else if (variant == CM_VARIANT_ROWS) launch(prof ? k_cm_decode_sync2_prof : k_cm_decode_sync2, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS_DEC>), s, d_jobs);
     else launch(prof ? k_cm_decode_sync_prof : k_cm_decode_sync, dim3(njobs), dim3(320), sizeof(CmLdsT<0>), s, d_jobs);

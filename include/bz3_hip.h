@@ -38,6 +38,9 @@ BZIP3_API int bz3_hip_state_device(struct bz3_state * state);
  * Environment BZ3_HIP_CM_MODE=auto|full|rows|rows3 has the same effect.  Output bytes do not depend on the variant.
  * Returns 0, or -1 for an invalid mode. */
 BZIP3_API int bz3_hip_set_cm_mode(int mode);
+/* Experiments (round 4): which build of the guess-ahead CM decoder the decode launches use; 0 = the shipped kernels.  Output bytes do
+ * not depend on it.  tools/cm_coresidency.py --exp=N. */
+BZIP3_API void bz3_hip_debug_cm_experiment(int x);
 /* Number of blocks the row-cache kernels have handed back to the full-model kernels so far (statistics). */
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void);
 

@@ -86,8 +86,15 @@ def bigram_tables():
     return tab
 
 
-def text(n, seed=1, chains=2048):
-    """n bytes of Markov text.  `chains` independent chains are generated in lockstep and concatenated."""
+ENWIK_NOISE = 0.035  # calibrated in round 4: 100,000,000 B at -b 16 -> 22,681,833 B with the reference (enwik8: 22,677,651)
+NOISE_ALPHABET = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789", dtype=np.uint8)
+
+
+def text(n, seed=1, chains=2048, noise=0.0):
+    """n bytes of Markov text.  `chains` independent chains are generated in lockstep and concatenated.
+    noise > 0: that fraction of the tokens has its letters replaced by random characters of [a-z0-9] (identifiers, numbers, markup:
+    what enwik8 has and Shakespeare has not); ENWIK_NOISE is the fraction at which 100,000,000 bytes compress like enwik8 does
+    with the reference's default block size (etc/BENCHMARKS.md:45-47: 4.41 : 1)."""
     t = bigram_tables()
     rng = np.random.Generator(np.random.PCG64(seed))
     avg = float(t["lens"][t["succ"]].mean())  # frequency-weighted word length (+1 space)
@@ -102,17 +109,23 @@ def text(n, seed=1, chains=2048):
     lens = t["lens"][toks]
     ends = np.cumsum(lens)
     total = int(ends[-1])
+    noisy = rng.random(len(toks)) < noise if noise > 0 else None
     if total < n:
-        return (text(n, seed, chains) if False else (np.tile(_emit(t, toks, lens, ends), n // total + 1)[:n])).tobytes()
-    return _emit(t, toks, lens, ends)[:n].tobytes()
+        return np.tile(_emit(t, toks, lens, ends, noisy, rng), n // total + 1)[:n].tobytes()
+    return _emit(t, toks, lens, ends, noisy, rng)[:n].tobytes()
 
 
-def _emit(t, toks, lens, ends):
+def _emit(t, toks, lens, ends, noisy=None, rng=None):
     starts = ends - lens
     total = int(ends[-1])
     tok_of_byte = np.repeat(np.arange(len(toks)), lens)
     within = np.arange(total) - starts[tok_of_byte]
-    return t["blob"][t["off"][toks[tok_of_byte]] + within]
+    out = t["blob"][t["off"][toks[tok_of_byte]] + within]
+    if noisy is not None:
+        mask = noisy[tok_of_byte] & (within < lens[tok_of_byte] - 1)  # the token's letters, not its space
+        out = out.copy()
+        out[mask] = NOISE_ALPHABET[rng.integers(0, len(NOISE_ALPHABET), size=int(mask.sum()))]
+    return out
 
 
 def random_bytes(n, seed=2):

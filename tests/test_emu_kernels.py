@@ -867,3 +867,27 @@ def test_unbwt_single_walk_with_strided_splitters(emu, oracle):
         jidx = int(rng.integers(1, n + 1))
         assert g.unbwt(junk, jidx) == oracle.unbwt(junk, jidx), n
         assert g.unbwt(u, jidx) == oracle.unbwt(u, jidx), n
+
+
+@pytest.mark.parametrize("x", [1, 2, 3, 5])
+def test_cm_decoder_experiments_match_oracle(emu, oracle, cm_mode, x):
+    """Round-4 builds of the guess-ahead decoder (cm.hip cm_decode_block_sync's X: model waves that own subtrees, lanes off the guessed
+    path that skip what cannot have changed): same bytes as the oracle on runs of every length around the thresholds of the skip
+    logic (1..8 equal bytes), BWT output of text, noise, truncated streams, with the whole model and with the tiny row cache."""
+    g = bzip3_amd.StageApi(emu)
+    rng = np.random.default_rng(40 + x)
+    runs = bytes(np.repeat(rng.integers(0x20, 0x7F, size=400, dtype=np.uint8), rng.integers(1, 9, size=400)))
+    longruns = bytes(np.repeat(rng.integers(0, 256, size=60, dtype=np.uint8), rng.integers(1, 70, size=60)))
+    cases = [runs, longruns, oracle.bwt(datagen.shakespeare()[200000:204000])[1], bytes(rng.integers(0, 256, size=1500, dtype=np.uint8)),
+             b"a" * 3000, b"ab" * 700 + b"~" * 40 + b"\x7f" * 40 + b"\xff" * 30 + b"\x00" * 30, b"x"]
+    try:
+        emu.bz3_hip_debug_cm_experiment(x)
+        for mode in (0, 9, 2):
+            assert cm_mode(mode) == 0
+            for d in cases:
+                c = oracle.cm_encode(d)
+                assert g.cm_decode(c, len(d)) == d, (mode, len(d))
+                cut = c[: len(c) * 2 // 3]
+                assert g.cm_decode(cut, len(d)) == oracle.cm_decode(cut, len(d)), (mode, len(d))
+    finally:
+        emu.bz3_hip_debug_cm_experiment(0)

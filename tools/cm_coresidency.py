@@ -1,5 +1,5 @@
 """How do CM decoder variants behave when several blocks share a CU?  (GPU box, no torch import.)
-    python tools/cm_coresidency.py [MiB=2] [copies ...=256 512 768] [--cycles] [--only=a,b] [--lib=path]
+    python tools/cm_coresidency.py [MiB=2] [copies ...=256 512 768] [--cycles] [--only=a,b] [--lib=path] [--exp=0,1,..]
 For every decoder (sync = whole model, sync2 / sync3 = row caches for two / three blocks per CU) and every number of identical blocks: ONE launch of the CM decoder over
 `copies` copies of the same coded block (bz3_hip_stage_cm_decode_many), launch time by HIP events, ns per byte and block,
 aggregate MiB/s.  --cycles additionally runs the guess-ahead variants with BZ3_CM_DEBUG=3 and prints the decoder's phase
@@ -36,15 +36,19 @@ def main():
     inb = bzip3_amd._cbuf(coded, len(coded))
     out = (C.c_uint8 * n)()
     only = [a[len("--only="):].split(",") for a in sys.argv if a.startswith("--only=")]
+    exps = [a[len("--exp="):].split(",") for a in sys.argv if a.startswith("--exp=")]  # decoder experiments (bz3_hip_debug_cm_experiment), each run in turn
+    exps = [int(x) for x in exps[0]] if exps else [0]
     for name, mode in MODES.items():
         if (only and name not in only[0]) or (not only and not name.startswith("sync")):
             continue
         assert lib.bz3_hip_set_cm_mode(mode) == 0
-        for k in copies:
+        for k, exp in [(k, e) for k in copies for e in exps]:
+            if hasattr(lib, "bz3_hip_debug_cm_experiment"):
+                lib.bz3_hip_debug_cm_experiment(exp)
             os.environ.pop("BZ3_CM_DEBUG", None)
             ms = lib.bz3_hip_stage_cm_decode_many(inb, len(coded), out, n, k, None)
             ok = bytes(out) == plain and ms >= 0  # (BZ3_CM_MANY_CHECK=1: ms == -2 when the copies disagree)
-            rec = {"variant": name, "copies": k, "block_mib": mib, "ms": round(ms, 1), "ns_per_byte_per_block": round(ms * 1e6 / n, 1),
+            rec = {"variant": name, "exp": exp, "copies": k, "block_mib": mib, "ms": round(ms, 1), "ns_per_byte_per_block": round(ms * 1e6 / n, 1),
                    "MiBps": round(k * mib / (ms * 1e-3), 1), "exact": ok}
             if cycles and not name.startswith("lock"):
                 os.environ["BZ3_CM_DEBUG"] = "3"

@@ -21,7 +21,8 @@ def main():
     mib = float(args[0]) if args else 2.0
     copies = [int(a) for a in args[1:]] or [256, 512, 768]
     n = int(mib * (1 << 20))
-    lib = bzip3_amd.load()
+    libs = [a[len("--lib="):] for a in sys.argv if a.startswith("--lib=")]  # --lib=<path>: another build of the library (same-box A/B)
+    lib = bzip3_amd.load(libs[0]) if libs else bzip3_amd.load()
     assert lib.bz3_hip_device_count() > 0
     g = bzip3_amd.StageApi(lib)
     assert lib.bz3_hip_set_cm_mode(0) == 0
