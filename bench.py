@@ -567,11 +567,11 @@ def main():
     assert lib.bz3_hip_set_lean_states(1 if lean else 0) == 0
     cap = lib.bz3_bound(block_size) + 4096
     noise = a.noise
-    if a.kind == "text" or a.leg:
+    if (a.kind == "text" or a.leg) and not a.emu:
         seed_text_source(lib)
-        import datagen
-
         if noise < 0:
+            import datagen
+
             noise = datagen.ENWIK_NOISE
 
     def markov16(n, seed):
@@ -594,8 +594,8 @@ def main():
     # ---- synthetic input, resident in HBM ----------------------------------------------------------------
     t_gen = time.perf_counter()
     nbase = max(1, min(a.text_bases, nblk))
-    if a.leg == "cfg5":
-        bases = [markov16(block_size, 50 + rank)]
+    if a.leg == "cfg5" or a.emu:  # (--emu: no corpus to decode with the emulator; the control flow does not care what the bytes are)
+        bases = [markov16(block_size, 50 + rank + 10 * j) for j in range(nbase if a.emu else 1)]
     elif a.kind == "text":
         bases = [gen_text_device(torch, block_size, seed=1 + rank + 100 * j, device=device, noise=noise) for j in range(nbase)]
     else:
@@ -628,7 +628,7 @@ def main():
     t_gen = time.perf_counter() - t_gen
     progress(f"{nblk} x {block_size} B input blocks resident in HBM ({t_gen:.1f}s)")
 
-    states = (C.c_void_p * nblk)(*[lib.bz3_new(block_size) for _ in range(nblk)])
+    states = (C.c_void_p * nblk)(*[lib.bz3_new(max(block_size, 65 * 1024)) for _ in range(nblk)])  # (blocks below bz3_new's minimum: --emu tests)
     assert all(states), "bz3_new failed"
     progress("states created")
     ptrs = (C.c_void_p * nblk)(*[b.data_ptr() for b in bufs])
@@ -774,6 +774,8 @@ def main():
         except Exception as e:
             progress(f"repeat-rate sample failed: {e}")
         what = {"": f"synthetic enwik-style {a.kind}", "cfg5": "16-symbol order-1 Markov (BASELINE.json configs[4] stand-in)"}[a.leg]
+        if a.emu:
+            what = "16-symbol order-1 Markov (--emu: CPU emulation of the kernels, control-flow test only)"
         out = {
             "metric": "MiB/s encode+decode round-trip, 256 MiB blocks" if not a.leg else f"MiB/s encode+decode round-trip, {block_size >> 20} MiB blocks (leg {a.leg})",
             "value": round(value, 3),
@@ -795,7 +797,7 @@ def main():
             "config": {
                 "workload": f"{nblk} x {block_size / 2 ** 20:g} MiB {what} blocks per GPU"
                             + (f" (word-bigram Markov over shakespeare.txt tokens, {noise * 100:g} % noise tokens = enwik8's 4.41 : 1 at -b 16; {nbase} independent texts, "
-                               f"block k = text k mod {nbase} with its 64 KiB pieces in a block-specific order)" if a.kind == "text" and not a.leg else "")
+                               f"block k = text k mod {nbase} with its 64 KiB pieces in a block-specific order)" if a.kind == "text" and not a.leg and not a.emu else "")
                             + ", resident in HBM, bz3_hip_encode_blocks_device + bz3_hip_decode_blocks_device",
                 "block_bytes": block_size,
                 "blocks_per_gpu": nblk,

@@ -1,0 +1,53 @@
+"""bench.py's multi-rank control flow on CPU: `python bench.py --gpus 2 --emu` starts its own two
+ranks (torch.distributed.run on 127.0.0.1), every rank codes and decodes its own blocks -- the kernel sources under the test-only HIP
+emulation instead of a GPU, gloo instead of RCCL -- and rank 0 prints ONE JSON line whose value is the whole job's bytes over the
+max-over-ranks time.  The same file is what the driver launches on the 8-GPU node:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--emu", "--blocks", "2", "--block-mib", "0.003", "--steps", "2", "--warmup", "0", "--text-bases", "2"]
+
+
+def _run(cmd):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE line, from rank 0
+    return json.loads(lines[0]), r.stderr
+
+
+def _check(d, world):
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["higher_is_better"] is True and d["unit"] == "MiB/s"
+    assert d["steps"] == 2 and len(d["step_s"]) == 2 and d["complete"] is True
+    nbytes = world * 2 * int(0.003 * (1 << 20)) * d["steps"]  # every rank's blocks count: the whole job's aggregate
+    assert abs(d["value"] - nbytes / 2 ** 20 / sum(d["step_s"])) <= 0.02 * d["value"] + 1e-3
+    assert d["config"]["blocks_per_gpu"] == 2 and d["cpu_baseline"]["value"] is None
+
+
+def test_bench_spawns_its_own_ranks_and_rank_0_reports_the_aggregate():
+    d, err = _run([sys.executable, "bench.py", "--gpus", "2"] + ARGS)
+    _check(d, 2)
+    assert err.count("encode_blocks done") == 2  # progress lines come from rank 0 only: two steps
+
+
+def test_bench_under_torch_distributed_run_as_the_driver_launches_it():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    d, _ = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                 "bench.py", "--gpus", "2"] + ARGS)
+    _check(d, 2)
+
+
+def test_bench_single_rank_on_the_emulator():
+    d, _ = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS)
+    _check(d, 1)
