@@ -301,7 +301,7 @@ def test_batch_over_all_gpus_of_the_node(gpu_lib, oracle, text):
     """bz3_encode_blocks / bz3_decode_blocks with states on EVERY visible GPU (the reference forks a thread per block,
     src/libbz3.c:845-870): bz3_new round-robins the states over the devices, the batch is split into one group per GPU and the groups
     run at the same time (api.hip for_each_device_group).  Oracle bytes both ways, as many groups inside their group function at once
-    as there are devices, and the batch takes no longer than 1.3 x the same per-GPU load on one GPU alone.  Skipped on a 1-GPU lease:
+    as there are devices, and the batch takes no longer than 1.15 x the same per-GPU load (6 blocks of 4 MiB: > 3 s of codec time) on one GPU alone -- groups that ran one after the other would take ndev x.  Skipped on a 1-GPU lease:
     it costs nothing there, and it is the only hardware evidence of row (e) when the node has more."""
     import time
 
@@ -352,7 +352,8 @@ def test_batch_over_all_gpus_of_the_node(gpu_lib, oracle, text):
     _, t_one, _, devs1 = run(pieces[:per_dev])  # the same per-GPU load on one GPU
     gpu_lib.bz3_hip_bind_device(-1)
     assert set(devs1) == {0}
-    assert t_all < 1.3 * t_one + 0.5, f"{ndev} GPUs x {per_dev} blocks took {t_all:.2f}s, one GPU x {per_dev} blocks {t_one:.2f}s"
+    assert t_one > 1.0, f"per-GPU load too small to tell overlap from serialisation ({t_one:.2f}s)"
+    assert t_all < 1.15 * t_one, f"{ndev} GPUs x {per_dev} blocks took {t_all:.2f}s, one GPU x {per_dev} blocks {t_one:.2f}s"
 
 
 def test_device_resident_api(gpu_lib, oracle, text):
