@@ -341,45 +341,19 @@ __device__ __forceinline__ void cm_code_bits_raw(const CmByteEvents & ev, u32 & 
 // holds i.  Compressed output trails its input by construction; should it ever catch up (the prefix coded so far
 // expands by more than the buffer's slack, the n/50 + 32 bytes bz3_bound adds) the sink switches, for the rest of
 // the block, to the side buffer, and the host appends that part once the input is dead.
-// The bytes are collected in LDS (put) and leave as four 16-byte stores per full group of 64 (flush_groups, called once behind a byte's
-// checked coding: a byte emits a handful of bytes at most, the stage holds 128) -- round 3: byte-granular stores cost 3.2 bytes of
-// HBM write traffic per coded byte, profiles/pmc_traffic.json.  A store that happens later than its put is still below the loaded
-// input, which only grows.
 struct CmSink {
     u8 * __restrict__ out;
     u8 * __restrict__ side;
     u32 gap, side_cap, n;
-    u8 * stage;                // 128 bytes of LDS (16-byte aligned): bytes [flushed, op) of the output, not stored yet
     u32 op = 0;                // bytes coded so far
     u32 sw = 0xFFFFFFFFu;      // first byte that went to the side buffer
     u32 failed = 0;            // side buffer exhausted
-    u32 flushed = 0;           // bytes stored so far (a multiple of 64 until the block ends)
-    __device__ __forceinline__ void flush_groups() {  // the full groups of 64 among the staged bytes (those that go to `out`: below sw)
-        const u32 lim = sw == 0xFFFFFFFFu ? op : sw;
-        while (lim - flushed >= 64u) {
-            const uint4 * __restrict__ src = reinterpret_cast<const uint4 *>(stage + (flushed & 127u));
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint4 q = src[k];
-                PackedU128 w;
-                w.v[0] = q.x; w.v[1] = q.y; w.v[2] = q.z; w.v[3] = q.w;
-                *reinterpret_cast<PackedU128 *>(out + flushed + 16u * (u32)k) = w;
-            }
-            flushed += 64u;
-        }
-    }
-    __device__ __forceinline__ void finish() {  // end of the block: the last, partial group one byte at a time
-        flush_groups();
-        const u32 lim = sw == 0xFFFFFFFFu ? op : sw;
-        for (u32 k = flushed; k < lim; k++) out[k] = stage[k & 127u];
-        flushed = lim;
-    }
     __device__ __forceinline__ void put(u32 byte, u32 i) {
         if (sw == 0xFFFFFFFFu && gap != CM_NO_GAP) {
             const u32 loaded = (i | (CM_CHUNK - 1u)) + 1u;  // input bytes below this index are in registers
-            if ((u64)op >= (u64)gap + (loaded < n ? loaded : n)) sw = op;  // (what is staged stays staged: it belongs below sw)
+            if ((u64)op >= (u64)gap + (loaded < n ? loaded : n)) sw = op;
         }
-        if (sw == 0xFFFFFFFFu) stage[op & 127u] = (u8)byte;
+        if (sw == 0xFFFFFFFFu) out[op] = (u8)byte;
         else if (op - sw < side_cap) side[op - sw] = (u8)byte;
         else failed = 1;
         op++;
@@ -450,7 +424,6 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     __shared__ CmLdsT<R> m;
     __shared__ __attribute__((aligned(16))) CmRing ring;
     __shared__ CmEvent ev[8 * CM_CHUNK];
-    __shared__ __attribute__((aligned(16))) u8 s_stage[128];  // the coder's output groups (CmSink)
     __shared__ u32 s_prod, s_cons;
     __shared__ CmRowCache<R> rc;  // R > 0: the directory of the row cache
     if (threadIdx.x == 0) s_prod = 0;
@@ -548,7 +521,7 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     cm_raise_priority();  // the coder is the critical path of its block (measured at three per CU: -9 .. -14 % launch time, profiles/r02_cm_priority.txt)
     const u32 vzero = cm_opaque_zero();  // keeps the recurrence on the vector ALU
     u32 range = 0xFFFFFFFFu ^ vzero, low = vzero, prod_seen = debug == 1 ? 0xFFFFFFFFu : 0u;
-    CmSink sink{out, global_ptr<u8>(jobs[blockIdx.x].side), jobs[blockIdx.x].gap, jobs[blockIdx.x].side_cap, n, s_stage};
+    CmSink sink{out, global_ptr<u8>(jobs[blockIdx.x].side), jobs[blockIdx.x].gap, jobs[blockIdx.x].side_cap, n};
     // Fast path: all 8 bits of the byte without a single test.  While nothing is renormalised the intervals are
     // nested, so "a renormalisation was due after some bit" is equivalent to "the final interval lies within one
     // 2^24 bucket" (:390): one test per byte (plus the guard against a range that reached zero on the way).  If it fires
@@ -613,7 +586,6 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
             } else {
                 cm_code_bits_checked<4, 4>(ev, range, low, sink, i);
             }
-            sink.flush_groups();
         }
     };
     // Waits until the model waves have published byte i (false: they gave the block up).
@@ -648,7 +620,6 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
         sink.put(low >> 24, n - 1u);
         low <<= 8;
     }
-    sink.finish();
     out_size[0] = sink.failed ? 0xFFFFFFFFu : sink.op;
     out_size[1] = sink.sw;
 }
