@@ -303,9 +303,9 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
 }
 
 // ---- small kernels of the orchestration layer ---------------------------------------------------
-__global__ void k_write_header(u8 * __restrict__ b, const u32 * __restrict__ crc, u32 idx, u32 model, u32 lzp_size, u32 rle_size) {
+__global__ void k_write_header(u8 * __restrict__ b, const u32 * __restrict__ crc, const u32 * __restrict__ idx_word, u32 model, u32 lzp_size, u32 rle_size) {
     if (threadIdx.x != 0) return;
-    const u32 c = *crc;
+    const u32 c = *crc, idx = *idx_word;  // (the primary index stays on the device: bwt_forward's d_idx)
     b[0] = (u8)c; b[1] = (u8)(c >> 8); b[2] = (u8)(c >> 16); b[3] = (u8)(c >> 24);
     b[4] = (u8)idx; b[5] = (u8)(idx >> 8); b[6] = (u8)(idx >> 16); b[7] = (u8)(idx >> 24);
     b[8] = (u8)model;
@@ -345,6 +345,7 @@ struct bz3_state {
     hipStream_t xs = nullptr;      // execution stream of the current call: the lead state's stream of its device group
     u8 * d_swap = nullptr;  // the reference's swap_buffer, in HBM (lean states: borrowed from the device's pool while a call needs it)
     bool lean = false;      // see bz3_hip_set_lean_states
+    bool timed = true;      // this block's stages are timed with host clocks (a stream synchronisation per stage): the first block of a group only
     u8 * d_io = nullptr;    // staging for the host-buffer API (lazy)
     size_t cap = 0;         // bz3_bound(block_size) rounded up
     u32 * d_words = nullptr;  // [0..1] crc scratch/result, [2] cm coded size, [4] rle total, [5] lzp result
@@ -459,8 +460,10 @@ void encode_front_a(bz3_state * st, u8 * buf, s32 data_size, Arena & arena, Aren
         st->pending = bz3_state::ENC_STORED;
         return;
     }
-    HIP_CHECK(hipStreamSynchronize(s));
-    st->t[BZ3_HIP_T_CRC] = (float)(now_ms() - t0);
+    if (st->timed) {
+        HIP_CHECK(hipStreamSynchronize(s));
+        st->t[BZ3_HIP_T_CRC] = (float)(now_ms() - t0);
+    }
 
     u32 n = (u32)data_size;
     lean_borrow(st);
@@ -475,7 +478,7 @@ void encode_front_a(bz3_state * st, u8 * buf, s32 data_size, Arena & arena, Aren
         st->rle_size = (s32)(32u + read_word(s, sc.total));
         if (st->rle_size < (s32)n) {
             mrle_encode_write(b1, n, sc, b2, s);
-            HIP_CHECK(hipStreamSynchronize(s));
+            if (st->timed) HIP_CHECK(hipStreamSynchronize(s));
             u8 * tmp = b1; b1 = b2; b2 = tmp;
             n = (u32)st->rle_size;
             st->model |= 4;
@@ -510,35 +513,35 @@ void encode_front_b(bz3_state * st, Arena & arena, const LzpEncodeCtx & c, float
     st->t[BZ3_HIP_T_LZP] += driver_ms + (float)(now_ms() - t0);
 
     t0 = now_ms();
-    s32 bwt_idx;
+    u32 * const d_idx = st->d_words + 6;  // the primary index never visits the host
     if (!st->lean) {
-        bwt_idx = bwt_forward(b1, n, b2, arena, s, &st->bwt);  // :623-627
+        (void)bwt_forward(b1, n, b2, arena, s, &st->bwt, d_idx);  // :623-627
     } else {
         // Lean state: the coder will work IN PLACE in the caller's buffer (capacity bz3_bound(size), libbz3.h:172-174):
         // the BWT output goes to the END of that buffer, the coded bytes grow from its start (cm.hip CmSink).
         u8 * tail = st->user + bz3_bound((size_t)st->size) - n;
         if (b1 != st->user) {
-            bwt_idx = bwt_forward(b1, n, tail, arena, s, &st->bwt);
+            (void)bwt_forward(b1, n, tail, arena, s, &st->bwt, d_idx);
         } else {
-            bwt_idx = bwt_forward(b1, n, b2, arena, s, &st->bwt);
-            if (bwt_idx >= 0) HIP_CHECK(hipMemcpyAsync(tail, b2, n, hipMemcpyDeviceToDevice, s));
+            (void)bwt_forward(b1, n, b2, arena, s, &st->bwt, d_idx);
+            HIP_CHECK(hipMemcpyAsync(tail, b2, n, hipMemcpyDeviceToDevice, s));
         }
         b1 = st->user;  // receives header + coded bytes
         b2 = tail;      // CM input
     }
-    st->t[BZ3_HIP_T_BWT] = (float)(now_ms() - t0);
-    if (bwt_idx < 0) {
-        st->last_error = BZ3_ERR_BWT;
-        return;
+    if (st->timed) {
+        HIP_CHECK(hipStreamSynchronize(s));
+        st->t[BZ3_HIP_T_BWT] = (float)(now_ms() - t0);
     }
     s32 overhead = 2;  // :630-632
     if (st->model & 2) overhead++;
     if (st->model & 4) overhead++;
-    launch(k_write_header, dim3(1), dim3(64), 0, s, b1, (const u32 *)(st->d_words + 1), (u32)bwt_idx, (u32)st->model, (u32)lzp_size, (u32)st->rle_size);  // :641-647
-    if (st->lean) {
-        HIP_CHECK(hipStreamSynchronize(s));  // the swap buffer goes back to the pool: nothing may still be reading it
-        lean_return(st);
-    }
+    launch(k_write_header, dim3(1), dim3(64), 0, s, b1, (const u32 *)(st->d_words + 1), (const u32 *)d_idx, (u32)st->model, (u32)lzp_size, (u32)st->rle_size);  // :641-647
+    // The swap buffer goes back to the pool.  Whoever borrows it next is a later block of this group -- the group holds the device's
+    // mutex for the whole call and every kernel that touches the buffer, this block's and the next borrower's, is launched on the group's
+    // ONE stream (the side streams only run LZP drivers, behind events recorded on it) --, so stream order is what protects it; rounds 1-3
+    // waited for the stream here, once per block.
+    if (st->lean) lean_return(st);
     st->b1 = b1;
     st->b2 = b2;
     st->n_cm = n;
@@ -613,7 +616,10 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     // One execution stream per call: the whole-GPU phases of the blocks run one after the other anyway, and stream
     // order is what protects the arena's scratch regions, which consecutive blocks reuse while earlier kernels are
     // still in flight.
-    for (s32 i = 0; i < n; i++) sts[i]->xs = lead->stream;
+    for (s32 i = 0; i < n; i++) {
+        sts[i]->xs = lead->stream;
+        sts[i]->timed = i == 0;  // stage timings (bz3_hip_last_timings) are sampled on the group's first block: timing a stage means waiting for the stream
+    }
     size_t need = 0;
     for (s32 i = 0; i < n; i++) {
         const size_t w = workspace_bytes_for((u64)(sizes[i] > 0 ? sizes[i] : 0) + 64);
@@ -1628,6 +1634,8 @@ BZIP3_API int bz3_hip_set_cm_mode(int mode) {
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void) { return g_cm_given_up.load(); }
 
 BZIP3_API void bz3_hip_debug_cm_experiment(int x) { cm_set_experiment(x); }
+
+BZIP3_API void bz3_hip_debug_bwt_big_rounds(int k) { bwt_set_big_rounds(k); }
 
 BZIP3_API int bz3_hip_cm_variant_for(int device, int blocks, int encode) {
     DeviceCtx * c = get_ctx(device);

@@ -28,6 +28,7 @@
 //
 // HBM per block of n bytes (carved from the per-device workspace): 2 x key u64[n], 2 x suffix u32[n], payload u8[n]; the deep path
 // additionally ISA u32[n], 2 x slot u32[n], rank u32[n], tile words.  Algorithmic traffic: 11 B per input byte.
+#include <atomic>
 #include <vector>
 
 #include "prims.hpp"
@@ -71,71 +72,111 @@ __global__ void __launch_bounds__(BW_BLOCK) k_bwt_sym_hist(const u8 * __restrict
 }
 
 // Optimal alphabetic (order-preserving) prefix-free code of height <= 8 for the byte values present, by dynamic programming over
-// intervals: cost[l][i][j] = lightest tree of height <= l over the present values i .. j-1 (Knuth's root bounds; a cell whose
-// bounded search finds nothing feasible is searched in full, so the result is always a valid code).  Host, ~1 ms.
-static void vlc_build(const u32 * cnt, u32 * table) {
-    int sym[256], s = 0;
-    for (int c = 0; c < 256; c++) {
-        table[c] = 0;
-        if (cnt[c]) sym[s++] = c;
+// intervals: cost[l][i][j] = lightest tree of height <= l over the present values i .. j-1 = min over the split k of
+// cost[l-1][i][k] + cost[l-1][k][j], plus the weight of the interval.  On the DEVICE since round 4 (rounds 1-3 copied the histogram to
+// the host, ran the recurrence there in ~1 ms and copied the table back: a stream synchronisation and a millisecond of idle GPU per
+// block, and a front end that slowed down with the host): a level is one launch with a thread per interval -- every cell of a level
+// only reads the level below --, the tables (two cost planes of 257 x 257 u64, nine root planes of u16) live in the block's arena.
+// Which optimal tree comes out does not matter to the BWT (any order-preserving prefix code sorts the suffixes the same way): ties
+// go to the smallest split.
+constexpr int VLC_S1 = 257;                         // intervals [i, j) over up to 256 present values: 0 <= i < j <= 256
+constexpr u64 VLC_INF = ~0ull >> 2;
+constexpr size_t VLC_PLANE = (size_t)VLC_S1 * VLC_S1;
+struct VlcWork {
+    u32 s;            // byte values present
+    u32 sym[256];     // ... in increasing order
+    u64 pre[257];     // prefix sums of their counts
+};
+constexpr size_t VLC_WORK_BYTES = ((sizeof(VlcWork) + 255) & ~(size_t)255) + 2 * VLC_PLANE * sizeof(u64) + (VLC_MAXLEN + 1) * VLC_PLANE * sizeof(u16) + 256;
+
+// the present values, their prefix sums, level 0 (single values cost nothing, nothing else fits height 0), the trivial tables
+__global__ void __launch_bounds__(256) k_vlc_init(const u32 * __restrict__ hist, VlcWork * __restrict__ w, u64 * __restrict__ cost0, u32 * __restrict__ table) {
+    __shared__ u32 lds[256 / WAVE + 1];
+    __shared__ u64 s_cnt[256];
+    const u32 c = threadIdx.x;
+    const u32 cnt = hist[c];
+    u32 total;
+    const u32 at = block_excl_add<256>(cnt ? 1u : 0u, lds, total);
+    s_cnt[c] = 0;
+    __syncthreads();
+    if (cnt) {
+        w->sym[at] = c;
+        s_cnt[at] = cnt;
     }
-    if (s == 0) return;
-    if (s == 1) {
-        table[sym[0]] = (0u << 4) | 1u;
-        return;
+    table[c] = (total == 1u && cnt) ? ((0u << 4) | 1u) : 0u;  // one value: code 0, one bit; the others are filled in by k_vlc_codes
+    __syncthreads();
+    if (c == 0) {
+        w->s = total;
+        u64 run = 0;
+        for (u32 k = 0; k <= 256u; k++) {
+            w->pre[k] = run;
+            if (k < 256u) run += s_cnt[k];
+        }
     }
-    constexpr u64 INF = ~0ull >> 2;
-    const int S1 = s + 1;
-    std::vector<u64> pre((size_t)S1, 0);
-    for (int i = 0; i < s; i++) pre[(size_t)i + 1] = pre[(size_t)i] + cnt[sym[i]];
-    static thread_local std::vector<u64> cost;
-    static thread_local std::vector<u16> root;
-    cost.assign((size_t)(VLC_MAXLEN + 1) * S1 * S1, INF);
-    root.assign((size_t)(VLC_MAXLEN + 1) * S1 * S1, 0);
-    auto at = [&](int l, int i, int j) -> size_t { return ((size_t)l * S1 + (size_t)i) * S1 + (size_t)j; };
-    for (int l = 0; l <= VLC_MAXLEN; l++)
-        for (int i = 0; i < s; i++) cost[at(l, i, i + 1)] = 0;
-    for (int l = 1; l <= VLC_MAXLEN; l++) {
-        for (int len = 2; len <= s && len <= (1 << l); len++) {
-            for (int i = 0; i + len <= s; i++) {
-                const int j = i + len;
-                int lo = i + 1, hi = j - 1;
-                if (len > 2) {
-                    const int a = root[at(l, i, j - 1)], b = root[at(l, i + 1, j)];
-                    if (a >= i + 1 && b >= a && b <= j - 1) { lo = a; hi = b; }
-                }
-                u64 best = INF;
-                int bk = 0;
-                for (int pass = 0; pass < 2 && best >= INF; pass++) {
-                    if (pass == 1) { lo = i + 1; hi = j - 1; }
-                    for (int k = lo; k <= hi; k++) {
-                        const u64 a = cost[at(l - 1, i, k)], b = cost[at(l - 1, k, j)];
-                        if (a >= INF || b >= INF) continue;
-                        if (a + b < best) { best = a + b; bk = k; }
-                    }
-                }
-                if (best < INF) {
-                    cost[at(l, i, j)] = best + (pre[(size_t)j] - pre[(size_t)i]);
-                    root[at(l, i, j)] = (u16)bk;
+    for (u32 i = 0; i < (u32)VLC_S1; i++) {  // row i of the level-0 plane
+        const u32 j0 = c, j1 = c + 256u;
+        cost0[(size_t)i * VLC_S1 + j0] = j0 == i + 1u ? 0ull : VLC_INF;
+        if (j1 < (u32)VLC_S1) cost0[(size_t)i * VLC_S1 + j1] = j1 == i + 1u ? 0ull : VLC_INF;
+    }
+}
+// level l from level l-1: workgroup i, thread j-1
+__global__ void __launch_bounds__(256) k_vlc_level(const VlcWork * __restrict__ w, u32 l, const u64 * __restrict__ below, u64 * __restrict__ cost, u16 * __restrict__ root) {
+    const u32 s = w->s;
+    const u32 i = blockIdx.x, j = threadIdx.x + 1u;
+    if (i >= s) return;
+    u64 best = VLC_INF;
+    u32 bk = 0;
+    if (j > i && j <= s) {
+        const u32 len = j - i, half = 1u << (l - 1u);
+        if (len == 1u) {
+            best = 0;
+        } else if (len <= 2u * half) {
+            const u32 klo = j > i + half ? j - half : i + 1u;      // both parts must fit height l-1: at most 2^(l-1) values each
+            const u32 khi = i + half < j - 1u ? i + half : j - 1u;
+            for (u32 k = klo; k <= khi; k++) {
+                const u64 a = below[(size_t)i * VLC_S1 + k], b = below[(size_t)k * VLC_S1 + j];
+                if (a < VLC_INF && b < VLC_INF && a + b < best) {
+                    best = a + b;
+                    bk = k;
                 }
             }
+            if (best < VLC_INF) best += w->pre[j] - w->pre[i];
         }
     }
-    // walk the tree (explicit stack: interval, level, code so far)
-    struct Node { int i, j, l; u32 code, len; };
-    std::vector<Node> st;
-    st.push_back({0, s, VLC_MAXLEN, 0u, 0u});
-    while (!st.empty()) {
-        const Node nd = st.back();
-        st.pop_back();
-        if (nd.j - nd.i == 1) {
-            table[sym[nd.i]] = (nd.code << 4) | nd.len;
-            continue;
-        }
-        const int k = root[at(nd.l, nd.i, nd.j)];
-        st.push_back({nd.i, k, nd.l - 1, nd.code << 1, nd.len + 1});
-        st.push_back({k, nd.j, nd.l - 1, (nd.code << 1) | 1u, nd.len + 1});
+    if (j > i && j < (u32)VLC_S1) {
+        cost[(size_t)i * VLC_S1 + j] = best;
+        root[(size_t)i * VLC_S1 + j] = (u16)bk;
     }
+}
+// every present value walks down from the root of the height-8 tree: table[c] = code << 4 | length
+__global__ void __launch_bounds__(256) k_vlc_codes(const VlcWork * __restrict__ w, const u16 * __restrict__ roots, u32 * __restrict__ table) {
+    const u32 s = w->s, x = threadIdx.x;
+    if (s < 2u || x >= s) return;
+    u32 i = 0, j = s, l = VLC_MAXLEN, code = 0, len = 0;
+    while (j - i > 1u) {
+        const u32 k = roots[(size_t)l * VLC_PLANE + (size_t)i * VLC_S1 + j];
+        if (x < k) {
+            j = k;
+            code <<= 1;
+        } else {
+            i = k;
+            code = (code << 1) | 1u;
+        }
+        l--;
+        len++;
+    }
+    table[w->sym[x]] = (code << 4) | len;
+}
+static void vlc_build_device(const u32 * d_hist, u32 * d_table, Arena & tmp, hipStream_t s) {
+    char * base = tmp.take<char>(VLC_WORK_BYTES);
+    VlcWork * w = reinterpret_cast<VlcWork *>(base);
+    u64 * cost[2] = {reinterpret_cast<u64 *>(base + ((sizeof(VlcWork) + 255) & ~(size_t)255)), nullptr};
+    cost[1] = cost[0] + VLC_PLANE;
+    u16 * roots = reinterpret_cast<u16 *>(cost[1] + VLC_PLANE);
+    launch(k_vlc_init, dim3(1), dim3(256), 0, s, d_hist, w, cost[0], d_table);
+    for (u32 l = 1; l <= (u32)VLC_MAXLEN; l++)
+        launch(k_vlc_level, dim3(256), dim3(256), 0, s, (const VlcWork *)w, l, (const u64 *)cost[(l - 1) & 1], cost[l & 1], roots + (size_t)l * VLC_PLANE);
+    launch(k_vlc_codes, dim3(1), dim3(256), 0, s, (const VlcWork *)w, (const u16 *)roots, d_table);
 }
 
 // The first B code bits of the symbols in the window (wa, wb: 16 bytes, little endian; avail <= 16 of them exist), zero padded;
@@ -847,62 +888,69 @@ __global__ void __launch_bounds__(RT_WAVES * WAVE) k_bwt_route(u32 n, const u32 
 // The wide kernel: one wave per group of 65 .. 512 suffixes (a descriptor of the router), 2 / 4 / 8 suffixes per lane in registers.
 // A step or two later its sub-groups have at most 64 members and go to the tail list.
 __global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_wide(const u8 * __restrict__ t, u32 n, u32 * __restrict__ v, u8 * __restrict__ pb, const u32 * __restrict__ vlc,
-                                                             const u32 * __restrict__ mid_slot, const u16 * __restrict__ mid_size, u32 nmid, u32 * __restrict__ tail_v,
+                                                             const u32 * __restrict__ mid_slot, const u16 * __restrict__ mid_size, u32 mid_cap, u32 * __restrict__ tail_v,
                                                              u32 * __restrict__ tail_slot, u16 * __restrict__ tail_d, u8 * __restrict__ tail_pb, u32 tail_cap,
                                                              u32 * __restrict__ counters, u32 chain) {
     __shared__ u32 tab[256];
     __shared__ WrLds wl[WR_WAVES];
     __shared__ u32 pend[WR_WAVES], pbase[WR_WAVES], pfit;
+    // The number of descriptors is where the router left it, on the device (round 4: the host used to read it back to size this
+    // launch -- a stream synchronisation per pass); the grid is fixed and walks the list.
+    const u32 nmid = counters[8] < mid_cap ? counters[8] : mid_cap;
+    if (blockIdx.x * WR_WAVES >= nmid) return;
     tab[threadIdx.x] = vlc[threadIdx.x];
     __syncthreads();
     const u32 lane = (u32)lane_id();
-    const u32 g = blockIdx.x * WR_WAVES + (u32)wave_id();
     WrLds & lds = wl[wave_id()];
-    u32 pending = 0;
-    u64 slot0 = 0;
-    if (g < nmid) {
-        const u32 L = mid_size[g];
-        slot0 = mid_slot[g];
-        WrCtx cx{t, n, v, pb, tab, counters, chain, slot0, tail_v, tail_slot, tail_d, tail_pb, tail_cap};
-        if (L <= 128u) pending = wr_batch<2>(cx, lds, L);
-        else pending = wr_batch<4>(cx, lds, L);
-    }
-    // ---- one append to the tail list per workgroup (an append per wave made the list's counter the bottleneck)
-    if (lane == 0) pend[wave_id()] = pending;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 tot = 0;
-        for (int w = 0; w < WR_WAVES; w++) {
-            pbase[w] = tot;
-            tot += pend[w];
+    for (u32 g0 = blockIdx.x * WR_WAVES; g0 < nmid; g0 += gridDim.x * WR_WAVES) {  // (uniform trip count per workgroup: barriers inside)
+        const u32 g = g0 + (u32)wave_id();
+        u32 pending = 0;
+        u64 slot0 = 0;
+        if (g < nmid) {
+            const u32 L = mid_size[g];
+            slot0 = mid_slot[g];
+            WrCtx cx{t, n, v, pb, tab, counters, chain, slot0, tail_v, tail_slot, tail_d, tail_pb, tail_cap};
+            if (L <= 128u) pending = wr_batch<2>(cx, lds, L);
+            else pending = wr_batch<4>(cx, lds, L);
         }
-        u32 fits = 1;
-        if (tot) {
-            const u32 b0 = atomicAdd(&counters[4], tot);
-            fits = b0 + tot <= tail_cap ? 1u : 0u;
-            if (!fits) {
-                counters[3] = 1u;
-                atomicMin(&counters[5], b0);  // the list is valid up to the first append that did not fit
-                atomicAdd(&counters[1], tot);
+        // ---- one append to the tail list per workgroup (an append per wave made the list's counter the bottleneck)
+        if (lane == 0) pend[wave_id()] = pending;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u32 tot = 0;
+            for (int w = 0; w < WR_WAVES; w++) {
+                pbase[w] = tot;
+                tot += pend[w];
             }
-            for (int w = 0; w < WR_WAVES; w++) pbase[w] += b0;
+            u32 fits = 1;
+            if (tot) {
+                const u32 b0 = atomicAdd(&counters[4], tot);
+                fits = b0 + tot <= tail_cap ? 1u : 0u;
+                if (!fits) {
+                    counters[3] = 1u;
+                    atomicMin(&counters[5], b0);  // the list is valid up to the first append that did not fit
+                    atomicAdd(&counters[1], tot);
+                }
+                for (int w = 0; w < WR_WAVES; w++) pbase[w] += b0;
+            }
+            pfit = fits;
         }
-        pfit = fits;
-    }
-    __syncthreads();
-    const u32 base = pbase[wave_id()];
-    for (u32 q = lane; q < pending; q += WAVE) {
-        const u64 x = lds.pl[q];
-        if (pfit) {
-            tail_v[base + q] = pl_v(x) | (lds.hd[q] ? V_HEAD : 0u);
-            tail_slot[base + q] = (u32)(slot0 + lds.aux[q]);
-            tail_d[base + q] = (u16)pl_d(x);
-            tail_pb[base + q] = (u8)pl_p(x);
-        } else {  // back where they are: the deep path takes them
-            const u64 p = slot0 + lds.aux[q];
-            v[p] = pl_v(x) | (lds.hd[q] ? V_HEAD : 0u);
-            pb[p] = (u8)pl_p(x);
+        __syncthreads();
+        const u32 base = pbase[wave_id()];
+        for (u32 q = lane; q < pending; q += WAVE) {
+            const u64 x = lds.pl[q];
+            if (pfit) {
+                tail_v[base + q] = pl_v(x) | (lds.hd[q] ? V_HEAD : 0u);
+                tail_slot[base + q] = (u32)(slot0 + lds.aux[q]);
+                tail_d[base + q] = (u16)pl_d(x);
+                tail_pb[base + q] = (u8)pl_p(x);
+            } else {  // back where they are: the deep path takes them
+                const u64 p = slot0 + lds.aux[q];
+                v[p] = pl_v(x) | (lds.hd[q] ? V_HEAD : 0u);
+                pb[p] = (u8)pl_p(x);
+            }
         }
+        __syncthreads();  // pend / pbase / the waves' LDS are reused by the next descriptors
     }
 }
 
@@ -915,28 +963,31 @@ __global__ void __launch_bounds__(WR_WAVES * WAVE) k_bwt_wide(const u8 * __restr
 // one is covered by the others -- which the resolve kernel, with eight suffixes per lane in registers, cannot offer.
 __global__ void __launch_bounds__(WAVE) k_bwt_tail(const u8 * __restrict__ t, u32 n, u32 * __restrict__ v, u8 * __restrict__ pb, const u32 * __restrict__ vlc,
                                                   const u32 * __restrict__ tail_v, const u32 * __restrict__ tail_slot, const u16 * __restrict__ tail_d,
-                                                  const u8 * __restrict__ tail_pb, u32 * __restrict__ counters, u32 total_entries, u32 chain) {
+                                                  const u8 * __restrict__ tail_pb, u32 * __restrict__ counters, u32 chain) {
     __shared__ u32 tab[256];
     __shared__ u64 s_word[WAVE];
     __shared__ u32 s_v[WAVE];
     __shared__ u16 s_d[WAVE];
     __shared__ u8 s_pb[WAVE];
     const u32 lane = (u32)lane_id();
-    const u32 off = blockIdx.x * WAVE;  // this wave's 64 entries; its groups end before off + 128
-    if (off >= total_entries) return;
+    // The length of the list is where the router and the wide kernel left it, on the device ([5]: where the first append that did
+    // not fit would have started); the grid is fixed and every wave walks the list in strides (round 4: no read-back to size the launch).
+    const u32 total_entries = counters[4] < counters[5] ? counters[4] : counters[5];
+    if (blockIdx.x * WAVE >= total_entries) return;
+#pragma unroll
+    for (int k = 0; k < 4; k++) tab[lane + 64u * k] = vlc[lane + 64u * k];
+    __syncthreads();
+  for (u32 off = blockIdx.x * WAVE; off < total_entries; off += gridDim.x * WAVE) {  // this wave's 64 entries; their groups end before off + 128
     u32 cursor, cnt;
     {
         const u32 i0 = off + lane, i1 = off + WAVE + lane;
         const u64 h0 = __ballot(i0 >= total_entries || (tail_v[i0 < total_entries ? i0 : 0u] >> 31) != 0u);
         const u64 h1 = __ballot(i1 >= total_entries || (tail_v[i1 < total_entries ? i1 : 0u] >> 31) != 0u);
-        if (!h0) return;  // these 64 entries continue a group headed in the previous wave's entries
+        if (!h0) continue;  // these 64 entries continue a group headed in the previous wave's entries
         cursor = (u32)__ffsll((unsigned long long)h0) - 1u;
         cnt = h1 ? (u32)WAVE + (u32)__ffsll((unsigned long long)h1) - 1u : 2u * WAVE;
         if (off + cnt > total_entries) cnt = total_entries - off;
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) tab[lane + 64u * k] = vlc[lane + 64u * k];
-    __syncthreads();
     while (cursor < cnt) {
         const u32 i = cursor + lane;
         const bool have = i < cnt;
@@ -1039,6 +1090,7 @@ __global__ void __launch_bounds__(WAVE) k_bwt_tail(const u8 * __restrict__ t, u3
         }
         cursor += e;
     }
+  }
 }
 
 // ---- the big path: one more window for the members of groups too large for the resolve kernel --------------------------------
@@ -1401,7 +1453,7 @@ static int bits_for(u64 x) {
 
 size_t bwt_workspace_bytes(u64 n) {
     // 2 keys (16) + 2 suffix arrays (8) + payload (1) + tail list (11) + ISA (4) + 2 slot lists (8) + ranks (4) + tile words (4) + a third suffix list (4)
-    return n * (16 + 8 + 1 + 11 + 4 + 8 + 4 + 4 + 4) + n / 8 + radix_temp_bytes(n) + scan_temp_words(n) * 4 + (1u << 20) + 16384;
+    return n * (16 + 8 + 1 + 11 + 4 + 8 + 4 + 4 + 4) + n / 8 + radix_temp_bytes(n) + scan_temp_words(n) * 4 + (1u << 20) + 16384 + VLC_WORK_BYTES;
 }
 
 // full LSD sort of (keys, iota) over key bits [bit_lo, bit_hi): the first pass generates the values.  Returns the buffer index of the result.
@@ -1420,10 +1472,37 @@ static int sort_iota(const K * kin, K * k0, K * k1, u32 * v0, u32 * v1, u64 n, i
     return cur;
 }
 
-s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, BwtStats * stats) {
-    if (n == 0) return 0;
+// Test / diagnosis switches, read from the environment ONCE (rounds 1-3 called getenv per block and per pass):
+//   BZ3_BWT_TRACE=1        one line per pass on stderr
+//   BZ3_BWT_BIG_ROUNDS=<k> tests only: how many more windows the big groups get before the deep path takes them (0: none; default 1);
+//                          within a process: bz3_hip_debug_bwt_big_rounds(k), k < 0 = default
+struct BwtSwitches {
+    bool trace;
+    std::atomic<int> big_rounds;
+};
+static BwtSwitches & bwt_switches() {
+    static BwtSwitches sw{getenv("BZ3_BWT_TRACE") != nullptr, {getenv("BZ3_BWT_BIG_ROUNDS") ? atoi(getenv("BZ3_BWT_BIG_ROUNDS")) : 1}};
+    return sw;
+}
+void bwt_set_big_rounds(int k) { bwt_switches().big_rounds.store(k < 0 ? 1 : k); }  // tests: bz3_hip_debug_bwt_big_rounds
+constexpr u32 WIDE_GRID = 2048;    // workgroups of the wide kernel (four descriptors each per trip)
+constexpr u32 TAIL_GRID = 24576;   // waves of the tail kernel (96 per CU: its ~50 registers and 2 KB of LDS let dozens share a CU)
+
+__global__ void k_bwt_set_word(u32 * p, u32 v) { *p = v; }
+
+// d_idx == nullptr: synchronous, returns the primary index.  d_idx != nullptr: the primary index is left THERE (a device word that outlives
+// the arena) and the call returns 0 without waiting for the stream -- the block's header is written by a kernel that reads it (round 4).
+s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, BwtStats * stats, u32 * d_idx) {
+    if (n == 0) {
+        if (d_idx) launch(k_bwt_set_word, dim3(1), dim3(1), 0, s, d_idx, 0u);
+        return 0;
+    }
     if (n == 1) {
         HIP_CHECK(hipMemcpyAsync(d_out, d_in, 1, hipMemcpyDeviceToDevice, s));
+        if (d_idx) {
+            launch(k_bwt_set_word, dim3(1), dim3(1), 0, s, d_idx, 1u);
+            return 0;
+        }
         HIP_CHECK(hipStreamSynchronize(s));
         return 1;
     }
@@ -1448,15 +1527,15 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     auto grid = [](u64 m) { return dim3((u32)((m + BW_BLOCK - 1) / BW_BLOCK)); };
 
     // ---- codes
-    u32 h_hist[256], h_vlc[256];
     HIP_CHECK(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), s));
     HIP_CHECK(hipMemsetAsync(d_words, 0, 16 * sizeof(u32), s));
     HIP_CHECK(hipMemsetAsync(d_words + 5, 0xFF, sizeof(u32), s));
     launch(k_bwt_sym_hist, grid(((u64)n + 63) / 64), dim3(BW_BLOCK), 0, s, d_in, n, d_hist);
-    HIP_CHECK(hipMemcpyAsync(h_hist, d_hist, sizeof h_hist, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
-    vlc_build(h_hist, h_vlc);
-    HIP_CHECK(hipMemcpyAsync(d_vlc, h_vlc, sizeof h_vlc, hipMemcpyHostToDevice, s));
+    {
+        const size_t vm = tmp.mark();
+        vlc_build_device(d_hist, d_vlc, tmp, s);  // (stream order protects the scratch: what reuses it is launched after the last level)
+        tmp.release(vm);
+    }
 
     // ---- round 0: all suffixes by their first 56 code bits
     launch(k_bwt_vlc_keys, grid(((u64)n + 7) / 8), dim3(BW_BLOCK), 0, s, d_in, n, (const u32 *)d_vlc, key[0]);
@@ -1498,29 +1577,20 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
         launch(k_bwt_route, dim3((tiles + RT_WAVES - 1) / RT_WAVES), dim3(RT_WAVES * WAVE), 0, s, n, (const u32 *)V, (const u8 *)pb, (const u32 *)hbits,
                (const u32 *)carry, (const u32 *)group_carry, (const u8 *)(pass ? dirty : nullptr), big_slot, big_hp, big_cap, mid_slot, mid_size, mid_cap, tail_v, tail_slot,
                tail_d, tail_pb, tail_cap, d_words);
-        HIP_CHECK(hipMemcpyAsync(h_words, d_words, sizeof h_words, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
-        const u32 nmid = h_words[8] < mid_cap ? h_words[8] : mid_cap;
-        if (nmid) {
-            launch(k_bwt_wide, dim3((nmid + WR_WAVES - 1) / WR_WAVES), dim3(WR_WAVES * WAVE), 0, s, d_in, n, V, pb, (const u32 *)d_vlc, (const u32 *)mid_slot,
-                   (const u16 *)mid_size, nmid, tail_v, tail_slot, tail_d, tail_pb, tail_cap, d_words, (u32)pass + 1u);
-            HIP_CHECK(hipMemcpyAsync(h_words, d_words, sizeof h_words, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-        }
-        const u32 ntail = h_words[4] < h_words[5] ? h_words[4] : h_words[5];  // ([5]: where the first append that did not fit would have started)
-        if (ntail)
-            launch(k_bwt_tail, dim3((ntail + WAVE - 1) / WAVE), dim3(WAVE), 0, s, d_in, n, V, pb, (const u32 *)d_vlc, (const u32 *)tail_v, (const u32 *)tail_slot,
-                   (const u16 *)tail_d, (const u8 *)tail_pb, d_words, ntail, (u32)pass + 1u);
+        // the wide and the tail kernel take their work lists' lengths from the counters on the device: fixed grids, ONE read-back per pass
+        launch(k_bwt_wide, dim3(WIDE_GRID), dim3(WR_WAVES * WAVE), 0, s, d_in, n, V, pb, (const u32 *)d_vlc, (const u32 *)mid_slot, (const u16 *)mid_size, mid_cap, tail_v,
+               tail_slot, tail_d, tail_pb, tail_cap, d_words, (u32)pass + 1u);
+        launch(k_bwt_tail, dim3(TAIL_GRID), dim3(WAVE), 0, s, d_in, n, V, pb, (const u32 *)d_vlc, (const u32 *)tail_v, (const u32 *)tail_slot, (const u16 *)tail_d,
+               (const u8 *)tail_pb, d_words, (u32)pass + 1u);
         HIP_CHECK(hipMemcpyAsync(h_words, d_words, sizeof h_words, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         const u32 nb = h_words[0];
-        if (getenv("BZ3_BWT_TRACE")) fprintf(stderr, "[bwt] n %u pass %d depth %u: %u suffixes in groups > %d, %u groups through the wide kernel, %u suffixes through the tail kernel, %u given up, overflow %u\n", n, pass, g, nb, TR_G, h_words[8], h_words[4], h_words[1], h_words[3]);
+        if (bwt_switches().trace) fprintf(stderr, "[bwt] n %u pass %d depth %u: %u suffixes in groups > %d, %u groups through the wide kernel, %u suffixes through the tail kernel, %u given up, overflow %u\n", n, pass, g, nb, TR_G, h_words[8], h_words[4], h_words[1], h_words[3]);
         if (nb == 0) {  // no group left that is too large: done, unless the resolve kernel gave some up (counted over all passes)
             deep = h_words[1] != 0;
             break;
         }
-        const char * env_rounds = getenv("BZ3_BWT_BIG_ROUNDS");  // tests only: 0 = big groups go straight to the deep path
-        const int max_big = env_rounds ? atoi(env_rounds) : 1;  // one more window takes text from ~12 % of its suffixes in big groups to ~1 %; what is left is deep and goes to rank doubling
+        const int max_big = bwt_switches().big_rounds.load();  // one more window takes text from ~12 % of its suffixes in big groups to ~1 %; what is left is deep and goes to rank doubling
         if (h_words[3] || pass >= max_big || nb > n / 4) {  // groups too many / too deep for windows of code bits
             deep = true;
             break;
@@ -1581,7 +1651,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
         // every group still ambiguous shares at least h symbols: 7 per window of the big rounds; a group the resolve kernel gave up
         // shares the first window's 7 and 5 more per step it took (WR_CAP steps): never the shallower of the two.
         u32 m = n, h = g < 7u + 5u * (u32)TL_CAP ? g : 7u + 5u * (u32)TL_CAP;
-        if (getenv("BZ3_BWT_TRACE")) fprintf(stderr, "[bwt] n %u deep path from depth %u\n", n, h);
+        if (bwt_switches().trace) fprintf(stderr, "[bwt] n %u deep path from depth %u\n", n, h);
         {
             // ranks in slot order, then the inverse suffix array from (suffix, rank) pairs bucketed by the top bits of the suffix
             u32 * rk = reinterpret_cast<u32 *>(key[0]);
@@ -1633,8 +1703,12 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
         // isa[0] = the slot of suffix 0
         launch(k_bwt_finish, grid(n), dim3(BW_BLOCK), 0, s, d_in, (const u8 *)pb, n, (const u32 *)isa, d_out, d_words + 7);
     }
-    HIP_CHECK(hipMemcpyAsync(&idx, d_words + 7, 4, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    if (d_idx) {
+        HIP_CHECK(hipMemcpyAsync(d_idx, d_words + 7, 4, hipMemcpyDeviceToDevice, s));
+    } else {
+        HIP_CHECK(hipMemcpyAsync(&idx, d_words + 7, 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
     tmp.release(mk);
     if (stats) *stats = st;
     return (s32)idx;

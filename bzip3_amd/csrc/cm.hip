@@ -28,6 +28,7 @@
 namespace bz3 {
 
 constexpr int CM_C2_STRIDE = 17;
+constexpr unsigned CM_RUN_K = 4;  // right guesses in a row after which the guess-ahead decoder works two tables ahead (cm_decode_block_sync, X & 8)
 
 // R = 0: the whole order-1 table (256 rows) in LDS, one block per CU.  R > 0: only R rows of the order-1 table are
 // resident ("row cache", see below), so that two workgroups share a CU's LDS.
@@ -870,7 +871,57 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         // One byte: `prev` = what the evaluation of byte i-1 left, `cur` receives that of byte i.  Two bytes per loop trip with the two
         // records swapping roles, so that neither they nor the table buffer / the s_done word of a byte cost a move or an address
         // computation (BUF = i & 1 is a compile-time constant).  Returns false when the block was given up.
-        auto step = [&](const u32 i, auto buf_tag, const CmEvalP & prev, CmEvalP & cur) __attribute__((always_inline)) -> bool {
+        // The repair after a wrong guess (byte i-1 = c, not g): put the old counters back (the old values are still in `prev`, the record of
+        // the table byte i-1 was decoded with), apply the real update and evaluate table i again, into *pt.  The new c1 row differs from the
+        // row being repaired, so its read goes first.  Returns true when the block was given up (R > 0).
+        // (Issue priority for these waves during the repair -- the walker waits for it -- was measured in round 3: 804 -> 800 ns per
+        // byte at three per CU, nothing.)
+        auto redo = [&](const u32 i, const u32 c, CM_LDS u32 * pt, const CmEvalP & prev, const u32 c0_old, const bool on_g, CmEvalP & cur) __attribute__((always_inline)) -> bool {
+            bool give_up = false;
+            u32 row = c;
+            if (R) {
+                row = (cm_readlane(rowreg, (int)(c >> 2)) >> (8u * (c & 3u))) & 0xFFu;
+                if (__builtin_expect(row >= CM_ROW_SPILLED, 0)) {
+                    // the only row still needed is the one of byte i-2 (prev.a1 points into it): pin it
+                    rs.tick++;
+                    if (lane == 0) rc.stamp[cm_uniform((u32)(prev.a1 - c1col) >> 8)] = rs.tick;
+                    wave_sync();
+                    row = cm_rows_fetch<R, 1>(m, rc, rs, spill, c, row, node);
+                    rowreg = reinterpret_cast<const u32 *>(rc.row_of)[lane];
+                    if (__builtin_expect(rs.misses > miss_base + (i >> miss_shift), 0)) {
+                        // the working set does not fit (every model wave gets here at the same byte): the block is given up.  The repair
+                        // below still runs -- no second way out of this branch, the compiler pays for one with moves on every path --
+                        // and the walker reads s_abort behind barrier 2
+                        give_up = true;
+                        if (threadIdx.x == 64) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
+                        LDS_POKE(s_abort, 1u);
+                    }
+                }
+            }
+            CM_LDS u16 * const a1 = c1col + row * 256u;
+            const u32 p1 = *a1;
+            u32 cell2 = prev.p1;
+            if (on_g) {
+                c0 = c0_old;
+                prev.ci->v = prev.w;
+            }
+            if ((c >> shr) == nodelow) {
+                const u32 mk = 0u - ((c >> bitpos) & 1u);
+                c0 = cm_upd(c0, 2, mk & 16383u);
+                cell2 = cm_upd(prev.p1, 4, mk & 4095u);
+                prev.ci->v = cm_upd_pair6(prev.w, mk & 0x03FF03FFu);
+            }
+            *prev.a1 = (u16)cell2;  // (unconditionally: storing the value that is there already costs less than finding out)
+            c2row = c2row0;  // c != k1: the run counter restarts
+            cur = evaluate(pt, a1, p1, cm_mad24(c0 + p1, 7u, 2u * cell2), c2row0);
+            if (R) wave_sync();  // (test emulation: a row fetch de-synchronises the fibers of a wave; no instruction on the GPU)
+            return give_up;
+        };
+        u32 hits = 0;  // right guesses in a row (X & 8; the walker counts the same)
+        // One byte: `prev` = what the evaluation of byte i-1 left, `cur` receives that of byte i.  Two bytes per loop trip with the two
+        // records swapping roles, so that neither they nor the table buffer / the s_done word of a byte cost a move or an address
+        // computation (BUF = i & 1 is a compile-time constant).  Returns 0 when the block was given up, 2 when the run phase starts (X & 8), else 1.
+        auto step = [&](const u32 i, auto buf_tag, const CmEvalP & prev, CmEvalP & cur) __attribute__((always_inline)) -> int {
             constexpr u32 BUF = decltype(buf_tag)::value;
             CM_LDS u32 * const pt = BUF ? ptab1 : ptab0;
             bool give_up = false;
@@ -917,58 +968,102 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
             }
             k1 = c;
             if (c != g) {
-                // wrong guess: put the old counters back (the old values are still in `prev`), apply the real update
-                // and evaluate again.  The new c1 row differs from the row being repaired, so its read goes first.
-                // (Issue priority for these waves during the repair -- the walker waits for it -- was measured in round 3: 804 -> 800 ns per
-                // byte at three per CU, nothing.)
-                u32 row = c;
-                if (R) {
-                    row = (cm_readlane(rowreg, (int)(c >> 2)) >> (8u * (c & 3u))) & 0xFFu;
-                    if (__builtin_expect(row >= CM_ROW_SPILLED, 0)) {
-                        // the only row still needed is the one of byte i-2 (prev.a1 points into it): pin it
-                        rs.tick++;
-                        if (lane == 0) rc.stamp[cm_uniform((u32)(prev.a1 - c1col) >> 8)] = rs.tick;
-                        wave_sync();
-                        row = cm_rows_fetch<R, 1>(m, rc, rs, spill, c, row, node);
-                        rowreg = reinterpret_cast<const u32 *>(rc.row_of)[lane];
-                        if (__builtin_expect(rs.misses > miss_base + (i >> miss_shift), 0)) {
-                            // the working set does not fit (every model wave gets here at the same byte): the block is given up.  The repair
-                            // below still runs -- no second way out of this branch, the compiler pays for one with moves on every path --
-                            // and the walker reads s_abort behind barrier 2
-                            give_up = true;
-                            if (threadIdx.x == 64) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
-                            LDS_POKE(s_abort, 1u);
-                        }
-                    }
-                }
-                CM_LDS u16 * const a1 = c1col + row * 256u;
-                const u32 p1 = *a1;
-                u32 cell2 = prev.p1;
-                if (on_g) {
-                    c0 = c0_old;
-                    prev.ci->v = prev.w;
-                }
-                if ((c >> shr) == nodelow) {
-                    const u32 mk = 0u - ((c >> bitpos) & 1u);
-                    c0 = cm_upd(c0, 2, mk & 16383u);
-                    cell2 = cm_upd(prev.p1, 4, mk & 4095u);
-                    prev.ci->v = cm_upd_pair6(prev.w, mk & 0x03FF03FFu);
-                }
-                *prev.a1 = (u16)cell2;  // (unconditionally: storing the value that is there already costs less than finding out)
-                c2row = c2row0;  // c != k1: the run counter restarts
-                cur = evaluate(pt, a1, p1, cm_mad24(c0 + p1, 7u, 2u * cell2), c2row0);
-                if (R) wave_sync();  // (test emulation: a row fetch de-synchronises the fibers of a wave; no instruction on the GPU)
+                give_up = redo(i, c, pt, prev, c0_old, on_g, cur);
                 if (PROF) mprof_redo += cm_clock() - m2;  // up to the arrival at barrier 2
                 __syncthreads();  // barrier 2: the corrected table of byte i is there
                 run_prev = 0;
+                hits = 0;
+                return give_up ? 0 : 1;
             }
-            return !give_up;
+            hits++;
+            return ((X & 8) && hits == CM_RUN_K) ? 2 : 1;
+        };
+        // ---- the run phase (X & 8): two tables ahead ------------------------------------------------------------------------------
+        // After CM_RUN_K right guesses in a row the next one is right 19 times in 20 (BWT output of text), so from here the waves stay TWO
+        // tables ahead of the walker: while it decodes byte t they make table t+2 on the guess that bytes t and t+1 repeat as well.  Table
+        // t+1 is then complete one barrier EARLIER than the walker needs it, and the walker loads it while it still walks byte t: on a
+        // right guess it goes from one byte to the next without waiting for anything (round 3: a third of a right guess's time was the
+        // walker's own table fetch behind the barrier).  A wrong guess undoes two updates instead of one and the phase ends.
+        // Buffers: table x lives in buffer x & 1 as always.  In the steady state the walker holds table t in registers while the waves
+        // write table t+2 over it; the two intervals that lead there -- in which the walker still fetches a table from the buffer the
+        // waves are about to write -- have one more barrier each ("E": the walker passes it after its fetch, the waves before their write).
+        // `t` = the byte the walker decodes next, rl = the record of table t (the newest one).  Returns 0 = given up, 1 = a wrong guess
+        // ended the phase (t is the next byte again, rl the record of its corrected table), 3 = the block ends.
+        auto run_phase = [&](u32 & t, CmEvalP & rl) __attribute__((always_inline)) -> int {
+            static_assert(CM_RUN_K >= 4, "tables t and t+2 must share their context (c1 = c2, run flag set) from the first interval of the phase on");
+            const u32 g = k1;
+            const bool on_g = (g >> shr) == nodelow;
+            const bool wave_on = !(X & 4) || __ballot(on_g) != 0ull;  // (X & 4) waves without a node on the path only keep the protocol: their tables stand still
+            const u32 mk = 0u - ((g >> bitpos) & 1u);
+            CmEvalP ra = rl, rb = rl;  // the records of the two updates in flight (a = the older one)
+            u32 c0a = c0, c0b = c0;    // this lane's order-0 counter before them
+            // one more speculative update (of the byte whose table `r` describes) and the table that follows, into buffer x & 1
+            auto spec = [&](CmEvalP & r, u32 & c0_save, const u32 x) __attribute__((always_inline)) {
+                if (!wave_on) return;
+                r = rl;
+                c0_save = c0;
+                u32 cell = r.p1;
+                if (on_g) {
+                    c0 = cm_upd(c0, 2, mk & 16383u);
+                    cell = cm_upd(r.p1, 4, mk & 4095u);
+                    *r.a1 = (u16)cell;
+                    r.ci->v = cm_upd_pair6(r.w, mk & 0x03FF03FFu);
+                }
+                rl = evaluate((x & 1u) ? ptab1 : ptab0, r.a1, cell, cm_mad24(cell, 9u, cm_mad24(c0, 7u, 0u)), c2row);
+            };
+            spec(ra, c0a, t + 1u);  // catch up: table t+1
+            u32 need_e = 2;
+            for (;;) {
+                if (need_e) {
+                    __syncthreads();  // barrier E: the walker has fetched table t
+                    need_e--;
+                }
+                if (t + 1u >= n) return 3;  // the walker decodes the last byte: no table is needed any more
+                spec(rb, c0b, t + 2u);  // table t+2
+                __syncthreads();  // barrier 1 of byte t
+                const u32 c = cm_uniform(LDS_PEEK(s_done[t & 1u]));
+                k1 = c;
+                if (__builtin_expect(c != g, 0)) {
+                    // undo the newer update (its order-0 / order-1 cells are restored with the older one's), then the usual repair
+                    if (wave_on && on_g) rb.ci->v = rb.w;
+                    const bool give_up = redo(t + 1u, c, ((t + 1u) & 1u) ? ptab1 : ptab0, ra, c0a, on_g, rl);
+                    __syncthreads();  // barrier 2: the corrected table of byte t+1
+                    run_prev = 0;
+                    hits = 0;
+                    t++;
+                    return give_up ? 0 : 1;
+                }
+                hits++;
+                if (wave_on) {
+                    ra = rb;
+                    c0a = c0b;
+                }
+                t++;
+            }
         };
         CmEvalP other = prev;
         for (u32 i = 1; i < n;) {
-            if (!step(i, CmConst<1>{}, prev, other)) return;
-            if (++i >= n) break;
-            if (!step(i, CmConst<0>{}, other, prev)) return;
+            int st;
+            if (i & 1u) {
+                st = step(i, CmConst<1>{}, prev, other);
+                if (st == 1) {
+                    if (++i >= n) break;
+                    st = step(i, CmConst<0>{}, other, prev);
+                } else if (st == 2) {
+                    prev = other;  // (the run phase takes the newest record in `prev`)
+                }
+            } else {
+                st = step(i, CmConst<0>{}, other, prev);
+            }
+            if (st == 0) return;
+            if ((X & 8) && st == 2) {
+                st = run_phase(i, prev);  // i = the byte whose table is the newest one = the byte the walker decodes next
+                if (st == 0) return;
+                if (st == 3) break;
+                other = prev;
+                i++;  // the next table to make
+                continue;
+            }
             ++i;
         }
         if (PROF && n >= 256 && threadIdx.x == 64) {  // profiling only: model wave 1's phases (cycles) at u64[8..10] of the output
@@ -1016,13 +1111,17 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
     }
     u64 prof_wait = 0, prof_walk = 0, prof_slow = 0, prof_miss = 0, prof_wait_miss = 0;  // PROF
     u64 t0 = 0, t1 = 0;
-    u32 P0, P1, P2, P3, P4, P5, P6, P7a, P7b;  // this lane's slice of the table of the byte being decoded
+    struct CmTab {  // this lane's slice of a table: its node of each of the six speculated levels, of level 6, and both of level 7
+        u32 p0, p1, p2, p3, p4, p5, p6, p7a, p7b;
+    };
+    CmTab TA = {0, 0, 0, 0, 0, 0, 0, 0, 0}, TB = TA;  // the table of the byte being decoded; X & 8: even bytes use TA, odd bytes TB (one is loaded while the other is walked)
+    u32 hits_w = 0;  // right guesses in a row (X & 8; the model waves count the same)
     u32 vi = cm_opaque_zero();                 // the byte index as a vector register: the offset of the byte's store
-#define CM_SYNC_FETCH(BUF)                                                                            \
+#define CM_SYNC_FETCH(T, BUF)                                                                         \
     do {                                                                                              \
         const u32 * __restrict__ pt_ = ptab[BUF];                                                     \
-        P0 = pt_[ix0]; P1 = pt_[ix1]; P2 = pt_[ix2]; P3 = pt_[ix3]; P4 = pt_[ix4]; P5 = pt_[ix5];     \
-        P6 = pt_[ix6]; P7a = pt_[ix7]; P7b = pt_[ix7 + 1u];                                           \
+        (T).p0 = pt_[ix0]; (T).p1 = pt_[ix1]; (T).p2 = pt_[ix2]; (T).p3 = pt_[ix3]; (T).p4 = pt_[ix4]; (T).p5 = pt_[ix5]; \
+        (T).p6 = pt_[ix6]; (T).p7a = pt_[ix7]; (T).p7b = pt_[ix7 + 1u];                               \
     } while (0)
 // one speculated level of the fast walk: (range, d) along the lane's assumed bit, no comparison (see above)
 #define CM_WALK_SPEC(P, NB)                                                                           \
@@ -1041,27 +1140,53 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         range = BIT ? t_ : range + ~t_;                            /* t  |  range - t - 1 */          \
         d = BIT ? d : d + ~t_;                                                                        \
     } while (0)
-    // Decodes byte i from the table in P0..P7b; returns it.
-    auto walk = [&]() __attribute__((always_inline)) -> u32 {
+// X & 8: the table loads as inline assembly, out of the compiler's sight.  The s_waitcnt instructions of the walk are placed for whichever
+// path needs them and count outstanding accesses from the youngest down: with the loads in sight the walk's levels wait at lgkmcnt(7), (6), ..
+// for "their" load, which in the run phase -- table i+2 is loaded while byte i+1 is walked -- means for the first of the EARLY loads, i.e. for
+// exactly the latency they are issued early to hide (measured in round 4: the run phase gained nothing); and a wait requested through
+// __builtin_amdgcn_s_waitcnt is only a hint that the compiler drops.  So: CM_TAB_LOAD issues the nine loads, CM_TAB_READY waits for every
+// LDS access of the wave and ties the registers to that point (the "+v" operands: nothing that reads them can move above it).
+#ifdef BZ3_EMU
+#define CM_TAB_LOAD(T, BUF) CM_SYNC_FETCH(T, BUF)
+#define CM_TAB_READY(T) ((void)0)
+#else
+#define CM_TAB_LOAD(T, BUF)                                                                           \
+    do {                                                                                              \
+        const u32 b_ = (u32)(__UINTPTR_TYPE__)(CM_LDS u32 *)ptab[BUF];                                 \
+        asm volatile("ds_read_b32 %0, %9\n\tds_read_b32 %1, %10\n\tds_read_b32 %2, %11\n\tds_read_b32 %3, %12\n\t"              \
+                     "ds_read_b32 %4, %13\n\tds_read_b32 %5, %14\n\tds_read_b32 %6, %15\n\tds_read_b32 %7, %16\n\tds_read_b32 %8, %16 offset:4" \
+                     : "+v"((T).p0), "+v"((T).p1), "+v"((T).p2), "+v"((T).p3), "+v"((T).p4), "+v"((T).p5), "+v"((T).p6), "+v"((T).p7a), "+v"((T).p7b) \
+                     : "v"(b_ + 4u * ix0), "v"(b_ + 4u * ix1), "v"(b_ + 4u * ix2), "v"(b_ + 4u * ix3), "v"(b_ + 4u * ix4), "v"(b_ + 4u * ix5),  \
+                       "v"(b_ + 4u * ix6), "v"(b_ + 4u * ix7)                                          \
+                     : "memory");                                                                     \
+    } while (0)
+#define CM_TAB_READY(T)                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                               \
+                 : "+v"((T).p0), "+v"((T).p1), "+v"((T).p2), "+v"((T).p3), "+v"((T).p4), "+v"((T).p5), "+v"((T).p6), "+v"((T).p7a), "+v"((T).p7b) \
+                 :                                                                                    \
+                 : "memory")
+#endif
+    // Decodes byte i from the table in T; returns it.
+    auto walk = [&](const CmTab & T) __attribute__((always_inline)) -> u32 {
         u32 range = range_u, low;  // per-lane copies of the wave-uniform coder state
         u32 d = code - low_u;
         const bool inside = d <= range_u;  // low <= code <= high: always, unless a truncated stream fed -1 bytes (:345)
-        CM_WALK_SPEC(P0, nb0);  // :453-489
-        CM_WALK_SPEC(P1, nb1);
+        CM_WALK_SPEC(T.p0, nb0);  // :453-489
+        CM_WALK_SPEC(T.p1, nb1);
         const u64 ok1 = __ballot(d <= range);
-        CM_WALK_SPEC(P2, nb2);
-        CM_WALK_SPEC(P3, nb3);
+        CM_WALK_SPEC(T.p2, nb2);
+        CM_WALK_SPEC(T.p3, nb3);
         const u64 ok3 = __ballot(d <= range);
-        CM_WALK_SPEC(P4, nb4);
-        CM_WALK_SPEC(P5, nb5);
+        CM_WALK_SPEC(T.p4, nb4);
+        CM_WALK_SPEC(T.p5, nb5);
         // the lane that decoded the six bits it had assumed.  (Tested every other level: a lane on an improbable wrong path often
         // reaches range 0 within two levels and wraps at the next 0 it assumes -- with one test at the end 14 % of the bytes of
         // text had a second "survivor" -- but between two tests it has no time for both.)
         const u64 ok = ok1 & ok3 & __ballot(d <= range);
         u32 cb = 0;
         bool bit6, bit7;
-        CM_WALK_REAL(P6, bit6);
-        const u32 P7f = bit6 ? P7b : P7a;
+        CM_WALK_REAL(T.p6, bit6);
+        const u32 P7f = bit6 ? T.p7b : T.p7a;
         CM_WALK_REAL(P7f, bit7);
         const int w = __ffsll((unsigned long long)ok) - 1;
         const u32 low_f = code - cm_readlane(d, w), range_f = cm_readlane(range, w);
@@ -1077,14 +1202,14 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
             low = low_old;
             range = range_old;
             u64 valid = ~0ull;
-            CM_SPEC_LEVEL(P0, nb0, 0xFFFFFFFF00000000ull);
-            CM_SPEC_LEVEL(P1, nb1, 0xFFFF0000FFFF0000ull);
-            CM_SPEC_LEVEL(P2, nb2, 0xFF00FF00FF00FF00ull);
-            CM_SPEC_LEVEL(P3, nb3, 0xF0F0F0F0F0F0F0F0ull);
-            CM_SPEC_LEVEL(P4, nb4, 0xCCCCCCCCCCCCCCCCull);
-            CM_SPEC_LEVEL(P5, nb5, 0xAAAAAAAAAAAAAAAAull);
-            CM_REAL_LEVEL(P6, bit6);
-            const u32 P7 = bit6 ? P7b : P7a;
+            CM_SPEC_LEVEL(T.p0, nb0, 0xFFFFFFFF00000000ull);
+            CM_SPEC_LEVEL(T.p1, nb1, 0xFFFF0000FFFF0000ull);
+            CM_SPEC_LEVEL(T.p2, nb2, 0xFF00FF00FF00FF00ull);
+            CM_SPEC_LEVEL(T.p3, nb3, 0xF0F0F0F0F0F0F0F0ull);
+            CM_SPEC_LEVEL(T.p4, nb4, 0xCCCCCCCCCCCCCCCCull);
+            CM_SPEC_LEVEL(T.p5, nb5, 0xAAAAAAAAAAAAAAAAull);
+            CM_REAL_LEVEL(T.p6, bit6);
+            const u32 P7 = bit6 ? T.p7b : T.p7a;
             CM_REAL_LEVEL(P7, bit7);
             const int w2 = __ffsll((unsigned long long)valid) - 1;  // exactly one lane survives
             low_u = cm_readlane(low, w2);
@@ -1094,8 +1219,11 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         return c;
     };
     // What follows the walk of byte i (BUF = i & 1, a compile-time constant): hand the byte over, meet the model waves, fetch the next
-    // table.  Returns false when the loop ends (last byte, or the block was given up).
-    auto after = [&](const u32 i, const u32 c, auto buf_tag) __attribute__((always_inline)) -> bool {
+    // table into `next`.  Returns false when the loop ends (last byte, or the block was given up).
+    // X & 8 (see the model waves' run phase): after CM_RUN_K right guesses in a row the waves work two tables ahead, and from the second
+    // byte of the phase on table i+2 is loaded into `mine` -- the registers byte i was decoded from -- while byte i+1 is walked, so that a
+    // right guess costs the walker nothing but barrier 1; the two intervals that lead there have one more barrier ("E") behind the fetch.
+    auto after = [&](const u32 i, const u32 c, auto buf_tag, CmTab & mine, CmTab & next) __attribute__((always_inline)) -> bool {
         constexpr u32 BUF = decltype(buf_tag)::value;
         LDS_POKE(s_done[BUF], c);  // every lane stores the same word: no EXEC juggling on the critical path
         if (PROF) t1 = cm_clock();
@@ -1105,12 +1233,24 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         c1 = c;
         if (i + 1u == n) return false;
         __syncthreads();  // barrier 1: the speculative table of byte i+1 is complete, the models read byte i
+        bool fetch_next = true;
         if (!hit) {
             if (PROF) prof_miss++;
             __syncthreads();  // barrier 2: the corrected table
             if (R && LDS_PEEK(s_abort) != 0u) return false;  // given up (R > 0): the block is decoded again by the full-model kernel
+            hits_w = 0;
+        } else if (X & 8) {
+            hits_w++;
+            fetch_next = hits_w <= CM_RUN_K + 1u;  // beyond that `next` holds table i+1 already
         }
-        CM_SYNC_FETCH(BUF ^ 1u);
+        if (!(X & 8)) {
+            CM_SYNC_FETCH(next, BUF ^ 1u);
+        } else {
+            if (fetch_next) CM_TAB_LOAD(next, BUF ^ 1u);
+            CM_TAB_READY(next);  // (run phase: loaded while byte i was walked; nothing is outstanding behind barrier 1)
+            if (hit && hits_w >= CM_RUN_K && hits_w <= CM_RUN_K + 1u) __syncthreads();  // barrier E: the waves may write the buffer table i+1 was fetched from
+            if (hit && hits_w >= CM_RUN_K + 1u) CM_TAB_LOAD(mine, BUF);  // table i+2 (complete since barrier 1), while byte i+1 is walked
+        }
         if (PROF) {
             const u64 t2 = cm_clock();
             prof_walk += t1 - t0;
@@ -1120,16 +1260,22 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         return true;
     };
     __syncthreads();  // barrier 0
-    CM_SYNC_FETCH(0);
+    if (X & 8) {
+        CM_TAB_LOAD(TA, 0);
+        CM_TAB_READY(TA);
+    } else {
+        CM_SYNC_FETCH(TA, 0);
+    }
+    CmTab & TO = (X & 8) ? TB : TA;  // the table of the odd bytes
     u32 i = 0;
     for (;;) {
         if (PROF) t0 = cm_clock();
-        const u32 ca = walk();
-        if (!after(i, ca, CmConst<0>{})) break;
+        const u32 ca = walk(TA);
+        if (!after(i, ca, CmConst<0>{}, TA, TO)) break;
         i++;
         if (PROF) t0 = cm_clock();
-        const u32 cb2 = walk();
-        if (!after(i, cb2, CmConst<1>{})) break;
+        const u32 cb2 = walk(TO);
+        if (!after(i, cb2, CmConst<1>{}, TO, TA)) break;
         i++;
     }
     if (PROF && n >= 256 && lane == 0) {  // profiling only: output bytes 0..31 become counters
@@ -1143,6 +1289,8 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         reinterpret_cast<u32 *>(out)[23] = xcc_id;
     }
 #undef CM_SYNC_FETCH
+#undef CM_TAB_LOAD
+#undef CM_TAB_READY
 #undef CM_WALK_SPEC
 #undef CM_WALK_REAL
 }
@@ -1201,6 +1349,10 @@ static bool cm_launch_experiment(int x, bool prof, const CmDecodeJob * d_jobs, u
         case 7: cm_launch_x<R, true, 3>(d_jobs, njobs, s); return true;
         case 10: cm_launch_x<R, false, 5>(d_jobs, njobs, s); return true;
         case 11: cm_launch_x<R, true, 5>(d_jobs, njobs, s); return true;
+        case 18: cm_launch_x<R, false, 9>(d_jobs, njobs, s); return true;
+        case 19: cm_launch_x<R, true, 9>(d_jobs, njobs, s); return true;
+        case 26: cm_launch_x<R, false, 13>(d_jobs, njobs, s); return true;
+        case 27: cm_launch_x<R, true, 13>(d_jobs, njobs, s); return true;
         default: return false;
     }
 }

@@ -75,14 +75,17 @@ constexpr size_t LZP_LUT_WORDS = (size_t)1 << 18;
 void lzp_decode_batch(const LzpDecodeJob * h_jobs, LzpDecodeJob * d_jobs, u32 njobs, hipStream_t s);  // asynchronous
 
 // ---- BWT (bwt.hip) -- replaces libsais_bwt, include/libsais.h:4095-4121 ----------------------
-// Synchronous.  Returns the primary index (>= 1).  Rounds/active statistics are reported for profiling.
+// Returns the primary index (>= 1), synchronously -- or, with d_idx, leaves it in that device word and returns 0 without waiting for
+// the stream (one read-back per pass remains inside: which path the block's groups take is decided on the host).  Rounds/active
+// statistics are reported for profiling.
 struct BwtStats {
     int rounds = 0;
     u64 sorted_elements = 0;  // sum over rounds of elements that went through the radix sorter
     int radix_passes = 0;
 };
-s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, BwtStats * stats);
+s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, BwtStats * stats, u32 * d_idx = nullptr);
 size_t bwt_workspace_bytes(u64 n);
+void bwt_set_big_rounds(int k);  // tests only: more windows for the big groups before the deep path (k < 0: the default, 1)
 
 // ---- inverse BWT (unbwt.hip) -- replaces libsais_unbwt, include/libsais.h:5260-5262 ----------
 // Synchronous.  idx must already be validated (0 < idx <= n).

@@ -41,6 +41,9 @@ BZIP3_API int bz3_hip_set_cm_mode(int mode);
 /* Experiments (round 4): which build of the guess-ahead CM decoder the decode launches use; 0 = the shipped kernels.  Output bytes do
  * not depend on it.  tools/cm_coresidency.py --exp=N. */
 BZIP3_API void bz3_hip_debug_cm_experiment(int x);
+/* Test hook: how many more code windows the suffix sorter gives groups that are too large for its in-LDS kernels before rank doubling
+ * takes them (0 = none: straight to the deep path; k < 0 = the default, 1).  Output bytes do not depend on it. */
+BZIP3_API void bz3_hip_debug_bwt_big_rounds(int k);
 /* Number of blocks the row-cache kernels have handed back to the full-model kernels so far (statistics). */
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void);
 

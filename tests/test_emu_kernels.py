@@ -726,18 +726,20 @@ def test_suffix_sorter_paths(emu, oracle, name):
     assert g.bwt(d) == oracle.bwt(d), (name, len(d))
 
 
-def test_suffix_sorter_deep_path_for_big_groups(emu, oracle, monkeypatch):
-    """BZ3_BWT_BIG_ROUNDS=0 (tests only, read per call): groups too large for the resolve kernel go straight to rank doubling,
+def test_suffix_sorter_deep_path_for_big_groups(emu, oracle):
+    """bz3_hip_debug_bwt_big_rounds(0) (test hook): groups too large for the resolve kernel go straight to rank doubling,
     so the deep path also runs on inputs that normally finish on the big path; and a block through the whole encoder."""
     g = bzip3_amd.StageApi(emu)
-    monkeypatch.setenv("BZ3_BWT_BIG_ROUNDS", "0")
-    for name in ("phrase1", "phrase3", "text300k"):
-        d = SORTER_CASES[name][:120000]
-        assert g.bwt(d) == oracle.bwt(d), name
-    monkeypatch.setenv("BZ3_BWT_BIG_ROUNDS", "8")  # several windows for the big groups, then the deep path for what the resolve kernel handed back
-    for name in ("mixdeep", "phrase3"):
-        assert g.bwt(SORTER_CASES[name]) == oracle.bwt(SORTER_CASES[name]), name
-    monkeypatch.delenv("BZ3_BWT_BIG_ROUNDS")
+    try:
+        emu.bz3_hip_debug_bwt_big_rounds(0)
+        for name in ("phrase1", "phrase3", "text300k"):
+            d = SORTER_CASES[name][:120000]
+            assert g.bwt(d) == oracle.bwt(d), name
+        emu.bz3_hip_debug_bwt_big_rounds(8)  # several windows for the big groups, then the deep path for what the resolve kernel handed back
+        for name in ("mixdeep", "phrase3"):
+            assert g.bwt(SORTER_CASES[name]) == oracle.bwt(SORTER_CASES[name]), name
+    finally:
+        emu.bz3_hip_debug_bwt_big_rounds(-1)
     t = datagen.shakespeare()
     d = t[40000:70000] + t[40000:52000]
     assert bzip3_amd.encode_block(d, 65 * 1024, emu)[2] == oracle.encode_block(d, 65 * 1024)[2]
@@ -869,7 +871,7 @@ def test_unbwt_single_walk_with_strided_splitters(emu, oracle):
         assert g.unbwt(u, jidx) == oracle.unbwt(u, jidx), n
 
 
-@pytest.mark.parametrize("x", [1, 2, 3, 5])
+@pytest.mark.parametrize("x", [1, 5, 9, 13])
 def test_cm_decoder_experiments_match_oracle(emu, oracle, cm_mode, x):
     """Round-4 builds of the guess-ahead decoder (cm.hip cm_decode_block_sync's X: model waves that own subtrees, lanes off the guessed
     path that skip what cannot have changed): same bytes as the oracle on runs of every length around the thresholds of the skip

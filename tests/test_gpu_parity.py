@@ -280,19 +280,21 @@ def test_front_end_and_tail_rings_on_gpu(gpu_lib, oracle, text, pipe, monkeypatc
 
 def test_suffix_sorter_paths_on_gpu(gpu_lib, oracle, monkeypatch):
     """Every path of the round-3 suffix sorter (bwt.hip; cases and what they exercise: datagen.suffix_sorter_cases) against the
-    oracle's BWT, then the big groups forced down the deep path (BZ3_BWT_BIG_ROUNDS=0, tests only), then a 6 MiB text block whose
+    oracle's BWT, then the big groups forced down the deep path (bz3_hip_debug_bwt_big_rounds(0), test hook), then a 6 MiB text block whose
     anchor tiles run concurrently on all CUs (the emulator runs them one after the other)."""
     g = bzip3_amd.StageApi(gpu_lib)
     cases = datagen.suffix_sorter_cases()
     for name in sorted(cases):
         assert g.bwt(cases[name]) == oracle.bwt(cases[name]), name
-    monkeypatch.setenv("BZ3_BWT_BIG_ROUNDS", "0")
-    for name in ("phrase1", "phrase3", "text300k"):
-        assert g.bwt(cases[name]) == oracle.bwt(cases[name]), name
-    monkeypatch.setenv("BZ3_BWT_BIG_ROUNDS", "8")
-    for name in ("mixdeep", "phrase3"):
-        assert g.bwt(cases[name]) == oracle.bwt(cases[name]), name
-    monkeypatch.delenv("BZ3_BWT_BIG_ROUNDS")
+    try:
+        gpu_lib.bz3_hip_debug_bwt_big_rounds(0)
+        for name in ("phrase1", "phrase3", "text300k"):
+            assert g.bwt(cases[name]) == oracle.bwt(cases[name]), name
+        gpu_lib.bz3_hip_debug_bwt_big_rounds(8)
+        for name in ("mixdeep", "phrase3"):
+            assert g.bwt(cases[name]) == oracle.bwt(cases[name]), name
+    finally:
+        gpu_lib.bz3_hip_debug_bwt_big_rounds(-1)
     d = datagen.text(6 << 20, seed=77, chains=4096)
     assert g.bwt(d) == oracle.bwt(d)
 

@@ -1,5 +1,5 @@
 """Times the whole-GPU stages (everything except the CM coder) at full block size through the stage hooks:
-python tools/stage_probe.py <MiB>.  Host wall-clock per call, includes the H2D/D2H of the hook."""
+python tools/stage_probe.py <MiB> [--lib=<another build>] [--noise=<fraction of noise tokens, default 0>].  Host wall-clock per call, includes the H2D/D2H of the hook."""
 import os
 import sys
 import time
@@ -13,10 +13,13 @@ from bench import gen_text_device  # noqa: E402
 
 
 def main():
-    mib = float(sys.argv[1]) if len(sys.argv) > 1 else 256
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    mib = float(args[0]) if args else 256
     n = int(mib * (1 << 20))
-    d = bytes(gen_text_device(torch, n, 7, torch.device("cuda", 0)).cpu().numpy())
-    g = bzip3_amd.StageApi(bzip3_amd.load())
+    libs = [a[len("--lib="):] for a in sys.argv if a.startswith("--lib=")]
+    noise = [float(a[len("--noise="):]) for a in sys.argv if a.startswith("--noise=")]
+    d = bytes(gen_text_device(torch, n, 7, torch.device("cuda", 0), noise=noise[0] if noise else 0.0).cpu().numpy())
+    g = bzip3_amd.StageApi(bzip3_amd.load(libs[0]) if libs else bzip3_amd.load())
     for rep in range(2):
         t = time.time(); crc = g.crc32c(d); t_crc = time.time() - t
         t = time.time(); rle = g.mrle_encode(d); t_rle = time.time() - t
