@@ -1374,6 +1374,8 @@ struct Collector {
     std::condition_variable cv;
     std::vector<SingleReq *> pending[2];  // [0] encode, [1] decode
     bool leader[2] = {false, false};
+    size_t last_size[2] = {0, 0};  // callers in the previous batch: the leader stops waiting as soon as that many have arrived
+    int lonely[2] = {0, 0};        // batches of ONE caller in a row with nobody queued behind them
 };
 Collector g_collect;
 std::atomic<int> g_collect_window_us{200};
@@ -1403,10 +1405,17 @@ void run_collected(int kind, std::vector<SingleReq *> & batch) {
     }
 }
 
+// The window is there for the FIRST batch of a group of threads; after it the callers that arrive while a batch runs form the next one
+// by themselves.  So (round 4): a caller that has been alone twice in a row -- a single-threaded program -- no longer
+// waits at all (it paid the window on every call, in both directions), and a leader stops waiting as soon as as many callers as
+// the previous batch had have arrived instead of sleeping the whole window.  What remains by design: the callers of one batch share
+// its latency -- a 64 KiB block that is collected with a 511 MiB block returns when that block does (bz3_hip_set_collect_window_us(0)
+// gives every call a batch of its own).
 void collect(int kind, SingleReq & r) {
     Collector & c = g_collect;
     std::unique_lock<std::mutex> lk(c.mu);
     c.pending[kind].push_back(&r);
+    c.cv.notify_all();  // a leader inside its window counts the arrivals
     while (!r.done) {
         if (c.leader[kind]) {
             c.cv.wait(lk);
@@ -1414,7 +1423,10 @@ void collect(int kind, SingleReq & r) {
         }
         c.leader[kind] = true;
         const int win = g_collect_window_us.load();
-        if (win > 0) c.cv.wait_for(lk, std::chrono::microseconds(win), [] { return false; });  // the others arrive meanwhile (the lock is released)
+        if (win > 0 && c.lonely[kind] < 2) {
+            const size_t want = c.last_size[kind] > 1 ? c.last_size[kind] : ~(size_t)0;
+            c.cv.wait_for(lk, std::chrono::microseconds(win), [&] { return c.pending[kind].size() >= want; });  // the others arrive meanwhile (the lock is released)
+        }
         std::vector<SingleReq *> batch;
         batch.swap(c.pending[kind]);
         lk.unlock();
@@ -1425,6 +1437,8 @@ void collect(int kind, SingleReq & r) {
         }
         lk.lock();
         for (SingleReq * q : batch) q->done = true;
+        c.last_size[kind] = batch.size();
+        c.lonely[kind] = (batch.size() == 1 && c.pending[kind].empty()) ? c.lonely[kind] + 1 : 0;
         c.leader[kind] = false;
         c.cv.notify_all();
     }
@@ -1444,13 +1458,23 @@ BZIP3_API unsigned bz3_hip_debug_collected_batches(int reset, unsigned * largest
 
 BZIP3_API int32_t bz3_encode_block(struct bz3_state * st, uint8_t * buffer, int32_t size) {
     SingleReq r{st, buffer, 0, size, 0};
-    collect(0, r);
+    try {
+        collect(0, r);
+    } catch (...) {  // (queueing the request could not allocate: nothing may cross the C boundary)
+        on_failure(st);
+        return -1;
+    }
     return r.size;
 }
 
 BZIP3_API int32_t bz3_decode_block(struct bz3_state * st, uint8_t * buffer, size_t buffer_size, int32_t compressed_size, int32_t orig_size) {
     SingleReq r{st, buffer, buffer_size, compressed_size, orig_size};
-    collect(1, r);
+    try {
+        collect(1, r);
+    } catch (...) {
+        on_failure(st);
+        return -1;
+    }
     return st->result;
 }
 

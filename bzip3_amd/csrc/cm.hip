@@ -247,7 +247,7 @@ struct CmByteEvents {      // the events of one byte in registers
     uint2 k[8];
     u32 m[8];
 };
-struct CmEvent {  // what the chain loop leaves for the event loop
+struct alignas(8) CmEvent {  // what the chain loop leaves for the event loop (8-byte aligned: it is stored and loaded as ONE 64-bit LDS access)
     u32 px1;      // p | x1 << 16
     u32 x2b;      // x2 | bit << 16
 };
@@ -262,6 +262,42 @@ __device__ __forceinline__ u32 cm_upd_pair6(u32 w, u32 k2) {
     return w - sh + k2;                     // no borrow/carry crosses the halves: each half stays within [0, 65535]
 }
 
+// The two neighbouring C2 cells x1 | x2 << 16 at a u16 address.  A C2 row is 17 cells (34 bytes), so half of these pairs straddle a
+// dword boundary, and an LDS dword access off its alignment is REPLAYED by the hardware at ~64 cycles per wave instruction: round 4's
+// counters of the decoder at three blocks per CU show the LDS busy 56 % of all cycles, three quarters of that in SQ_LDS_UNALIGNED_STALL
+// (profiles/r04_pmc_decoder_lds.txt) -- every evaluation of every model wave paid it.  HALVES: two 16-bit accesses instead (each aligned).
+template <bool HALVES>
+__device__ __forceinline__ u32 cm_pair_load(const u16 * p) {
+    if (HALVES) return (u32)p[0] | ((u32)p[1] << 16);
+    return reinterpret_cast<const PackedU32 *>(p)->v;
+}
+template <bool HALVES>
+__device__ __forceinline__ void cm_pair_store(u16 * p, u32 w) {
+    if (HALVES) {
+        p[0] = (u16)w;
+        p[1] = (u16)(w >> 16);
+    } else {
+        reinterpret_cast<PackedU32 *>(p)->v = w;
+    }
+}
+#ifndef BZ3_EMU  // the same through 32-bit LDS pointers (the decoder's model waves); the emulator's LDS is ordinary memory
+template <bool HALVES>
+__device__ __forceinline__ u32 cm_pair_load(const __attribute__((address_space(3))) u16 * p) {
+    if (HALVES) return (u32)p[0] | ((u32)p[1] << 16);
+    return reinterpret_cast<const __attribute__((address_space(3))) PackedU32 *>(p)->v;
+}
+template <bool HALVES>
+__device__ __forceinline__ void cm_pair_store(__attribute__((address_space(3))) u16 * p, u32 w) {
+    if (HALVES) {
+        p[0] = (u16)w;
+        p[1] = (u16)(w >> 16);
+    } else {
+        reinterpret_cast<__attribute__((address_space(3))) PackedU32 *>(p)->v = w;
+    }
+}
+#endif
+constexpr bool CM_ENC_PAIR_HALVES = true;
+
 // One byte of the chain, for the lane of one tree level: wave-uniform (c, c1 << 8, c2 << 8, f); the level's node on the byte's path.
 template <class M>
 __device__ __forceinline__ void cm_chain_step(M & m, CmEvent * __restrict__ ev_row, u32 hibit, u32 shr, u32 bitpos, u32 c, u32 c1s, u32 c2s, u32 f) {
@@ -274,10 +310,10 @@ __device__ __forceinline__ void cm_chain_step(M & m, CmEvent * __restrict__ ev_r
     const u32 p2 = m.c1[a2];
     const u32 p = cm_mad24(p0 + p1, 7u, 2u * p2) >> 4;  // :380 (p0 + p1 < 2^17)
     const u32 ci = (2u * node + f) * CM_C2_STRIDE + (p >> 12);
-    const u32 w = load_u32_any(reinterpret_cast<const u8 *>(&m.c2[ci]));  // x1 | x2 << 16 (cells j, j+1)
+    const u32 w = cm_pair_load<CM_ENC_PAIR_HALVES>(&m.c2[ci]);  // x1 | x2 << 16 (cells j, j+1)
     m.c0[node] = (u16)cm_upd(p0, 2, mk & 16383u);   // :396-399 / :411-414
     m.c1[a1] = (u16)cm_upd(p1, 4, mk & 4095u);
-    reinterpret_cast<PackedU32 *>(&m.c2[ci])->v = cm_upd_pair6(w, mk & 0x03FF03FFu);
+    cm_pair_store<CM_ENC_PAIR_HALVES>(&m.c2[ci], cm_upd_pair6(w, mk & 0x03FF03FFu));
     CmEvent e;
     e.px1 = p | (bit << 16);
     e.x2b = w;
@@ -766,7 +802,7 @@ __device__ __forceinline__ u64 cm_clock() {
 struct CmEvalP {              // CmEval with the cells remembered by address
     CM_LDS u16 * a1;          // C1[c1][node]
     u32 p1;                   // its value
-    CM_LDS PackedU32 * ci;    // the first of the two C2 cells
+    CM_LDS u16 * ci;          // the first of the two C2 cells
     u32 w;                    // both cells, x1 | x2 << 16
 };
 
@@ -835,16 +871,16 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
             e.a1 = a1;
             e.p1 = p1;
 #ifdef BZ3_EMU
-            e.ci = (CM_LDS PackedU32 *)(c2row + cm_bfe(p16, 16, 4));  // cell p >> 12 of the row
+            e.ci = c2row + cm_bfe(p16, 16, 4);  // cell p >> 12 of the row
 #else
             {  // the same in two instructions (the compiler's own rendering of the line above takes three)
                 u32 j, a;
                 asm("v_bfe_u32 %0, %1, 16, 4" : "=v"(j) : "v"(p16));
                 asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(a) : "v"(j), "v"((u32)(__UINTPTR_TYPE__)c2row));
-                e.ci = (CM_LDS PackedU32 *)(__UINTPTR_TYPE__)a;
+                e.ci = (CM_LDS u16 *)(__UINTPTR_TYPE__)a;
             }
 #endif
-            e.w = e.ci->v;                                     // x1 | x2 << 16 (cells j, j + 1)
+            e.w = cm_pair_load<(X & 16) != 0>(e.ci);            // x1 | x2 << 16 (cells j, j + 1)
             const int p = (int)(p16 >> 4);
             const int x1 = (int)(e.w & 0xFFFFu), x2 = (int)(e.w >> 16);
             const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);
@@ -903,13 +939,13 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
             u32 cell2 = prev.p1;
             if (on_g) {
                 c0 = c0_old;
-                prev.ci->v = prev.w;
+                cm_pair_store<(X & 16) != 0>(prev.ci, prev.w);
             }
             if ((c >> shr) == nodelow) {
                 const u32 mk = 0u - ((c >> bitpos) & 1u);
                 c0 = cm_upd(c0, 2, mk & 16383u);
                 cell2 = cm_upd(prev.p1, 4, mk & 4095u);
-                prev.ci->v = cm_upd_pair6(prev.w, mk & 0x03FF03FFu);
+                cm_pair_store<(X & 16) != 0>(prev.ci, cm_upd_pair6(prev.w, mk & 0x03FF03FFu));
             }
             *prev.a1 = (u16)cell2;  // (unconditionally: storing the value that is there already costs less than finding out)
             c2row = c2row0;  // c != k1: the run counter restarts
@@ -937,7 +973,7 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
                 c0 = cm_upd(c0, 2, mk & 16383u);
                 cell = cm_upd(prev.p1, 4, mk & 4095u);
                 *prev.a1 = (u16)cell;
-                prev.ci->v = cm_upd_pair6(prev.w, mk & 0x03FF03FFu);
+                cm_pair_store<(X & 16) != 0>(prev.ci, cm_upd_pair6(prev.w, mk & 0x03FF03FFu));
             }
             // ... and the table of byte i with c1 = g, c2 = k1: both order-1 counters are `cell`, the run counter goes up
             run_prev++;
@@ -972,11 +1008,14 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
                 if (PROF) mprof_redo += cm_clock() - m2;  // up to the arrival at barrier 2
                 __syncthreads();  // barrier 2: the corrected table of byte i is there
                 run_prev = 0;
-                hits = 0;
+                if (X & 8) hits = 0;
                 return give_up ? 0 : 1;
             }
-            hits++;
-            return ((X & 8) && hits == CM_RUN_K) ? 2 : 1;
+            if (X & 8) {
+                hits++;
+                if (hits == CM_RUN_K) return 2;
+            }
+            return 1;
         };
         // ---- the run phase (X & 8): two tables ahead ------------------------------------------------------------------------------
         // After CM_RUN_K right guesses in a row the next one is right 19 times in 20 (BWT output of text), so from here the waves stay TWO
@@ -1007,7 +1046,7 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
                     c0 = cm_upd(c0, 2, mk & 16383u);
                     cell = cm_upd(r.p1, 4, mk & 4095u);
                     *r.a1 = (u16)cell;
-                    r.ci->v = cm_upd_pair6(r.w, mk & 0x03FF03FFu);
+                    cm_pair_store<(X & 16) != 0>(r.ci, cm_upd_pair6(r.w, mk & 0x03FF03FFu));
                 }
                 rl = evaluate((x & 1u) ? ptab1 : ptab0, r.a1, cell, cm_mad24(cell, 9u, cm_mad24(c0, 7u, 0u)), c2row);
             };
@@ -1025,7 +1064,7 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
                 k1 = c;
                 if (__builtin_expect(c != g, 0)) {
                     // undo the newer update (its order-0 / order-1 cells are restored with the older one's), then the usual repair
-                    if (wave_on && on_g) rb.ci->v = rb.w;
+                    if (wave_on && on_g) cm_pair_store<(X & 16) != 0>(rb.ci, rb.w);
                     const bool give_up = redo(t + 1u, c, ((t + 1u) & 1u) ? ptab1 : ptab0, ra, c0a, on_g, rl);
                     __syncthreads();  // barrier 2: the corrected table of byte t+1
                     run_prev = 0;
@@ -1042,29 +1081,38 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
             }
         };
         CmEvalP other = prev;
-        for (u32 i = 1; i < n;) {
-            int st;
-            if (i & 1u) {
-                st = step(i, CmConst<1>{}, prev, other);
-                if (st == 1) {
-                    if (++i >= n) break;
+        if (!(X & 8)) {
+            for (u32 i = 1; i < n;) {
+                if (!step(i, CmConst<1>{}, prev, other)) return;
+                if (++i >= n) break;
+                if (!step(i, CmConst<0>{}, other, prev)) return;
+                ++i;
+            }
+        } else {
+            for (u32 i = 1; i < n;) {
+                int st;
+                if (i & 1u) {
+                    st = step(i, CmConst<1>{}, prev, other);
+                    if (st == 1) {
+                        if (++i >= n) break;
+                        st = step(i, CmConst<0>{}, other, prev);
+                    } else if (st == 2) {
+                        prev = other;  // (the run phase takes the newest record in `prev`)
+                    }
+                } else {
                     st = step(i, CmConst<0>{}, other, prev);
-                } else if (st == 2) {
-                    prev = other;  // (the run phase takes the newest record in `prev`)
                 }
-            } else {
-                st = step(i, CmConst<0>{}, other, prev);
-            }
-            if (st == 0) return;
-            if ((X & 8) && st == 2) {
-                st = run_phase(i, prev);  // i = the byte whose table is the newest one = the byte the walker decodes next
                 if (st == 0) return;
-                if (st == 3) break;
-                other = prev;
-                i++;  // the next table to make
-                continue;
+                if (st == 2) {
+                    st = run_phase(i, prev);  // i = the byte whose table is the newest one = the byte the walker decodes next
+                    if (st == 0) return;
+                    if (st == 3) break;
+                    other = prev;
+                    i++;  // the next table to make
+                    continue;
+                }
+                ++i;
             }
-            ++i;
         }
         if (PROF && n >= 256 && threadIdx.x == 64) {  // profiling only: model wave 1's phases (cycles) at u64[8..10] of the output
             u64 * o = reinterpret_cast<u64 *>(out) + 8;
@@ -1343,16 +1391,18 @@ static bool cm_launch_experiment(int x, bool prof, const CmDecodeJob * d_jobs, u
     switch (x * 2 + (prof ? 1 : 0)) {
         case 2: cm_launch_x<R, false, 1>(d_jobs, njobs, s); return true;
         case 3: cm_launch_x<R, true, 1>(d_jobs, njobs, s); return true;
-        case 4: cm_launch_x<R, false, 2>(d_jobs, njobs, s); return true;
-        case 5: cm_launch_x<R, true, 2>(d_jobs, njobs, s); return true;
-        case 6: cm_launch_x<R, false, 3>(d_jobs, njobs, s); return true;
-        case 7: cm_launch_x<R, true, 3>(d_jobs, njobs, s); return true;
         case 10: cm_launch_x<R, false, 5>(d_jobs, njobs, s); return true;
         case 11: cm_launch_x<R, true, 5>(d_jobs, njobs, s); return true;
         case 18: cm_launch_x<R, false, 9>(d_jobs, njobs, s); return true;
         case 19: cm_launch_x<R, true, 9>(d_jobs, njobs, s); return true;
         case 26: cm_launch_x<R, false, 13>(d_jobs, njobs, s); return true;
         case 27: cm_launch_x<R, true, 13>(d_jobs, njobs, s); return true;
+        case 34: cm_launch_x<R, false, 17>(d_jobs, njobs, s); return true;
+        case 35: cm_launch_x<R, true, 17>(d_jobs, njobs, s); return true;
+        case 42: cm_launch_x<R, false, 21>(d_jobs, njobs, s); return true;
+        case 43: cm_launch_x<R, true, 21>(d_jobs, njobs, s); return true;
+        case 58: cm_launch_x<R, false, 29>(d_jobs, njobs, s); return true;
+        case 59: cm_launch_x<R, true, 29>(d_jobs, njobs, s); return true;
         default: return false;
     }
 }

@@ -93,15 +93,25 @@ struct Pipe {
     std::vector<std::vector<u8 *>> bufs;      // [slot][block]: host buffers of bz3_bound(block_size) bytes
     Batch batch[SLOTS];
     Lane to_reader, to_coder, to_writer;
-    bool pinned = false;                      // the buffers are page-locked (hipHostMalloc): the copies of a batch run at the link's rate
+    std::vector<std::vector<bool>> locked;    // per buffer: page-locked (hipHostMalloc) or plain malloc
+    size_t n_locked = 0;                      // statistics: buffers that ARE page-locked
 
     ~Pipe() {
         for (bz3_state * s : states) bz3_free(s);
-        for (auto & v : bufs)
-            for (u8 * p : v) {
-                if (pinned) (void)hipHostFree(p);
-                else free(p);
+        for (size_t k = 0; k < bufs.size(); k++)
+            for (size_t i = 0; i < bufs[k].size(); i++) {
+                if (locked[k][i]) (void)hipHostFree(bufs[k][i]);
+                else free(bufs[k][i]);
             }
+    }
+    // How much host memory the pipe may page-lock: BZ3_HIP_STREAM_PINNED_MIB (read once), default 4 GiB.  Page-locked buffers let a
+    // batch's copies run at the link's rate; pinning more than that of somebody else's host is not this library's call.
+    static size_t pinned_budget() {
+        static const size_t b = [] {
+            const char * e = getenv("BZ3_HIP_STREAM_PINNED_MIB");
+            return e ? (size_t)strtoull(e, nullptr, 10) << 20 : (size_t)4 << 30;
+        }();
+        return b;
     }
     bool init(s32 bs, s32 nb) {
         block_size = bs;
@@ -113,22 +123,34 @@ struct Pipe {
             states.push_back(s);
         }
         bufs.assign(SLOTS, std::vector<u8 *>());
+        locked.assign(SLOTS, std::vector<bool>());
         // Page-locked buffers (the reference's buffers are plain malloc, main.c:227-228, so the staging has to be the
-        // backend's business) while the three slots stay within 16 GiB; beyond that pageable memory: pinning tens of GB of a host
-        // is not this library's call.
-        pinned = (size_t)SLOTS * (size_t)nb * cap <= ((size_t)16 << 30);
+        // backend's business) while they fit the budget AND the host grants them: a buffer the runtime refuses to lock (memlock ulimit,
+        // container limit, fragmented host) is a plain malloc instead -- the pipe works either way, only the copies of those buffers
+        // are staged by the runtime (round 3 failed the whole stream with BZ3_ERR_INIT on the first refusal: ADVICE r03).
+        bool try_lock = true;
+        size_t locked_bytes = 0;
         for (int k = 0; k < SLOTS; k++) {
             batch[k].size.assign((size_t)nb, 0);
             batch[k].orig.assign((size_t)nb, 0);
             for (s32 i = 0; i < nb; i++) {
                 u8 * p = nullptr;
-                if (pinned) {
-                    if (hipHostMalloc((void **)&p, cap, hipHostMallocDefault) != hipSuccess) p = nullptr;
-                } else {
-                    p = (u8 *)malloc(cap);
+                bool is_locked = false;
+                if (try_lock && locked_bytes + cap <= pinned_budget()) {
+                    if (hipHostMalloc((void **)&p, cap, hipHostMallocDefault) == hipSuccess && p) {
+                        is_locked = true;
+                        locked_bytes += cap;
+                        n_locked++;
+                    } else {
+                        (void)hipGetLastError();  // (the refusal is not an error of the stream)
+                        p = nullptr;
+                        try_lock = false;  // do not ask again for every buffer
+                    }
                 }
+                if (!p) p = (u8 *)malloc(cap);
                 if (!p) return false;
                 bufs[(size_t)k].push_back(p);
+                locked[(size_t)k].push_back(is_locked);
             }
             to_reader.put(k);
         }

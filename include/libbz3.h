@@ -16,14 +16,24 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* Symbol visibility / import-export control, the same switches as the reference's header (ref: include/libbz3.h:27-41): a caller that
+ * defines BZIP3_DLL_IMPORT=1 (or a build that defines BZIP3_DLL_EXPORT=1, BZIP3_VISIBLE) keeps compiling against this header.
+ * (The header is written for this implementation rather than copied: the rules of this repository keep reference sources out of
+ * it; tests/test_abi.py checks the 14 prototypes against the reference's header whenever /root/reference is present.) */
 #ifndef BZIP3_VISIBLE
-#  if defined(__GNUC__) && (__GNUC__ >= 4)
+#  if defined(__GNUC__) && (__GNUC__ >= 4) && !defined(__MINGW32__)
 #    define BZIP3_VISIBLE __attribute__((visibility("default")))
 #  else
 #    define BZIP3_VISIBLE
 #  endif
 #endif
-#define BZIP3_API BZIP3_VISIBLE
+#if defined(BZIP3_DLL_EXPORT) && (BZIP3_DLL_EXPORT == 1)
+#  define BZIP3_API __declspec(dllexport) BZIP3_VISIBLE
+#elif defined(BZIP3_DLL_IMPORT) && (BZIP3_DLL_IMPORT == 1)
+#  define BZIP3_API __declspec(dllimport) BZIP3_VISIBLE
+#else
+#  define BZIP3_API BZIP3_VISIBLE
+#endif
 
 #ifdef __cplusplus
 extern "C" {

@@ -89,3 +89,35 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 s = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in s and "oracle_lib" not in s and "libbz3ref" not in s and "libbz3_emu" not in s, f
+
+
+def test_prototypes_equal_the_reference_header_when_it_is_here():
+    """include/libbz3.h is written for this implementation (reference sources stay out of the repository), so its 14 prototypes are
+    compared with the reference's own header token for token wherever the reference tree exists (the build container; not the GPU box)."""
+    import re
+
+    ref_path = "/root/reference/include/libbz3.h"
+    if not os.path.exists(ref_path):
+        pytest.skip("the reference tree is not on this machine")
+
+    def protos(path):
+        text = re.sub(r"/\*.*?\*/", " ", open(path).read(), flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        out = {}
+        for m in re.finditer(r"BZIP3_API\s+([^;{]+);", text):
+            decl = re.sub(r"\s+", " ", m.group(1)).strip()
+            decl = re.sub(r"\s*([(),*])\s*", r"\1", decl)
+            name = re.search(r"(bz3_\w+)\(", decl).group(1)
+            out[name] = decl
+        return out
+
+    ours, theirs = protos(os.path.join(ROOT, "include", "libbz3.h")), protos(ref_path)
+    assert sorted(ours) == sorted(theirs) and len(theirs) == 14
+    for name in theirs:
+        a = re.sub(r"\b\w+(?=[,)])", "", ours[name])    # parameter names may differ, types and order may not
+        b = re.sub(r"\b\w+(?=[,)])", "", theirs[name])
+        assert a == b, (name, ours[name], theirs[name])
+    for macro in ("BZ3_OK", "BZ3_ERR_OUT_OF_BOUNDS", "BZ3_ERR_BWT", "BZ3_ERR_CRC", "BZ3_ERR_MALFORMED_HEADER", "BZ3_ERR_TRUNCATED_DATA", "BZ3_ERR_DATA_TOO_BIG",
+                  "BZ3_ERR_INIT", "BZ3_ERR_DATA_SIZE_TOO_SMALL"):
+        val = lambda p: re.search(r"#define\s+%s\s+(-?\d+)" % macro, open(p).read()).group(1)
+        assert val(os.path.join(ROOT, "include", "libbz3.h")) == val(ref_path), macro

@@ -871,7 +871,7 @@ def test_unbwt_single_walk_with_strided_splitters(emu, oracle):
         assert g.unbwt(u, jidx) == oracle.unbwt(u, jidx), n
 
 
-@pytest.mark.parametrize("x", [1, 5, 9, 13])
+@pytest.mark.parametrize("x", [1, 5, 13, 21, 29])
 def test_cm_decoder_experiments_match_oracle(emu, oracle, cm_mode, x):
     """Round-4 builds of the guess-ahead decoder (cm.hip cm_decode_block_sync's X: model waves that own subtrees, lanes off the guessed
     path that skip what cannot have changed): same bytes as the oracle on runs of every length around the thresholds of the skip
