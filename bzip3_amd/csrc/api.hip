@@ -270,8 +270,8 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
         for (size_t i = 0; i < jobs.size(); i++) {
             jobs[i].spill = dev_addr(spill + i * CM_SPILL_BYTES);
             jobs[i].status = dev_addr(d_status + i);
-            jobs[i].miss_base = cm_variant_is_test(variant) ? 64u : 256u;
-            jobs[i].miss_shift = cm_variant_is_test(variant) ? 3u : 8u;  // give up beyond 0.4 % misses (test variants: 12.5 %)
+            jobs[i].miss_base = cm_variant_is_test(variant) ? 64u : CM_MISS_BASE;
+            jobs[i].miss_shift = cm_variant_is_test(variant) ? 3u : CM_MISS_SHIFT;  // give up beyond 3 % misses (test variants: 12.5 %)
         }
     }
     float ms = 0.f, ms2 = 0.f;
@@ -1890,8 +1890,8 @@ void stage_cm_job(StageEnv & e, Job job, Launch && go) {
         status = (u32 *)e.dev(64);
         HIP_CHECK(hipMemsetAsync(status, 0, 64, e.s));  // on the launching stream: a non-blocking stream does not order with the null stream
         job.status = dev_addr(status);
-        job.miss_base = cm_variant_is_test(variant) ? 64u : 256u;
-        job.miss_shift = cm_variant_is_test(variant) ? 3u : 8u;
+        job.miss_base = cm_variant_is_test(variant) ? 64u : CM_MISS_BASE;
+        job.miss_shift = cm_variant_is_test(variant) ? 3u : CM_MISS_SHIFT;
     }
     Job * d_job = (Job *)e.dev(sizeof job, &job, sizeof job);
     go(d_job, 1u, e.s, variant);
@@ -1974,8 +1974,8 @@ BZIP3_API float bz3_hip_stage_cm_decode_many(const uint8_t * in, int32_t in_size
             if (spill) {
                 j.spill = dev_addr(spill + CM_SPILL_BYTES * (size_t)k);
                 j.status = dev_addr(status + k);
-                j.miss_base = 256u;
-                j.miss_shift = 8u;
+                j.miss_base = CM_MISS_BASE;
+                j.miss_shift = CM_MISS_SHIFT;
             }
             jobs.push_back(j);
         }
@@ -2028,8 +2028,8 @@ BZIP3_API float bz3_hip_stage_cm_encode_many(const uint8_t * in, int32_t n, uint
             if (spill) {
                 j.spill = dev_addr(spill + CM_SPILL_BYTES * (size_t)k);
                 j.status = dev_addr(status + k);
-                j.miss_base = 256u;
-                j.miss_shift = 8u;
+                j.miss_base = CM_MISS_BASE;
+                j.miss_shift = CM_MISS_SHIFT;
             }
             jobs.push_back(j);
         }

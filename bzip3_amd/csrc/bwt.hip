@@ -1485,8 +1485,22 @@ static BwtSwitches & bwt_switches() {
     return sw;
 }
 void bwt_set_big_rounds(int k) { bwt_switches().big_rounds.store(k < 0 ? 1 : k); }  // tests: bz3_hip_debug_bwt_big_rounds
-constexpr u32 WIDE_GRID = 2048;    // workgroups of the wide kernel (four descriptors each per trip)
-constexpr u32 TAIL_GRID = 24576;   // waves of the tail kernel (96 per CU: its ~50 registers and 2 KB of LDS let dozens share a CU)
+// Grids of the wide / tail kernels: fixed by the block's size (their work lists' lengths stay on the device), a quarter of what the
+// longest possible list would take so that a wave walks at most four strides -- call 3 measured a grid of 24,576 waves, dozens of strides
+// per wave, 13 % slower than the exactly sized launch of rounds 1-3.  BZ3_BWT_GRIDS="wide,tail" (read once) overrides: experiments.
+struct BwtGrids {
+    u32 wide, tail;
+};
+static BwtGrids bwt_grids(u32 n) {
+    static const BwtGrids forced = [] {
+        BwtGrids g{0, 0};
+        if (const char * e = getenv("BZ3_BWT_GRIDS")) (void)sscanf(e, "%u,%u", &g.wide, &g.tail);
+        return g;
+    }();
+    if (forced.wide && forced.tail) return forced;
+    const u32 tail = n / (64u * 4u), wide = n / (64u * 4u * 16u);  // (lists: <= n entries, 64 per wave; <= n / 64 descriptors, 4 per workgroup)
+    return BwtGrids{wide < 8u ? 8u : wide, tail < 32u ? 32u : tail};
+}
 
 __global__ void k_bwt_set_word(u32 * p, u32 v) { *p = v; }
 
@@ -1573,14 +1587,15 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     u32 g = 7;            // symbols every group is known to share at least (7 per 56-bit window)
     bool deep = false;    // fall back to rank doubling
     u32 h_words[16];
+    const BwtGrids grids = bwt_grids(n);
     for (int pass = 0;; pass++) {
         launch(k_bwt_route, dim3((tiles + RT_WAVES - 1) / RT_WAVES), dim3(RT_WAVES * WAVE), 0, s, n, (const u32 *)V, (const u8 *)pb, (const u32 *)hbits,
                (const u32 *)carry, (const u32 *)group_carry, (const u8 *)(pass ? dirty : nullptr), big_slot, big_hp, big_cap, mid_slot, mid_size, mid_cap, tail_v, tail_slot,
                tail_d, tail_pb, tail_cap, d_words);
         // the wide and the tail kernel take their work lists' lengths from the counters on the device: fixed grids, ONE read-back per pass
-        launch(k_bwt_wide, dim3(WIDE_GRID), dim3(WR_WAVES * WAVE), 0, s, d_in, n, V, pb, (const u32 *)d_vlc, (const u32 *)mid_slot, (const u16 *)mid_size, mid_cap, tail_v,
+        launch(k_bwt_wide, dim3(grids.wide), dim3(WR_WAVES * WAVE), 0, s, d_in, n, V, pb, (const u32 *)d_vlc, (const u32 *)mid_slot, (const u16 *)mid_size, mid_cap, tail_v,
                tail_slot, tail_d, tail_pb, tail_cap, d_words, (u32)pass + 1u);
-        launch(k_bwt_tail, dim3(TAIL_GRID), dim3(WAVE), 0, s, d_in, n, V, pb, (const u32 *)d_vlc, (const u32 *)tail_v, (const u32 *)tail_slot, (const u16 *)tail_d,
+        launch(k_bwt_tail, dim3(grids.tail), dim3(WAVE), 0, s, d_in, n, V, pb, (const u32 *)d_vlc, (const u32 *)tail_v, (const u32 *)tail_slot, (const u16 *)tail_d,
                (const u8 *)tail_pb, d_words, (u32)pass + 1u);
         HIP_CHECK(hipMemcpyAsync(h_words, d_words, sizeof h_words, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));

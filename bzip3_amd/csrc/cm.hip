@@ -296,7 +296,7 @@ __device__ __forceinline__ void cm_pair_store(__attribute__((address_space(3))) 
     }
 }
 #endif
-constexpr bool CM_ENC_PAIR_HALVES = true;
+constexpr bool CM_ENC_PAIR_HALVES = false;  // (measured in round 4: the encoder gains nothing from the halves -- its eight chain lanes pay two instructions more per bit instead)
 
 // One byte of the chain, for the lane of one tree level: wave-uniform (c, c1 << 8, c2 << 8, f); the level's node on the byte's path.
 template <class M>
@@ -814,7 +814,7 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
     const u32 in_size = jobs[blockIdx.x].in_size;
     u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
     const u32 n = jobs[blockIdx.x].n;
-    __shared__ u32 ptab[2][256];  // (18-bit probability of node) << 14
+    __shared__ __attribute__((aligned(16))) u32 ptab[2][256];  // (18-bit probability of node) << 14 (aligned: the walker reads the two level-7 entries of a lane as one 64-bit access)
     __shared__ u32 s_done[2];     // [i & 1] = byte i, written by the walker before barrier 1 of byte i.  Two words: after a right guess the
                                   // walker decodes byte i+1 and stores it while a model wave that was held up may not have read byte i yet
     __shared__ u32 s_abort;       // R > 0: the model waves gave the block up

@@ -130,6 +130,12 @@ enum { CM_VARIANT_FULL = 0, CM_VARIANT_ROWS = 1, CM_VARIANT_ROWS3 = 2, CM_VARIAN
 inline bool cm_variant_has_rows(int v) { return v != CM_VARIANT_FULL; }
 inline bool cm_variant_is_test(int v) { return v == CM_VARIANT_ROWS_TEST; }
 constexpr size_t CM_SPILL_BYTES = 256 * 256 * 2;
+// When the row-cache kernels give a block up: row misses > CM_MISS_BASE + (position >> CM_MISS_SHIFT), i.e. beyond ~3 % of the bytes.
+// A miss moves two 512-byte rows between LDS and HBM, ~2 us during which the block's coder waits: 3 % of misses cost ~60 ns per byte
+// (+10 %), whereas a block that is given up is coded again by the whole-model kernel, one block per CU.  Rounds 1-3 gave up beyond
+// 0.4 %, which text with digits and markup reaches (the enwik8-calibrated generator: 0.33 % at 44 rows, tools/cm_row_cache_sim.py) --
+// round 4 found every block of such a batch coded twice.  Binary data misses on most bytes and is still given up within its first KiB.
+constexpr u32 CM_MISS_BASE = 1024, CM_MISS_SHIFT = 5;
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL);
 void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL, bool prof = false);  // prof: the sync decoders' cycle-counter build
 void cm_set_experiment(int x);  // round-4 decoder experiments (cm.hip cm_decode_block_sync's X); 0 = the shipped kernels
