@@ -1657,8 +1657,6 @@ BZIP3_API int bz3_hip_set_cm_mode(int mode) {
 
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void) { return g_cm_given_up.load(); }
 
-BZIP3_API void bz3_hip_debug_cm_experiment(int x) { cm_set_experiment(x); }
-
 BZIP3_API void bz3_hip_debug_bwt_big_rounds(int k) { bwt_set_big_rounds(k); }
 
 BZIP3_API int bz3_hip_cm_variant_for(int device, int blocks, int encode) {

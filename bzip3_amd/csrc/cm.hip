@@ -28,7 +28,6 @@
 namespace bz3 {
 
 constexpr int CM_C2_STRIDE = 17;
-constexpr unsigned CM_RUN_K = 4;  // right guesses in a row after which the guess-ahead decoder works two tables ahead (cm_decode_block_sync, X & 8)
 
 // R = 0: the whole order-1 table (256 rows) in LDS, one block per CU.  R > 0: only R rows of the order-1 table are
 // resident ("row cache", see below), so that two workgroups share a CU's LDS.
@@ -297,6 +296,7 @@ __device__ __forceinline__ void cm_pair_store(__attribute__((address_space(3))) 
 }
 #endif
 constexpr bool CM_ENC_PAIR_HALVES = false;  // (measured in round 4: the encoder gains nothing from the halves -- its eight chain lanes pay two instructions more per bit instead)
+constexpr bool CM_DEC_PAIR_HALVES = true;   // the decoder's model waves: 767.7 -> 618.3 ns per byte and block at three blocks per CU together with the subtree form (profiles/r04_cm_decoder_experiments.txt)
 
 // One byte of the chain, for the lane of one tree level: wave-uniform (c, c1 << 8, c2 << 8, f); the level's node on the byte's path.
 template <class M>
@@ -806,9 +806,7 @@ struct CmEvalP {              // CmEval with the cells remembered by address
     u32 w;                    // both cells, x1 | x2 << 16
 };
 
-// X: experiment bits (round 4).  1 = the model waves own SUBTREES instead of consecutive nodes (see "node of a lane" below);
-//    2 = lanes whose node is not on the guessed byte's path skip what cannot have changed (see "what a right guess leaves to do").
-template <int R, bool PROF, int X>  // PROF: cycle counters instead of the first output bytes (profiling only, BZ3_CM_DEBUG=3)
+template <int R, bool PROF>  // PROF: cycle counters instead of the first output bytes (profiling only, BZ3_CM_DEBUG=3)
 __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restrict__ jobs, CmLdsT<R> & m) {
     const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 in_size = jobs[blockIdx.x].in_size;
@@ -839,16 +837,17 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         // hide.  Hence: LDS cells are remembered as address-space-3 POINTERS (the address that read a cell also writes it back: no index
         // arithmetic), the two C2 rows of the node (run flag 0 / 1) are pointers that only change when the flag does, both order-1
         // counters of the speculative table are the same cell (7 c0 + 9 cell), and two bytes are unrolled per loop trip.
-        // Node of a lane.  Plain form: node = lane number among the 256 model lanes (breadth-first order; lane 0 owns no node).
-        // Subtree form (X & 1): model wave w owns the 63 nodes below the level-2 node 4 + w, i.e. levels 2..7 of every byte whose
-        // two top bits are w, and one spare lane each takes the root, the two level-1 nodes and nothing.  A byte's path then lies
-        // in ONE wave plus the spare lanes: with the root and node 2 (top bit 0) in wave 1 -- its leaf for 0x7E / 0x7F moves to
-        // wave 3's spare lane to make room -- the bytes 0x40 .. 0x7D (the letters of text) touch wave 1 only.
+        // Node of a lane (round 4): model wave w owns the 63 nodes BELOW the level-2 node 4 + w, i.e. levels 2..7 of every byte whose two
+        // top bits are w, and one spare lane of each wave takes the root, the two level-1 nodes and nothing.  A byte's path then lies in
+        // ONE wave plus the spare lanes, and the waves without a node on it fall through the update and undo blocks -- with one node per
+        // lane in breadth-first order (rounds 2-3) every byte's path crossed three of the four waves.  With the root and node 2 (top bit
+        // 0) in wave 1 -- its leaf for 0x7E / 0x7F moves to wave 3's spare lane to make room -- the bytes 0x40 .. 0x7D, the letters of
+        // text, touch wave 1 only.  Measured at three blocks per CU: 731.3 -> 678.5 ns per byte and block (profiles/r04_cm_decoder_experiments.txt).
         u32 node = threadIdx.x - 64u;
-        if (X & 1) {
+        {
             const u32 w = node >> 6, l = node & 63u;
             if (l == 0u) {
-                node = w == 0u ? 0u : (w == 1u ? 1u : (w == 2u ? 3u : 191u));
+                node = w == 0u ? 0u : (w == 1u ? 1u : (w == 2u ? 3u : 191u));  // (node 0: the lane owns none, nodelow = 1 > byte >> 8)
             } else {
                 const u32 d = (u32)(31 - __clz((int)l));
                 node = ((4u + w) << d) | (l - (1u << d));
@@ -857,7 +856,7 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         }
         const u32 lvl = node ? (u32)(31 - __clz((int)node)) : 0u;
         const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
-        const u32 nodelow = node ^ hibit;  // the bits of a byte that lead to this node, i.e. byte >> shr (lane 0 of wave 1 owns no node: nodelow = 1 > byte >> 8)
+        const u32 nodelow = node ^ hibit;  // the bits of a byte that lead to this node, i.e. byte >> shr (the lane without a node: nodelow = 1 > byte >> 8)
         u32 c0 = 32768u;  // the node's C0 counter lives in a register
         CM_LDS u16 * const c1col = (CM_LDS u16 *)&m.c1[node];                                // C1[slot 0][node]; slot s is 512 bytes further
         CM_LDS u16 * const c2row0 = (CM_LDS u16 *)&m.c2[(2u * node) * CM_C2_STRIDE];         // run flag 0
@@ -865,7 +864,6 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         CM_LDS u32 * const ptab0 = (CM_LDS u32 *)&ptab[0][node];
         CM_LDS u32 * const ptab1 = (CM_LDS u32 *)&ptab[1][node];
         // Probability of the node (:377-388) into *pt, given 16 p = (c0 + p1) * 7 + 2 * p2 and the node's C2 row for the run flag.
-        u32 lastval = 0;  // what this lane wrote into the table last (X & 2)
         auto evaluate = [&](CM_LDS u32 * pt, CM_LDS u16 * a1, u32 p1, u32 p16, CM_LDS u16 * c2row) __attribute__((always_inline)) -> CmEvalP {
             CmEvalP e;
             e.a1 = a1;
@@ -880,12 +878,11 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
                 e.ci = (CM_LDS u16 *)(__UINTPTR_TYPE__)a;
             }
 #endif
-            e.w = cm_pair_load<(X & 16) != 0>(e.ci);            // x1 | x2 << 16 (cells j, j + 1)
+            e.w = cm_pair_load<CM_DEC_PAIR_HALVES>(e.ci);       // x1 | x2 << 16 (cells j, j + 1)
             const int p = (int)(p16 >> 4);
             const int x1 = (int)(e.w & 0xFFFFu), x2 = (int)(e.w >> 16);
             const int ssep = x1 + (((x2 - x1) * (p & 4095)) >> 12);
-            lastval = cm_mad24((u32)ssep, 3u, (u32)p) << 14;   // (ssep < 2^16)
-            *pt = lastval;
+            *pt = cm_mad24((u32)ssep, 3u, (u32)p) << 14;       // (ssep < 2^16)
             return e;
         };
         // byte 0: nothing to guess (c1 = c2 = 0, run = 1, :367-372)
@@ -907,57 +904,7 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         // One byte: `prev` = what the evaluation of byte i-1 left, `cur` receives that of byte i.  Two bytes per loop trip with the two
         // records swapping roles, so that neither they nor the table buffer / the s_done word of a byte cost a move or an address
         // computation (BUF = i & 1 is a compile-time constant).  Returns false when the block was given up.
-        // The repair after a wrong guess (byte i-1 = c, not g): put the old counters back (the old values are still in `prev`, the record of
-        // the table byte i-1 was decoded with), apply the real update and evaluate table i again, into *pt.  The new c1 row differs from the
-        // row being repaired, so its read goes first.  Returns true when the block was given up (R > 0).
-        // (Issue priority for these waves during the repair -- the walker waits for it -- was measured in round 3: 804 -> 800 ns per
-        // byte at three per CU, nothing.)
-        auto redo = [&](const u32 i, const u32 c, CM_LDS u32 * pt, const CmEvalP & prev, const u32 c0_old, const bool on_g, CmEvalP & cur) __attribute__((always_inline)) -> bool {
-            bool give_up = false;
-            u32 row = c;
-            if (R) {
-                row = (cm_readlane(rowreg, (int)(c >> 2)) >> (8u * (c & 3u))) & 0xFFu;
-                if (__builtin_expect(row >= CM_ROW_SPILLED, 0)) {
-                    // the only row still needed is the one of byte i-2 (prev.a1 points into it): pin it
-                    rs.tick++;
-                    if (lane == 0) rc.stamp[cm_uniform((u32)(prev.a1 - c1col) >> 8)] = rs.tick;
-                    wave_sync();
-                    row = cm_rows_fetch<R, 1>(m, rc, rs, spill, c, row, node);
-                    rowreg = reinterpret_cast<const u32 *>(rc.row_of)[lane];
-                    if (__builtin_expect(rs.misses > miss_base + (i >> miss_shift), 0)) {
-                        // the working set does not fit (every model wave gets here at the same byte): the block is given up.  The repair
-                        // below still runs -- no second way out of this branch, the compiler pays for one with moves on every path --
-                        // and the walker reads s_abort behind barrier 2
-                        give_up = true;
-                        if (threadIdx.x == 64) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
-                        LDS_POKE(s_abort, 1u);
-                    }
-                }
-            }
-            CM_LDS u16 * const a1 = c1col + row * 256u;
-            const u32 p1 = *a1;
-            u32 cell2 = prev.p1;
-            if (on_g) {
-                c0 = c0_old;
-                cm_pair_store<(X & 16) != 0>(prev.ci, prev.w);
-            }
-            if ((c >> shr) == nodelow) {
-                const u32 mk = 0u - ((c >> bitpos) & 1u);
-                c0 = cm_upd(c0, 2, mk & 16383u);
-                cell2 = cm_upd(prev.p1, 4, mk & 4095u);
-                cm_pair_store<(X & 16) != 0>(prev.ci, cm_upd_pair6(prev.w, mk & 0x03FF03FFu));
-            }
-            *prev.a1 = (u16)cell2;  // (unconditionally: storing the value that is there already costs less than finding out)
-            c2row = c2row0;  // c != k1: the run counter restarts
-            cur = evaluate(pt, a1, p1, cm_mad24(c0 + p1, 7u, 2u * cell2), c2row0);
-            if (R) wave_sync();  // (test emulation: a row fetch de-synchronises the fibers of a wave; no instruction on the GPU)
-            return give_up;
-        };
-        u32 hits = 0;  // right guesses in a row (X & 8; the walker counts the same)
-        // One byte: `prev` = what the evaluation of byte i-1 left, `cur` receives that of byte i.  Two bytes per loop trip with the two
-        // records swapping roles, so that neither they nor the table buffer / the s_done word of a byte cost a move or an address
-        // computation (BUF = i & 1 is a compile-time constant).  Returns 0 when the block was given up, 2 when the run phase starts (X & 8), else 1.
-        auto step = [&](const u32 i, auto buf_tag, const CmEvalP & prev, CmEvalP & cur) __attribute__((always_inline)) -> int {
+        auto step = [&](const u32 i, auto buf_tag, const CmEvalP & prev, CmEvalP & cur) __attribute__((always_inline)) -> bool {
             constexpr u32 BUF = decltype(buf_tag)::value;
             CM_LDS u32 * const pt = BUF ? ptab1 : ptab0;
             bool give_up = false;
@@ -973,27 +920,12 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
                 c0 = cm_upd(c0, 2, mk & 16383u);
                 cell = cm_upd(prev.p1, 4, mk & 4095u);
                 *prev.a1 = (u16)cell;
-                cm_pair_store<(X & 16) != 0>(prev.ci, cm_upd_pair6(prev.w, mk & 0x03FF03FFu));
+                cm_pair_store<CM_DEC_PAIR_HALVES>(prev.ci, cm_upd_pair6(prev.w, mk & 0x03FF03FFu));
             }
             // ... and the table of byte i with c1 = g, c2 = k1: both order-1 counters are `cell`, the run counter goes up
             run_prev++;
             if (__builtin_expect(run_prev == 3u, 0)) c2row = c2row1;
-            // What a right guess leaves to do (X & 2).  The table of byte i is made with c1 = c2 = g and the run flag of run_prev.  A node
-            // that is NOT on g's path has seen no update since the last table, so once the context stands still its entry is the one
-            // it wrote before: run_prev = 1 (new c1 row) and 3 (the flag turns) evaluate everywhere; 2 and 4 repeat the previous step's
-            // value into this step's buffer; from 5 on the buffer already holds it (it was written two steps ago with the same
-            // context).  Whole waves without a node on the path then fall through the evaluation (cf. the subtree form above).
-            // (X & 4: the same decision per WAVE -- a wave that holds a node of the path evaluates all its lanes, so that the wave the
-            // others wait for runs one arm only.)
-            bool full = true;
-            if (X & 4) full = __ballot(on_g) != 0ull || run_prev == 1u || run_prev == 3u;
-            else if (X & 2) full = on_g || run_prev == 1u || run_prev == 3u;
-            if (full) {
-                cur = evaluate(pt, prev.a1, cell, cm_mad24(cell, 9u, cm_mad24(c0, 7u, 0u)), c2row);
-            } else {
-                cur = prev;
-                if (run_prev < 5u) *pt = lastval;
-            }
+            cur = evaluate(pt, prev.a1, cell, cm_mad24(cell, 9u, cm_mad24(c0, 7u, 0u)), c2row);
             if (PROF) m1 = cm_clock();
             __syncthreads();  // barrier 1: the walker has decoded byte i-1
             const u32 c = cm_uniform(LDS_PEEK(s_done[BUF ^ 1u]));
@@ -1004,115 +936,59 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
             }
             k1 = c;
             if (c != g) {
-                give_up = redo(i, c, pt, prev, c0_old, on_g, cur);
+                // wrong guess: put the old counters back (the old values are still in `prev`), apply the real update
+                // and evaluate again.  The new c1 row differs from the row being repaired, so its read goes first.
+                // (Issue priority for these waves during the repair -- the walker waits for it -- was measured in round 3: 804 -> 800 ns per
+                // byte at three per CU, nothing.)
+                u32 row = c;
+                if (R) {
+                    row = (cm_readlane(rowreg, (int)(c >> 2)) >> (8u * (c & 3u))) & 0xFFu;
+                    if (__builtin_expect(row >= CM_ROW_SPILLED, 0)) {
+                        // the only row still needed is the one of byte i-2 (prev.a1 points into it): pin it
+                        rs.tick++;
+                        if (lane == 0) rc.stamp[cm_uniform((u32)(prev.a1 - c1col) >> 8)] = rs.tick;
+                        wave_sync();
+                        row = cm_rows_fetch<R, 1>(m, rc, rs, spill, c, row, node);
+                        rowreg = reinterpret_cast<const u32 *>(rc.row_of)[lane];
+                        if (__builtin_expect(rs.misses > miss_base + (i >> miss_shift), 0)) {
+                            // the working set does not fit (every model wave gets here at the same byte): the block is given up.  The repair
+                            // below still runs -- no second way out of this branch, the compiler pays for one with moves on every path --
+                            // and the walker reads s_abort behind barrier 2
+                            give_up = true;
+                            if (threadIdx.x == 64) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
+                            LDS_POKE(s_abort, 1u);
+                        }
+                    }
+                }
+                CM_LDS u16 * const a1 = c1col + row * 256u;
+                const u32 p1 = *a1;
+                u32 cell2 = prev.p1;
+                if (on_g) {
+                    c0 = c0_old;
+                    cm_pair_store<CM_DEC_PAIR_HALVES>(prev.ci, prev.w);
+                }
+                if ((c >> shr) == nodelow) {
+                    const u32 mk = 0u - ((c >> bitpos) & 1u);
+                    c0 = cm_upd(c0, 2, mk & 16383u);
+                    cell2 = cm_upd(prev.p1, 4, mk & 4095u);
+                    cm_pair_store<CM_DEC_PAIR_HALVES>(prev.ci, cm_upd_pair6(prev.w, mk & 0x03FF03FFu));
+                }
+                *prev.a1 = (u16)cell2;  // (unconditionally: storing the value that is there already costs less than finding out)
+                c2row = c2row0;  // c != k1: the run counter restarts
+                cur = evaluate(pt, a1, p1, cm_mad24(c0 + p1, 7u, 2u * cell2), c2row0);
+                if (R) wave_sync();  // (test emulation: a row fetch de-synchronises the fibers of a wave; no instruction on the GPU)
                 if (PROF) mprof_redo += cm_clock() - m2;  // up to the arrival at barrier 2
                 __syncthreads();  // barrier 2: the corrected table of byte i is there
                 run_prev = 0;
-                if (X & 8) hits = 0;
-                return give_up ? 0 : 1;
             }
-            if (X & 8) {
-                hits++;
-                if (hits == CM_RUN_K) return 2;
-            }
-            return 1;
-        };
-        // ---- the run phase (X & 8): two tables ahead ------------------------------------------------------------------------------
-        // After CM_RUN_K right guesses in a row the next one is right 19 times in 20 (BWT output of text), so from here the waves stay TWO
-        // tables ahead of the walker: while it decodes byte t they make table t+2 on the guess that bytes t and t+1 repeat as well.  Table
-        // t+1 is then complete one barrier EARLIER than the walker needs it, and the walker loads it while it still walks byte t: on a
-        // right guess it goes from one byte to the next without waiting for anything (round 3: a third of a right guess's time was the
-        // walker's own table fetch behind the barrier).  A wrong guess undoes two updates instead of one and the phase ends.
-        // Buffers: table x lives in buffer x & 1 as always.  In the steady state the walker holds table t in registers while the waves
-        // write table t+2 over it; the two intervals that lead there -- in which the walker still fetches a table from the buffer the
-        // waves are about to write -- have one more barrier each ("E": the walker passes it after its fetch, the waves before their write).
-        // `t` = the byte the walker decodes next, rl = the record of table t (the newest one).  Returns 0 = given up, 1 = a wrong guess
-        // ended the phase (t is the next byte again, rl the record of its corrected table), 3 = the block ends.
-        auto run_phase = [&](u32 & t, CmEvalP & rl) __attribute__((always_inline)) -> int {
-            static_assert(CM_RUN_K >= 4, "tables t and t+2 must share their context (c1 = c2, run flag set) from the first interval of the phase on");
-            const u32 g = k1;
-            const bool on_g = (g >> shr) == nodelow;
-            const bool wave_on = !(X & 4) || __ballot(on_g) != 0ull;  // (X & 4) waves without a node on the path only keep the protocol: their tables stand still
-            const u32 mk = 0u - ((g >> bitpos) & 1u);
-            CmEvalP ra = rl, rb = rl;  // the records of the two updates in flight (a = the older one)
-            u32 c0a = c0, c0b = c0;    // this lane's order-0 counter before them
-            // one more speculative update (of the byte whose table `r` describes) and the table that follows, into buffer x & 1
-            auto spec = [&](CmEvalP & r, u32 & c0_save, const u32 x) __attribute__((always_inline)) {
-                if (!wave_on) return;
-                r = rl;
-                c0_save = c0;
-                u32 cell = r.p1;
-                if (on_g) {
-                    c0 = cm_upd(c0, 2, mk & 16383u);
-                    cell = cm_upd(r.p1, 4, mk & 4095u);
-                    *r.a1 = (u16)cell;
-                    cm_pair_store<(X & 16) != 0>(r.ci, cm_upd_pair6(r.w, mk & 0x03FF03FFu));
-                }
-                rl = evaluate((x & 1u) ? ptab1 : ptab0, r.a1, cell, cm_mad24(cell, 9u, cm_mad24(c0, 7u, 0u)), c2row);
-            };
-            spec(ra, c0a, t + 1u);  // catch up: table t+1
-            u32 need_e = 2;
-            for (;;) {
-                if (need_e) {
-                    __syncthreads();  // barrier E: the walker has fetched table t
-                    need_e--;
-                }
-                if (t + 1u >= n) return 3;  // the walker decodes the last byte: no table is needed any more
-                spec(rb, c0b, t + 2u);  // table t+2
-                __syncthreads();  // barrier 1 of byte t
-                const u32 c = cm_uniform(LDS_PEEK(s_done[t & 1u]));
-                k1 = c;
-                if (__builtin_expect(c != g, 0)) {
-                    // undo the newer update (its order-0 / order-1 cells are restored with the older one's), then the usual repair
-                    if (wave_on && on_g) cm_pair_store<(X & 16) != 0>(rb.ci, rb.w);
-                    const bool give_up = redo(t + 1u, c, ((t + 1u) & 1u) ? ptab1 : ptab0, ra, c0a, on_g, rl);
-                    __syncthreads();  // barrier 2: the corrected table of byte t+1
-                    run_prev = 0;
-                    hits = 0;
-                    t++;
-                    return give_up ? 0 : 1;
-                }
-                hits++;
-                if (wave_on) {
-                    ra = rb;
-                    c0a = c0b;
-                }
-                t++;
-            }
+            return !give_up;
         };
         CmEvalP other = prev;
-        if (!(X & 8)) {
-            for (u32 i = 1; i < n;) {
-                if (!step(i, CmConst<1>{}, prev, other)) return;
-                if (++i >= n) break;
-                if (!step(i, CmConst<0>{}, other, prev)) return;
-                ++i;
-            }
-        } else {
-            for (u32 i = 1; i < n;) {
-                int st;
-                if (i & 1u) {
-                    st = step(i, CmConst<1>{}, prev, other);
-                    if (st == 1) {
-                        if (++i >= n) break;
-                        st = step(i, CmConst<0>{}, other, prev);
-                    } else if (st == 2) {
-                        prev = other;  // (the run phase takes the newest record in `prev`)
-                    }
-                } else {
-                    st = step(i, CmConst<0>{}, other, prev);
-                }
-                if (st == 0) return;
-                if (st == 2) {
-                    st = run_phase(i, prev);  // i = the byte whose table is the newest one = the byte the walker decodes next
-                    if (st == 0) return;
-                    if (st == 3) break;
-                    other = prev;
-                    i++;  // the next table to make
-                    continue;
-                }
-                ++i;
-            }
+        for (u32 i = 1; i < n;) {
+            if (!step(i, CmConst<1>{}, prev, other)) return;
+            if (++i >= n) break;
+            if (!step(i, CmConst<0>{}, other, prev)) return;
+            ++i;
         }
         if (PROF && n >= 256 && threadIdx.x == 64) {  // profiling only: model wave 1's phases (cycles) at u64[8..10] of the output
             u64 * o = reinterpret_cast<u64 *>(out) + 8;
@@ -1159,17 +1035,13 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
     }
     u64 prof_wait = 0, prof_walk = 0, prof_slow = 0, prof_miss = 0, prof_wait_miss = 0;  // PROF
     u64 t0 = 0, t1 = 0;
-    struct CmTab {  // this lane's slice of a table: its node of each of the six speculated levels, of level 6, and both of level 7
-        u32 p0, p1, p2, p3, p4, p5, p6, p7a, p7b;
-    };
-    CmTab TA = {0, 0, 0, 0, 0, 0, 0, 0, 0}, TB = TA;  // the table of the byte being decoded; X & 8: even bytes use TA, odd bytes TB (one is loaded while the other is walked)
-    u32 hits_w = 0;  // right guesses in a row (X & 8; the model waves count the same)
+    u32 P0, P1, P2, P3, P4, P5, P6, P7a, P7b;  // this lane's slice of the table of the byte being decoded
     u32 vi = cm_opaque_zero();                 // the byte index as a vector register: the offset of the byte's store
-#define CM_SYNC_FETCH(T, BUF)                                                                         \
+#define CM_SYNC_FETCH(BUF)                                                                            \
     do {                                                                                              \
         const u32 * __restrict__ pt_ = ptab[BUF];                                                     \
-        (T).p0 = pt_[ix0]; (T).p1 = pt_[ix1]; (T).p2 = pt_[ix2]; (T).p3 = pt_[ix3]; (T).p4 = pt_[ix4]; (T).p5 = pt_[ix5]; \
-        (T).p6 = pt_[ix6]; (T).p7a = pt_[ix7]; (T).p7b = pt_[ix7 + 1u];                               \
+        P0 = pt_[ix0]; P1 = pt_[ix1]; P2 = pt_[ix2]; P3 = pt_[ix3]; P4 = pt_[ix4]; P5 = pt_[ix5];     \
+        P6 = pt_[ix6]; P7a = pt_[ix7]; P7b = pt_[ix7 + 1u];                                           \
     } while (0)
 // one speculated level of the fast walk: (range, d) along the lane's assumed bit, no comparison (see above)
 #define CM_WALK_SPEC(P, NB)                                                                           \
@@ -1188,53 +1060,27 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         range = BIT ? t_ : range + ~t_;                            /* t  |  range - t - 1 */          \
         d = BIT ? d : d + ~t_;                                                                        \
     } while (0)
-// X & 8: the table loads as inline assembly, out of the compiler's sight.  The s_waitcnt instructions of the walk are placed for whichever
-// path needs them and count outstanding accesses from the youngest down: with the loads in sight the walk's levels wait at lgkmcnt(7), (6), ..
-// for "their" load, which in the run phase -- table i+2 is loaded while byte i+1 is walked -- means for the first of the EARLY loads, i.e. for
-// exactly the latency they are issued early to hide (measured in round 4: the run phase gained nothing); and a wait requested through
-// __builtin_amdgcn_s_waitcnt is only a hint that the compiler drops.  So: CM_TAB_LOAD issues the nine loads, CM_TAB_READY waits for every
-// LDS access of the wave and ties the registers to that point (the "+v" operands: nothing that reads them can move above it).
-#ifdef BZ3_EMU
-#define CM_TAB_LOAD(T, BUF) CM_SYNC_FETCH(T, BUF)
-#define CM_TAB_READY(T) ((void)0)
-#else
-#define CM_TAB_LOAD(T, BUF)                                                                           \
-    do {                                                                                              \
-        const u32 b_ = (u32)(__UINTPTR_TYPE__)(CM_LDS u32 *)ptab[BUF];                                 \
-        asm volatile("ds_read_b32 %0, %9\n\tds_read_b32 %1, %10\n\tds_read_b32 %2, %11\n\tds_read_b32 %3, %12\n\t"              \
-                     "ds_read_b32 %4, %13\n\tds_read_b32 %5, %14\n\tds_read_b32 %6, %15\n\tds_read_b32 %7, %16\n\tds_read_b32 %8, %16 offset:4" \
-                     : "+v"((T).p0), "+v"((T).p1), "+v"((T).p2), "+v"((T).p3), "+v"((T).p4), "+v"((T).p5), "+v"((T).p6), "+v"((T).p7a), "+v"((T).p7b) \
-                     : "v"(b_ + 4u * ix0), "v"(b_ + 4u * ix1), "v"(b_ + 4u * ix2), "v"(b_ + 4u * ix3), "v"(b_ + 4u * ix4), "v"(b_ + 4u * ix5),  \
-                       "v"(b_ + 4u * ix6), "v"(b_ + 4u * ix7)                                          \
-                     : "memory");                                                                     \
-    } while (0)
-#define CM_TAB_READY(T)                                                                               \
-    asm volatile("s_waitcnt lgkmcnt(0)"                                                               \
-                 : "+v"((T).p0), "+v"((T).p1), "+v"((T).p2), "+v"((T).p3), "+v"((T).p4), "+v"((T).p5), "+v"((T).p6), "+v"((T).p7a), "+v"((T).p7b) \
-                 :                                                                                    \
-                 : "memory")
-#endif
-    // Decodes byte i from the table in T; returns it.
-    auto walk = [&](const CmTab & T) __attribute__((always_inline)) -> u32 {
+    // Decodes byte i from the table in P0..P7b; returns it.
+    auto walk = [&]() __attribute__((always_inline)) -> u32 {
         u32 range = range_u, low;  // per-lane copies of the wave-uniform coder state
         u32 d = code - low_u;
         const bool inside = d <= range_u;  // low <= code <= high: always, unless a truncated stream fed -1 bytes (:345)
-        CM_WALK_SPEC(T.p0, nb0);  // :453-489
-        CM_WALK_SPEC(T.p1, nb1);
+        CM_WALK_SPEC(P0, nb0);  // :453-489
+        CM_WALK_SPEC(P1, nb1);
         const u64 ok1 = __ballot(d <= range);
-        CM_WALK_SPEC(T.p2, nb2);
-        CM_WALK_SPEC(T.p3, nb3);
+        CM_WALK_SPEC(P2, nb2);
+        CM_WALK_SPEC(P3, nb3);
         const u64 ok3 = __ballot(d <= range);
-        CM_WALK_SPEC(T.p4, nb4);
-        CM_WALK_SPEC(T.p5, nb5);
+        CM_WALK_SPEC(P4, nb4);
+        CM_WALK_SPEC(P5, nb5);
         // the lane that decoded the six bits it had assumed.  (Tested every other level: a lane on an improbable wrong path often
         // reaches range 0 within two levels and wraps at the next 0 it assumes -- with one test at the end 14 % of the bytes of
         // text had a second "survivor" -- but between two tests it has no time for both.)
         const u64 ok = ok1 & ok3 & __ballot(d <= range);
         u32 cb = 0;
         bool bit6, bit7;
-        CM_WALK_REAL(T.p6, bit6);
-        const u32 P7f = bit6 ? T.p7b : T.p7a;
+        CM_WALK_REAL(P6, bit6);
+        const u32 P7f = bit6 ? P7b : P7a;
         CM_WALK_REAL(P7f, bit7);
         const int w = __ffsll((unsigned long long)ok) - 1;
         const u32 low_f = code - cm_readlane(d, w), range_f = cm_readlane(range, w);
@@ -1250,14 +1096,14 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
             low = low_old;
             range = range_old;
             u64 valid = ~0ull;
-            CM_SPEC_LEVEL(T.p0, nb0, 0xFFFFFFFF00000000ull);
-            CM_SPEC_LEVEL(T.p1, nb1, 0xFFFF0000FFFF0000ull);
-            CM_SPEC_LEVEL(T.p2, nb2, 0xFF00FF00FF00FF00ull);
-            CM_SPEC_LEVEL(T.p3, nb3, 0xF0F0F0F0F0F0F0F0ull);
-            CM_SPEC_LEVEL(T.p4, nb4, 0xCCCCCCCCCCCCCCCCull);
-            CM_SPEC_LEVEL(T.p5, nb5, 0xAAAAAAAAAAAAAAAAull);
-            CM_REAL_LEVEL(T.p6, bit6);
-            const u32 P7 = bit6 ? T.p7b : T.p7a;
+            CM_SPEC_LEVEL(P0, nb0, 0xFFFFFFFF00000000ull);
+            CM_SPEC_LEVEL(P1, nb1, 0xFFFF0000FFFF0000ull);
+            CM_SPEC_LEVEL(P2, nb2, 0xFF00FF00FF00FF00ull);
+            CM_SPEC_LEVEL(P3, nb3, 0xF0F0F0F0F0F0F0F0ull);
+            CM_SPEC_LEVEL(P4, nb4, 0xCCCCCCCCCCCCCCCCull);
+            CM_SPEC_LEVEL(P5, nb5, 0xAAAAAAAAAAAAAAAAull);
+            CM_REAL_LEVEL(P6, bit6);
+            const u32 P7 = bit6 ? P7b : P7a;
             CM_REAL_LEVEL(P7, bit7);
             const int w2 = __ffsll((unsigned long long)valid) - 1;  // exactly one lane survives
             low_u = cm_readlane(low, w2);
@@ -1267,11 +1113,8 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         return c;
     };
     // What follows the walk of byte i (BUF = i & 1, a compile-time constant): hand the byte over, meet the model waves, fetch the next
-    // table into `next`.  Returns false when the loop ends (last byte, or the block was given up).
-    // X & 8 (see the model waves' run phase): after CM_RUN_K right guesses in a row the waves work two tables ahead, and from the second
-    // byte of the phase on table i+2 is loaded into `mine` -- the registers byte i was decoded from -- while byte i+1 is walked, so that a
-    // right guess costs the walker nothing but barrier 1; the two intervals that lead there have one more barrier ("E") behind the fetch.
-    auto after = [&](const u32 i, const u32 c, auto buf_tag, CmTab & mine, CmTab & next) __attribute__((always_inline)) -> bool {
+    // table.  Returns false when the loop ends (last byte, or the block was given up).
+    auto after = [&](const u32 i, const u32 c, auto buf_tag) __attribute__((always_inline)) -> bool {
         constexpr u32 BUF = decltype(buf_tag)::value;
         LDS_POKE(s_done[BUF], c);  // every lane stores the same word: no EXEC juggling on the critical path
         if (PROF) t1 = cm_clock();
@@ -1281,24 +1124,12 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         c1 = c;
         if (i + 1u == n) return false;
         __syncthreads();  // barrier 1: the speculative table of byte i+1 is complete, the models read byte i
-        bool fetch_next = true;
         if (!hit) {
             if (PROF) prof_miss++;
             __syncthreads();  // barrier 2: the corrected table
             if (R && LDS_PEEK(s_abort) != 0u) return false;  // given up (R > 0): the block is decoded again by the full-model kernel
-            hits_w = 0;
-        } else if (X & 8) {
-            hits_w++;
-            fetch_next = hits_w <= CM_RUN_K + 1u;  // beyond that `next` holds table i+1 already
         }
-        if (!(X & 8)) {
-            CM_SYNC_FETCH(next, BUF ^ 1u);
-        } else {
-            if (fetch_next) CM_TAB_LOAD(next, BUF ^ 1u);
-            CM_TAB_READY(next);  // (run phase: loaded while byte i was walked; nothing is outstanding behind barrier 1)
-            if (hit && hits_w >= CM_RUN_K && hits_w <= CM_RUN_K + 1u) __syncthreads();  // barrier E: the waves may write the buffer table i+1 was fetched from
-            if (hit && hits_w >= CM_RUN_K + 1u) CM_TAB_LOAD(mine, BUF);  // table i+2 (complete since barrier 1), while byte i+1 is walked
-        }
+        CM_SYNC_FETCH(BUF ^ 1u);
         if (PROF) {
             const u64 t2 = cm_clock();
             prof_walk += t1 - t0;
@@ -1308,22 +1139,16 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         return true;
     };
     __syncthreads();  // barrier 0
-    if (X & 8) {
-        CM_TAB_LOAD(TA, 0);
-        CM_TAB_READY(TA);
-    } else {
-        CM_SYNC_FETCH(TA, 0);
-    }
-    CmTab & TO = (X & 8) ? TB : TA;  // the table of the odd bytes
+    CM_SYNC_FETCH(0);
     u32 i = 0;
     for (;;) {
         if (PROF) t0 = cm_clock();
-        const u32 ca = walk(TA);
-        if (!after(i, ca, CmConst<0>{}, TA, TO)) break;
+        const u32 ca = walk();
+        if (!after(i, ca, CmConst<0>{})) break;
         i++;
         if (PROF) t0 = cm_clock();
-        const u32 cb2 = walk(TO);
-        if (!after(i, cb2, CmConst<1>{}, TO, TA)) break;
+        const u32 cb2 = walk();
+        if (!after(i, cb2, CmConst<1>{})) break;
         i++;
     }
     if (PROF && n >= 256 && lane == 0) {  // profiling only: output bytes 0..31 become counters
@@ -1337,8 +1162,6 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         reinterpret_cast<u32 *>(out)[23] = xcc_id;
     }
 #undef CM_SYNC_FETCH
-#undef CM_TAB_LOAD
-#undef CM_TAB_READY
 #undef CM_WALK_SPEC
 #undef CM_WALK_REAL
 }
@@ -1348,10 +1171,10 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
 #undef CM_SPEC_LEVEL
 #undef CM_REAL_LEVEL
 
-template <int R, bool PROF = false, int X = 0>
+template <int R, bool PROF = false>
 __device__ __forceinline__ void cm_decode_sync_entry(const CmDecodeJob * __restrict__ jobs) {
     BZ3_DYN_SMEM(dyn_lds);
-    cm_decode_block_sync<R, PROF, X>(jobs, *reinterpret_cast<CmLdsT<R> *>(dyn_lds));
+    cm_decode_block_sync<R, PROF>(jobs, *reinterpret_cast<CmLdsT<R> *>(dyn_lds));
 }
 __global__ void __launch_bounds__(320) k_cm_decode_sync(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<0>(jobs); }
 __global__ void __launch_bounds__(320) k_cm_decode_sync2(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS_DEC>(jobs); }
@@ -1360,9 +1183,6 @@ __global__ void __launch_bounds__(320) k_cm_decode_sync3(const CmDecodeJob * __r
 __global__ void __launch_bounds__(320) k_cm_decode_sync_prof(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<0, true>(jobs); }
 __global__ void __launch_bounds__(320) k_cm_decode_sync2_prof(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS_DEC, true>(jobs); }
 __global__ void __launch_bounds__(320) k_cm_decode_sync3_prof(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS3_DEC, true>(jobs); }
-// round-4 experiments (cm_decode_block_sync's X), selected by bz3_hip_debug_cm_experiment()
-template <int R, bool PROF, int X>
-__global__ void __launch_bounds__(320) k_cm_decode_x(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<R, PROF, X>(jobs); }
 #ifdef BZ3_EMU
 __global__ void __launch_bounds__(320) k_cm_decode_sync_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS_TEST>(jobs); }
 #endif
@@ -1376,45 +1196,10 @@ void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int v
     else launch(k_cm_encode, dim3(njobs), dim3(128), 0, s, d_jobs);
 }
 
-static std::atomic<int> g_cm_experiment{0};
-void cm_set_experiment(int x) { g_cm_experiment.store(x); }
-
-template <int R, bool PROF, int X>
-static void cm_launch_x(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s) {
-#ifndef BZ3_EMU
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_decode_x<R, PROF, X>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CmLdsT<R>)));
-#endif
-    launch(k_cm_decode_x<R, PROF, X>, dim3(njobs), dim3(320), sizeof(CmLdsT<R>), s, d_jobs);
-}
-template <int R>
-static bool cm_launch_experiment(int x, bool prof, const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s) {
-    switch (x * 2 + (prof ? 1 : 0)) {
-        case 2: cm_launch_x<R, false, 1>(d_jobs, njobs, s); return true;
-        case 3: cm_launch_x<R, true, 1>(d_jobs, njobs, s); return true;
-        case 10: cm_launch_x<R, false, 5>(d_jobs, njobs, s); return true;
-        case 11: cm_launch_x<R, true, 5>(d_jobs, njobs, s); return true;
-        case 18: cm_launch_x<R, false, 9>(d_jobs, njobs, s); return true;
-        case 19: cm_launch_x<R, true, 9>(d_jobs, njobs, s); return true;
-        case 26: cm_launch_x<R, false, 13>(d_jobs, njobs, s); return true;
-        case 27: cm_launch_x<R, true, 13>(d_jobs, njobs, s); return true;
-        case 34: cm_launch_x<R, false, 17>(d_jobs, njobs, s); return true;
-        case 35: cm_launch_x<R, true, 17>(d_jobs, njobs, s); return true;
-        case 42: cm_launch_x<R, false, 21>(d_jobs, njobs, s); return true;
-        case 43: cm_launch_x<R, true, 21>(d_jobs, njobs, s); return true;
-        case 58: cm_launch_x<R, false, 29>(d_jobs, njobs, s); return true;
-        case 59: cm_launch_x<R, true, 29>(d_jobs, njobs, s); return true;
-        default: return false;
-    }
-}
-
 void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant, bool prof) {
     if (!njobs) return;
-    const int x = g_cm_experiment.load();
 #ifdef BZ3_EMU
-    if (variant == CM_VARIANT_ROWS_TEST) {
-        if (x && cm_launch_experiment<CM_ROWS_TEST>(x, false, d_jobs, njobs, s)) return;
-        return launch(k_cm_decode_sync_test, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS_TEST>), s, d_jobs);
-    }
+    if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_decode_sync_test, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS_TEST>), s, d_jobs);
 #else
     {  // dynamic LDS beyond 64 KB has to be asked for, once per kernel AND per device (a batch may span several GPUs of one process)
         static std::atomic<u64> prepared[4] = {{0}, {0}, {0}, {0}};  // one bit per device ordinal (up to 256)
@@ -1431,10 +1216,6 @@ void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int v
         }
     }
 #endif
-    if (x) {
-        if (variant == CM_VARIANT_ROWS3 && cm_launch_experiment<CM_ROWS3_DEC>(x, prof, d_jobs, njobs, s)) return;
-        if (variant == CM_VARIANT_FULL && cm_launch_experiment<0>(x, prof, d_jobs, njobs, s)) return;
-    }
     if (variant == CM_VARIANT_ROWS3) launch(prof ? k_cm_decode_sync3_prof : k_cm_decode_sync3, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS3_DEC>), s, d_jobs);
     else if (variant == CM_VARIANT_ROWS) launch(prof ? k_cm_decode_sync2_prof : k_cm_decode_sync2, dim3(njobs), dim3(320), sizeof(CmLdsT<CM_ROWS_DEC>), s, d_jobs);
     else launch(prof ? k_cm_decode_sync_prof : k_cm_decode_sync, dim3(njobs), dim3(320), sizeof(CmLdsT<0>), s, d_jobs);

@@ -138,6 +138,5 @@ constexpr size_t CM_SPILL_BYTES = 256 * 256 * 2;
 constexpr u32 CM_MISS_BASE = 1024, CM_MISS_SHIFT = 5;
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL);
 void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL, bool prof = false);  // prof: the sync decoders' cycle-counter build
-void cm_set_experiment(int x);  // round-4 decoder experiments (cm.hip cm_decode_block_sync's X); 0 = the shipped kernels
 
 }  // namespace bz3

@@ -38,9 +38,6 @@ BZIP3_API int bz3_hip_state_device(struct bz3_state * state);
  * Environment BZ3_HIP_CM_MODE=auto|full|rows|rows3 has the same effect.  Output bytes do not depend on the variant.
  * Returns 0, or -1 for an invalid mode. */
 BZIP3_API int bz3_hip_set_cm_mode(int mode);
-/* Experiments (round 4): which build of the guess-ahead CM decoder the decode launches use; 0 = the shipped kernels.  Output bytes do
- * not depend on it.  tools/cm_coresidency.py --exp=N. */
-BZIP3_API void bz3_hip_debug_cm_experiment(int x);
 /* Test hook: how many more code windows the suffix sorter gives groups that are too large for its in-LDS kernels before rank doubling
  * takes them (0 = none: straight to the deep path; k < 0 = the default, 1).  Output bytes do not depend on it. */
 BZIP3_API void bz3_hip_debug_bwt_big_rounds(int k);

@@ -35,7 +35,6 @@ while time.time() - t0 < budget:
     if not d: continue
     mode = int(rng.choice([9, 9, 9, 0, 1, 2]))  # tiny cache (recycles slots all the time), whole model, the shipped caches
     lib.bz3_hip_set_cm_mode(mode)
-    lib.bz3_hip_debug_cm_experiment(int(rng.choice([0, 1, 5, 13, 21, 21, 29, 29])) if os.environ.get('BZ3_FUZZ_EXPERIMENTS') else 0)
     c = o.cm_encode(d)
     e = g.cm_encode(d); dd = g.cm_decode(c, len(d))
     cut = c[: int(rng.integers(0, len(c) + 1))]
