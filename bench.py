@@ -302,6 +302,22 @@ def cpu_info():
     return model, os.cpu_count() or 1
 
 
+def cpu_quota():
+    """CPUs the container may use at once (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited: os.cpu_count() does not know it."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, p = fh.read().split()
+            return None if q == "max" else round(int(q) / int(p), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p, 2)
+    except (OSError, ValueError):
+        return None
+
+
 def host_mem_available():
     try:
         with open("/proc/meminfo") as fh:
@@ -394,7 +410,7 @@ def reference_round_trip(sample_blocks, block_size, keep_encoded=False, lib_path
         rec = {"value": round(total / 2 ** 20 / (t_enc + t_dec), 3), "unit": "MiB/s", "cores": n, "kind": "reference",
                "sample": f"{n} x {len(sample_blocks[0]) / 2 ** 20:.0f} MiB blocks (the GPU's blocks 0..{n - 1}), one pass of bz3_encode_blocks + "
                          f"bz3_decode_blocks of the {label} reference, one thread per block",
-               "t_enc_s": round(t_enc, 2), "t_dec_s": round(t_dec, 2), "host_cpu": model, "host_cores": ncpu}
+               "t_enc_s": round(t_enc, 2), "t_dec_s": round(t_dec, 2), "host_cpu": model, "host_cores": ncpu, "cpu_quota_cpus": cpu_quota()}
         return rec, enc
     o = Oracle()
     d = bytes(sample_blocks[0][: 4 << 20])
@@ -988,7 +1004,9 @@ def main():
             rec = res["rec"]
             ref_choice.update(label=res.get("ref_label") or "gcc -O2", path=res.get("ref_path"))
             rec["build_probe_1_thread_8MiB_MiBps"] = res.get("probe", {})
-            rec["threads_note"] = "64 threads: the reference's CLI caps -j at 64 (src/main.c:213); one thread per block as in bz3_encode_blocks (src/libbz3.c:845-856)"
+            rec["threads_note"] = ("64 threads: the reference's CLI caps -j at 64 (src/main.c:213); one thread per block as in bz3_encode_blocks (src/libbz3.c:845-856).  "
+                                   "cpu_quota_cpus is what the container may use at once (cgroup): on the round-4 GPU boxes 16 of the 256 logical CPUs, where 64, 32 and 16 threads "
+                                   "give the same rate within 8 % (profiles/r04_cpu_threads_probe.json)")
             rec["process"] = f"a process of its own (no torch, no HIP runtime), pinned to {res.get('pinned_to_cpus', 0)} cores; started after the timed steps, while the GPU ran legs that use no host cores"
             rec["gpu_over_cpu"] = round(RESULT["line"]["value"] / rec["value"], 3) if rec.get("value") else None
             if "parity_same" in res:
