@@ -464,7 +464,8 @@ s32 lzp_encode_finish(const LzpEncodeCtx & c, u8 * d_out, Arena & tmp, hipStream
     u32 total = 0;
     HIP_CHECK(hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
-    if (getenv("BZ3_HIP_TRACE")) {
+    static const bool trace = getenv("BZ3_HIP_TRACE") != nullptr;  // (read once)
+    if (trace) {
         LzDriverOut h;
         HIP_CHECK(hipMemcpy(&h, c.d_res, sizeof h, hipMemcpyDeviceToHost));
         fprintf(stderr, "[bz3 lzp] n=%u matches=%u driver_iterations=%u evaluated=%u out=%u\n", n, h.n_matches, h.iterations, h.evaluated, total);
