@@ -701,7 +701,7 @@ def main():
             stage["bwt"] = {"rounds": r.value, "radix_passes": p.value, "sorted_elements": e.value}
             ring = lib.bz3_hip_debug_front_end_ring()  # the encoder's front-end pipeline: context slots x blocks per window
             stage["front_end_ring"] = {"slots": (ring >> 16) & 0xFF, "window": ring & 0xFFFF, "workspace_handed_back": bool(ring >> 30)}
-            if cpu_block == block_size and not coded_kept and not step_s:  # a few ms of device-to-device copies inside the timed region, first step only
+            if cpu_block == block_size and not coded_kept and not step_s and want_cpu:  # a few ms of device-to-device copies inside the timed region, first step only
                 for i in range(cpu_n):
                     coded_kept.append(bufs[i][: sizes[i]].clone())
         t2 = time.perf_counter()
@@ -736,6 +736,16 @@ def main():
             assert torch.equal(bufs[k][:block_size], kept[k]), f"block {k}: round trip changed the data"
 
     verify_round_trip()
+    # the GPU's coded bytes of the parity sample go to shared memory NOW (outside the timed steps): 64 x ~50 MB of HBM that the second
+    # step's ring of LZP contexts can use
+    shared_coded = None
+    if want_cpu and coded_kept:
+        shared_coded = SharedBlocks("bz3_bench_coded", [int(c.numel()) for c in coded_kept])
+        for i, c in enumerate(coded_kept):
+            shared_coded.put_tensor(torch, i, c)
+        coded_kept.clear()
+        if cuda:
+            torch.cuda.empty_cache()
     left = agree(a.budget_s - elapsed()) - reserve
     second = (a.steps >= 2 or a.warmup > 0) and left > step_s[0] * 1.03
     if second:
@@ -890,12 +900,6 @@ def main():
         shared_plain = SharedBlocks("bz3_bench_plain", [bs_cpu] * cpu_n)
         for i in range(cpu_n):
             shared_plain.put_tensor(torch, i, bufs[i if cpu_block == block_size else 0])
-        shared_coded = None
-        if coded_kept:
-            shared_coded = SharedBlocks("bz3_bench_coded", [int(c.numel()) for c in coded_kept])
-            for i, c in enumerate(coded_kept):
-                shared_coded.put_tensor(torch, i, c)
-            coded_kept.clear()
         progress(f"cpu_baseline: {cpu_n} threads x {bs_cpu >> 20} MiB blocks in a process of its own (estimated {cpu_need:.0f}s); GPU-only legs meanwhile")
         cpu_worker_proc = RefWorker(shared_plain.meta(), max(bs_cpu, 65 * 1024), coded=shared_coded.meta() if shared_coded else None, probe=True)
     elif want_cpu:
@@ -969,34 +973,6 @@ def main():
             "cm_blocks_given_up": int(lib.bz3_hip_cm_blocks_given_up()) - before}
         progress(f"mixed: {RESULT['line']['configs']['mixed']['value']} MiB/s, {RESULT['line']['configs']['mixed']['cm_blocks_given_up']} blocks given up by the row-cache kernels")
 
-    if extras_wanted and a.kind == "text" and left_s() > 200.0:
-        # cfg5's stage (BASELINE.json configs[4]: "-b 511 max block ... decode-path unBWT throughput"): the inverse BWT of one block of the
-        # maximum size.  Verbatim long repeats would be collapsed by LZP (SURVEY.md 8d), so the source is a skewed order-1 Markov chain
-        # over 16 symbols (repeat units < 40 B: LZP / RLE decline, the BWT stage sees all n bytes).
-        try:
-            n5 = 511 << 20
-            src5 = markov16(n5, 5).cpu().numpy().tobytes()
-            if cuda:
-                torch.cuda.empty_cache()
-            gs = bzip3_amd.StageApi(lib)
-            idx5, u5 = gs.bwt(src5)
-            ms_fwd = float(lib.bz3_hip_stage_last_ms())
-            rc5, back5 = gs.unbwt(u5, idx5)
-            ms_inv = float(lib.bz3_hip_stage_last_ms())
-            assert rc5 == 0 and back5 == src5, "cfg5_unbwt: the inverse BWT did not return the block"
-            RESULT["line"]["configs"]["cfg5_unbwt"] = {
-                "workload": "BASELINE.json configs[4]'s stage on one GPU: inverse BWT of ONE 511 MiB block (535,822,336 B, the maximum block size) of a skewed "
-                            "order-1 Markov source over 16 symbols (bz3_hip_stage_unbwt; transform alone, PCIe copies of the hook excluded); "
-                            "the whole-pipeline round trip of a batch of such blocks is `bench.py --leg cfg5` (profiles/)",
-                "value": round(ALG_BYTES_BWT * n5 / (ms_inv * 1e-3) / 1e9, 3), "unit": "GB/s (11 algorithmic bytes per byte, SURVEY.md 8d)",
-                "ms": round(ms_inv, 2), "MiBps": round(511.0 / (ms_inv * 1e-3), 1), "frac_of_hbm_peak": round(ALG_BYTES_BWT * n5 / (ms_inv * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                "forward_bwt_ms": round(ms_fwd, 2), "forward_bwt_GBps": round(ALG_BYTES_BWT * n5 / (ms_fwd * 1e-3) / 1e9, 3)}
-            progress(f"cfg5_unbwt: inverse BWT of a 511 MiB block in {ms_inv:.1f} ms (forward {ms_fwd:.1f} ms)")
-            del src5, u5, back5
-            lib.bz3_hip_release_cached_memory()
-        except Exception as e:
-            RESULT["line"]["configs"]["cfg5_unbwt"] = {"skipped": f"failed: {e}"}
-
     # ---- cpu_baseline: started after the timed steps, collected here (the legs above used the GPU only) ----------------
     if cpu_worker_proc is not None:
         res = cpu_worker_proc.result()
@@ -1031,6 +1007,36 @@ def main():
         else:
             rec["cpu"] = {"value": None, "sample": "failed: " + res.get("err", "?")}
         random_host.close()
+
+    if extras_wanted and a.kind == "text" and left_s() > 200.0:
+        # (after the reference process has finished: the stage hooks wait for the stream between launches, and a host whose CPU quota 64
+        # reference threads saturate stretches exactly those waits -- round 4's rehearsal measured this leg 3.4x slower beside them)
+        # cfg5's stage (BASELINE.json configs[4]: "-b 511 max block ... decode-path unBWT throughput"): the inverse BWT of one block of the
+        # maximum size.  Verbatim long repeats would be collapsed by LZP (SURVEY.md 8d), so the source is a skewed order-1 Markov chain
+        # over 16 symbols (repeat units < 40 B: LZP / RLE decline, the BWT stage sees all n bytes).
+        try:
+            n5 = 511 << 20
+            src5 = markov16(n5, 5).cpu().numpy().tobytes()
+            if cuda:
+                torch.cuda.empty_cache()
+            gs = bzip3_amd.StageApi(lib)
+            idx5, u5 = gs.bwt(src5)
+            ms_fwd = float(lib.bz3_hip_stage_last_ms())
+            rc5, back5 = gs.unbwt(u5, idx5)
+            ms_inv = float(lib.bz3_hip_stage_last_ms())
+            assert rc5 == 0 and back5 == src5, "cfg5_unbwt: the inverse BWT did not return the block"
+            RESULT["line"]["configs"]["cfg5_unbwt"] = {
+                "workload": "BASELINE.json configs[4]'s stage on one GPU: inverse BWT of ONE 511 MiB block (535,822,336 B, the maximum block size) of a skewed "
+                            "order-1 Markov source over 16 symbols (bz3_hip_stage_unbwt; transform alone, PCIe copies of the hook excluded); "
+                            "the whole-pipeline round trip of a batch of such blocks is `bench.py --leg cfg5` (profiles/)",
+                "value": round(ALG_BYTES_BWT * n5 / (ms_inv * 1e-3) / 1e9, 3), "unit": "GB/s (11 algorithmic bytes per byte, SURVEY.md 8d)",
+                "ms": round(ms_inv, 2), "MiBps": round(511.0 / (ms_inv * 1e-3), 1), "frac_of_hbm_peak": round(ALG_BYTES_BWT * n5 / (ms_inv * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                "forward_bwt_ms": round(ms_fwd, 2), "forward_bwt_GBps": round(ALG_BYTES_BWT * n5 / (ms_fwd * 1e-3) / 1e9, 3)}
+            progress(f"cfg5_unbwt: inverse BWT of a 511 MiB block in {ms_inv:.1f} ms (forward {ms_fwd:.1f} ms)")
+            del src5, u5, back5
+            lib.bz3_hip_release_cached_memory()
+        except Exception as e:
+            RESULT["line"]["configs"]["cfg5_unbwt"] = {"skipped": f"failed: {e}"}
 
     def small_config(name, total_bytes_, bs, what):
         """BASELINE configs of a few blocks: `total_bytes_` of the batch's text at block size bs on one GPU, the reference's -j N beside it."""

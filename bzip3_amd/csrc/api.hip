@@ -641,10 +641,22 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     // ends (below): the decode call that follows needs the room for staged payloads and the swap buffers of its tail windows.
     size_t budget = (size_t)32 << 30;
     {
+        // Swap buffers the previous call left idle in the pool (a decode call's tail ring holds up to 4 x 16 of them, 17 GB at 256 MiB)
+        // are memory this call's ring of LZP contexts cannot use: round 4's full-size run had a ring of 4 x 4 contexts and an encode
+        // front end 14 s longer in its SECOND step than in its first for this.  What the front end borrows again is a few dozen buffers.
+        if (lead->lean) lead->ctx->temp_trim();
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t have = lead->ctx->ws_cap;  // the arena already holds this much
             budget = (free_b + have > need) ? (free_b + have - need) / 10 * 7 : 0;
+            if (lead->lean) {
+                // lean states: what a block in the ring holds is known exactly -- its LZP context and one borrowed swap buffer -- so the ring may take
+                // all but a fixed margin (round 4: 7/10 of the free memory gave 17 contexts, a ring of 4 x 4, where 21 fit: 4 x 5)
+                const size_t margin = (size_t)4 << 30;
+                const size_t avail = free_b + have > need + margin ? free_b + have - need - margin : 0;
+                const size_t exact = avail / (ctx_bytes + lead->cap) * ctx_bytes;
+                if (exact > budget) budget = exact;
+            }
         }
     }
     s32 window = 1, ns = 2;
