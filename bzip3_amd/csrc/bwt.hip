@@ -2,24 +2,31 @@
 // Replaces libsais_bwt (reference include/libsais.h:4095-4121, SA-IS: :3941-3983, :3740-3939), which is a sequential
 // induced-sorting algorithm whose inner scans carry a dependency through 256 bucket cursors.  This is NOT a port of it.
 //
-// Round 3 design ("sort once, then resolve groups where they lie"):
+// Design of rounds 3-4 ("sort once, then resolve groups where they lie"):
 //
-//   codes   : the bytes of the block are given an order-preserving prefix-free code of at most 8 bits per symbol, built on the
-//             host from the block's byte histogram (an optimal height-limited alphabetic tree: frequent bytes get short codes).
-//             Comparing the concatenated code bits of two suffixes is the same as comparing their bytes, and a 56-bit window
-//             holds 7 symbols at least and ~12 of English text.
+//   codes   : the bytes of the block are given an order-preserving prefix-free code of at most 8 bits per symbol, the optimal
+//             height-limited alphabetic tree for the block's byte histogram (frequent bytes get short codes), built on the DEVICE
+//             (k_vlc_init / k_vlc_level / k_vlc_codes; rounds 1-3: on the host).  Comparing the concatenated code bits of two suffixes
+//             is the same as comparing their bytes, and a 56-bit window holds 7 symbols at least and ~12 of English text.
 //   round 0 : key(i) = first 56 code bits of suffix i (16 symbols at most, zero padded past the end) << 8 | T[i-1]; ONE stable LSD
 //             radix sort of all n (key, i) pairs over the upper 56 bits (7 passes of sort.hip).  The byte that precedes the suffix
 //             rides in the low byte: it is the BWT symbol of the suffix, so the output needs no gather through the suffix array.
-//   groups  : suffixes with equal 56-bit windows form a group of neighbouring slots.  V[slot] = suffix | head flag (bit 31).
-//   resolve : k_bwt_resolve -- one workgroup per 1536 slots sorts every group of <= 512 suffixes that starts there COMPLETELY, in
-//             LDS: each step fetches the next 40 code bits of every still-ambiguous suffix straight from the text (no inverse
-//             suffix array, no rank table: groups are independent of each other), ranks small groups by counting and larger ones
-//             with a bitonic network, splits the groups and drops the suffixes that became unique.  Text needs 2-3 steps.
-//   big     : groups of > 512 suffixes (a few % of text) get one more 56-bit window each through the global radix sorter
-//             (k_big_*), after which they are small and go through k_bwt_resolve again.
+//   groups  : suffixes with equal 56-bit windows form a group of neighbouring slots.  V[slot] = suffix | head flag (bit 31);
+//             k_bwt_heads marks them and snapshots the flags, k_bwt_spine_a / _b give every anchor tile of 512 slots (WR_A) the last
+//             head before it.
+//   route   : k_bwt_route -- a wave per anchor tile sends the groups that start there to one of three lists: up to 64 members -> the
+//             tail list (one entry per suffix), 65 .. 256 members (WR_G) -> a descriptor for the wide kernel, more -> the big list.
+//   wide    : k_bwt_wide -- a wave per descriptor, 2 or 4 suffixes per lane in registers: a step fetches the next 40 code bits of
+//             every still-ambiguous suffix straight from the text (no inverse suffix array, no rank table: groups are independent of
+//             each other), a bitonic network over the wave's registers sorts all sub-groups at once; what is down to <= 64 members
+//             moves on to the tail list.
+//   tail    : k_bwt_tail -- a wave per 64 list entries takes the whole groups that start there, a lane per suffix, ranks groups of up
+//             to 12 by counting and larger ones with a 64-lane bitonic network, up to TL_CAP steps.  Text needs 2-3 steps.
+//             The wide and the tail kernel read the lengths of their lists from the router's counters on the device (round 4).
+//   big     : groups of > 256 suffixes (a few % of text) get one more 56-bit window each through the global radix sorter
+//             (k_big_*), after which they are small and are routed again.
 //   deep    : what is still ambiguous after that (long repeats: runs, periodic data) falls back to classic prefix doubling on
-//             ranks (ISA built once, k_fb_* / k_bg_* / doubling_rounds) -- the only path that needs random 4-byte scatters.
+//             ranks (ISA built once, k_bg_* / k_isa_scatter / k_bwt_doubling_keys_grp) -- the only path that needs random 4-byte scatters.
 //   output  : U[0] = T[n-1]; U[i < i0 ? i+1 : i] = payload byte of slot i for i != i0 = slot of suffix 0; idx = i0+1.
 //
 // Order of equal windows past the end of the block: a suffix that is a proper prefix of another sorts first (zero padding is the

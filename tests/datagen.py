@@ -205,7 +205,8 @@ def suffix_sorter_cases():
     alphabets: counting for groups <= 64, the bitonic network above), groups of > 512 suffixes that take the big path once or
     several times (a phrase repeated in random surroundings), lists that overflow it or repeat too deeply and fall back to rank
     doubling (runs, periods, Fibonacci strings, a passage repeated verbatim), suffixes that end inside a window (zero-coded tails),
-    and sizes around the tile geometry (1536-slot anchors, 2048-slot windows)."""
+    and sizes around the tile geometry (round 3's first kernel: 1536-slot anchors, 2048-slot windows; the shipped kernels: 512-slot anchor
+    tiles, groups of <= 64 to the tail list, <= 256 to the wide kernel)."""
     rng = np.random.default_rng(5)
     t = shakespeare()
     letters = lambda k: bytes(rng.integers(97, 123, size=k, dtype=np.uint8))
@@ -227,4 +228,11 @@ def suffix_sorter_cases():
     for n in (1535, 1536, 1537, 2047, 2048, 2049, 3071, 3072, 3073, 4097):
         c["text%d" % n] = t[777 : 777 + n]
         c["pair%d" % n] = (t[9000:9000 + n // 2] * 2)[:n]
+    # the geometry of the shipped kernels (round 4): groups of exactly 64 / 65 members (tail list | wide kernel), 256 / 257 (wide
+    # kernel | big list), blocks around one and two anchor tiles of 512 slots, and a group that straddles two anchor tiles
+    for members in (64, 65, 256, 257):
+        c["group%d" % members] = b"".join(b"zyxwvutsrqponm" + letters(30) for _ in range(members)) + letters(3000)
+    for n in (511, 512, 513, 1023, 1024, 1025):
+        c["tile%d" % n] = t[4242 : 4242 + n]
+    c["straddle"] = letters(400) + b"".join(b"mmmmmmmmmmmmmm" + bytes([97 + (k % 26)]) + letters(5) for k in range(200)) + letters(300)
     return c
