@@ -652,7 +652,7 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
             if (lead->lean) {
                 // lean states: what a block in the ring holds is known exactly -- its LZP context and one borrowed swap buffer -- so the ring may take
                 // all but a fixed margin (round 4: 7/10 of the free memory gave 17 contexts, a ring of 4 x 4, where 21 fit: 4 x 5)
-                const size_t margin = (size_t)4 << 30;
+                const size_t margin = (size_t)6 << 30;
                 const size_t avail = free_b + have > need + margin ? free_b + have - need - margin : 0;
                 const size_t exact = avail / (ctx_bytes + lead->cap) * ctx_bytes;
                 if (exact > budget) budget = exact;
