@@ -889,3 +889,16 @@ def test_cm_decoder_on_runs_of_every_length_and_every_top_bit_pair(emu, oracle, 
             assert g.cm_decode(c, len(d)) == d, (mode, len(d))
             cut = c[: len(c) * 2 // 3]
             assert g.cm_decode(cut, len(d)) == oracle.cm_decode(cut, len(d)), (mode, len(d))
+
+
+def test_calibrated_text_through_the_three_per_cu_kernels(emu, oracle, cm_mode):
+    """bench.py's workload (tests/datagen.py text with ENWIK_NOISE: digits and random identifiers among the words) through the
+    44 / 56-row caches: oracle bytes both ways and nothing given up (the GPU twin of this test runs 6 MiB blocks)."""
+    g = bzip3_amd.StageApi(emu)
+    d = oracle.bwt(datagen.text(9000, seed=71, chains=16, noise=datagen.ENWIK_NOISE))[1]
+    c = oracle.cm_encode(d)
+    assert cm_mode(2) == 0
+    n0 = emu.bz3_hip_cm_blocks_given_up()
+    assert g.cm_encode(d) == c
+    assert g.cm_decode(c, len(d)) == d
+    assert emu.bz3_hip_cm_blocks_given_up() == n0
