@@ -7,7 +7,7 @@ Times bz3_hip_encode_blocks_device + bz3_hip_decode_blocks_device over 768 x <Mi
     mmap_subproc  the same 64 threads in ANOTHER process, pinned to the upper half of the cores
 The front end (t_enc - CM launch) is the part of a step in which the host sits between kernels (stream syncs), so it is the part a busy
 host can slow down.
-    python tools/host_contention.py [MiB=8] [blocks=768]
+    python tools/host_contention.py [MiB=8] [blocks=768] [--only=idle,mmap_subproc]
 """
 import ctypes as C
 import json
@@ -62,8 +62,11 @@ def worker_main():  # mmap_subproc's child
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--worker":
         return worker_main()
-    mib = float(sys.argv[1]) if len(sys.argv) > 1 else 8.0
-    nblk = int(sys.argv[2]) if len(sys.argv) > 2 else 768
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    only = [a[len("--only="):].split(",") for a in sys.argv if a.startswith("--only=")]
+    only = only[0] if only else ["idle", "spin_inproc", "mmap_inproc", "mmap_subproc", "idle_again"]
+    mib = float(args[0]) if len(args) > 0 else 8.0
+    nblk = int(args[1]) if len(args) > 1 else 768
     import torch
 
     import bench
@@ -104,8 +107,11 @@ def main():
 
     step()  # warm-up: allocations
     out = {"blocks": nblk, "block_mib": mib, "host_cores": os.cpu_count()}
-    out["idle"] = step()
+    if "idle" in only:
+        out["idle"] = step()
     for name, fn in (("spin_inproc", spin), ("mmap_inproc", churn)):
+        if name not in only:
+            continue
         STOP.clear()
         ts = load_threads(fn)
         time.sleep(1.0)
@@ -113,12 +119,14 @@ def main():
         STOP.set()
         for t in ts:
             t.join()
-    p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker"])
-    time.sleep(2.0)
-    out["mmap_subproc"] = step()
-    p.kill()
-    p.wait()
-    out["idle_again"] = step()
+    if "mmap_subproc" in only:
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker"])
+        time.sleep(2.0)
+        out["mmap_subproc"] = step()
+        p.kill()
+        p.wait()
+    if "idle_again" in only:
+        out["idle_again"] = step()
     print(json.dumps(out))
 
 
