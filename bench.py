@@ -115,6 +115,7 @@ def parse():
     ap.add_argument("--noise", type=float, default=-1.0, help="fraction of noise tokens in the text (-1 = tests/datagen.py ENWIK_NOISE, the enwik8 calibration)")
     ap.add_argument("--text-bases", type=int, default=8, help="independent texts the blocks are drawn from")
     ap.add_argument("--leg", default="", choices=["", "cfg5"], help="run ONE optional leg instead of the default workload (cfg5: a GPU-filling batch of 511 MiB blocks)")
+    ap.add_argument("--leg-block-mib", type=float, default=511.0, help="block size of --leg cfg5 (511 = BASELINE's; smaller values are for tests)")
     ap.add_argument("--emu", action="store_true", help="TESTS ONLY: the CPU emulator build of the kernels (tests/emu) and gloo instead of a GPU and RCCL; checks the control flow, measures nothing")
     ap.add_argument("--cpu-worker", default="", help="internal: run the reference on the blocks described by this JSON file (the cpu_baseline process)")
     return ap.parse_args()
@@ -576,7 +577,7 @@ def main():
     nblk = a.blocks if a.blocks > 0 else cus * per_cu
     block_size = int(a.block_mib * (1 << 20))
     if a.leg == "cfg5":
-        block_size = 511 << 20
+        block_size = int(a.leg_block_mib * (1 << 20))
         if a.blocks <= 0:
             nblk = cus  # 256 x 511 MiB + workspace is what fits beside the swap-buffer pool
     lean = a.lean == 1 or (a.lean < 0 and nblk > cus)

@@ -105,7 +105,13 @@ struct DeviceCtx {
                 return t.first;
             }
         u8 * p = nullptr;
-        HIP_CHECK(hipMalloc((void **)&p, cap));
+        if (hipMalloc((void **)&p, cap) != hipSuccess) {
+            // (the ring's budget is an estimate: before the block fails, give back what the pool holds idle -- buffers of other sizes -- and ask again)
+            (void)hipGetLastError();
+            for (auto & t : temps_free) (void)hipFree(t.first);
+            temps_free.clear();
+            HIP_CHECK(hipMalloc((void **)&p, cap));
+        }
         temps_out.push_back({p, cap});
         return p;
     }

@@ -51,3 +51,13 @@ def test_bench_under_torch_distributed_run_as_the_driver_launches_it():
 def test_bench_single_rank_on_the_emulator():
     d, _ = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS)
     _check(d, 1)
+
+
+def test_bench_cfg5_leg_control_flow_on_the_emulator():
+    """`bench.py --leg cfg5` (a batch of maximum-size blocks of the 16-symbol source; run on its own, not by the driver) at a test size."""
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--emu", "--leg", "cfg5", "--leg-block-mib", "0.003", "--blocks", "2", "--steps", "1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "leg cfg5" in d["metric"] and d["steps"] == 1 and d["cpu_baseline"]["value"] is None and d["configs"] == {}
