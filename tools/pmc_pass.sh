@@ -7,7 +7,7 @@ OUT=$(realpath "$1")
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--blocks 768 --block-mib 2 --no-cpu-baseline --no-extras --steps 1 --warmup 0"
+ARGS="--blocks 768 --block-mib ${PMC_BLOCK_MIB:-2} --no-cpu-baseline --no-extras --steps 1 --warmup 0"
 for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf "$OUT/$c"
     rocprofv3 --kernel-trace --pmc $c -d "$OUT/$c" -o pass -- python "$REPO/bench.py" $ARGS > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err" || { tail -5 "$OUT/bench_$c.err"; exit 1; }
