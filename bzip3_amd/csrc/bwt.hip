@@ -1112,7 +1112,7 @@ __global__ void __launch_bounds__(BW_BLOCK) k_big_keys(const u8 * __restrict__ t
     u64 pos = s;
     u64 wa, wb, key;
     u32 avl, cnt;
-    for (u32 hop = 0; hop < chain; hop++) {  // past the windows the group was formed on (see k_bwt_resolve)
+    for (u32 hop = 0; hop < chain; hop++) {  // past the windows the group was formed on (cf. k_bwt_tail's `fresh` entries)
         load_window(t, pos, n, wa, wb, avl);
         vlc_pack<56>(tab, wa, wb, avl, key, cnt);
         pos += cnt;

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY: differential fuzzer of the batch paths under the CPU emulator (tests/emu) against the oracle -- random
 batches (stored / plain / LZP-coded / run-length-coded / incompressible blocks of random sizes) through random shapes of the
-encoder's front-end ring and the decoder's tail ring (BZ3_HIP_LZP_PIPE, BZ3_HIP_TAIL_PIPE), classic and lean states, the seven-launch
-and the two-pass regrouping of the suffix sorter (BZ3_BWT_FUSED), workspaces kept or handed back (BZ3_HIP_WS_KEEP_MB).
+encoder's front-end ring and the decoder's tail ring (BZ3_HIP_LZP_PIPE, BZ3_HIP_TAIL_PIPE), classic and lean states, the suffix sorter's
+big groups through 0 / 1 / 8 more windows before the deep path (bz3_hip_debug_bwt_big_rounds), workspaces kept or handed back (BZ3_HIP_WS_KEEP_MB).
     python tests/fuzz_rings.py <seed> <minutes>"""
 import ctypes as C
 import os
@@ -51,11 +51,10 @@ def main():
             env["BZ3_HIP_LZP_PIPE"] = "%d,%d" % (rng.randint(1, 9), rng.randint(2, 4))
         if rng.random() < 0.7:
             env["BZ3_HIP_TAIL_PIPE"] = "%d,%d" % (rng.randint(1, 9), rng.randint(2, 4))
-        if rng.random() < 0.5:
-            env["BZ3_BWT_FUSED"] = "1"
+        lib.bz3_hip_debug_bwt_big_rounds(rng.choice([-1, -1, 0, 8]))
         if rng.random() < 0.3:
             env["BZ3_HIP_WS_KEEP_MB"] = "0"
-        for k in ("BZ3_HIP_LZP_PIPE", "BZ3_HIP_TAIL_PIPE", "BZ3_BWT_FUSED", "BZ3_HIP_WS_KEEP_MB"):
+        for k in ("BZ3_HIP_LZP_PIPE", "BZ3_HIP_TAIL_PIPE", "BZ3_HIP_WS_KEEP_MB"):
             os.environ.pop(k, None)
         os.environ.update(env)
         lean = rng.random() < 0.5

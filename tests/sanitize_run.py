@@ -18,11 +18,12 @@ for d in cases:
     idx, u = o.bwt(d)
     assert g.unbwt(u, idx) == (0, d), len(d)
 print("stages ok", flush=True)
-os.environ["BZ3_BWT_FUSED"] = "1"  # the opt-in two-pass regrouping of the suffix sorter (read per call)
-for d in cases + [t[777:777 + n] for n in (2047, 2048, 2049, 4097)] + [b"a" * 2049]:
-    assert g.bwt(d) == o.bwt(d), len(d)
-del os.environ["BZ3_BWT_FUSED"]
-print("fused regrouping ok", flush=True)
+for rounds in (0, 8):  # big groups straight to rank doubling / through several more windows first (test hook of the suffix sorter)
+    lib.bz3_hip_debug_bwt_big_rounds(rounds)
+    for d in cases + [t[777:777 + n] for n in (511, 512, 513, 1025, 2049, 4097)] + [b"a" * 2049]:
+        assert g.bwt(d) == o.bwt(d), (rounds, len(d))
+lib.bz3_hip_debug_bwt_big_rounds(-1)
+print("sorter paths ok", flush=True)
 bs = 65 * 1024
 def batch(n, pipe):
     for var in ("BZ3_HIP_LZP_PIPE", "BZ3_HIP_TAIL_PIPE"):
