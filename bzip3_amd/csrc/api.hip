@@ -1676,6 +1676,7 @@ BZIP3_API int bz3_hip_set_cm_mode(int mode) {
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void) { return g_cm_given_up.load(); }
 
 BZIP3_API void bz3_hip_debug_bwt_big_rounds(int k) { bwt_set_big_rounds(k); }
+BZIP3_API int bz3_hip_debug_cm_encode_trio(int on) { return cm_set_encode_trio(on); }
 
 BZIP3_API int bz3_hip_cm_variant_for(int device, int blocks, int encode) {
     DeviceCtx * c = get_ctx(device);
@@ -2024,6 +2025,7 @@ BZIP3_API float bz3_hip_stage_cm_decode_many(const uint8_t * in, int32_t in_size
 // Profiling: `copies` identical CM encode jobs in ONE launch through the encoder of the current CM kernel variant; returns the launch
 // time in ms (HIP events) and the coded size of copy 0 in *coded (its bytes in `out`, capacity bz3_bound(n)).  BZ3_CM_DEBUG=1 / 2 runs
 // the coder wave / the model waves alone (output invalid): which side of the LDS ring limits the kernel at a given co-residency.
+// BZ3_CM_MANY_CHECK=1: every copy's coded bytes are compared with copy 0's (-2 when they differ).
 BZIP3_API float bz3_hip_stage_cm_encode_many(const uint8_t * in, int32_t n, uint8_t * out, int32_t * coded, int32_t copies) {
     return stage_guard([&]() -> float {
         StageEnv e;
@@ -2063,7 +2065,17 @@ BZIP3_API float bz3_hip_stage_cm_encode_many(const uint8_t * in, int32_t n, uint
         (void)hipEventDestroy(e1);
         const u32 got = e.word(w);
         if (coded) *coded = (int32_t)got;
-        if (got != 0xFFFFFFFFu && got <= bz3_bound((size_t)n) && !(debug & 15u)) e.down(out, o, (size_t)got);
+        if (got != 0xFFFFFFFFu && got <= bz3_bound((size_t)n) && !(debug & 15u)) {
+            e.down(out, o, (size_t)got);
+            if (getenv("BZ3_CM_MANY_CHECK")) {  // every copy must have coded the same bytes (-2 otherwise)
+                std::vector<u8> other((size_t)got);
+                for (int32_t k = 1; k < copies; k++) {
+                    if (e.word(w + 4 * (size_t)k) != got) return -2.f;
+                    e.down(other.data(), o + stride * (size_t)k, (size_t)got);
+                    if (memcmp(other.data(), out, (size_t)got) != 0) return -2.f;
+                }
+            }
+        }
         return ms;
     });
 }
