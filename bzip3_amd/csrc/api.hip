@@ -1676,7 +1676,6 @@ BZIP3_API int bz3_hip_set_cm_mode(int mode) {
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void) { return g_cm_given_up.load(); }
 
 BZIP3_API void bz3_hip_debug_bwt_big_rounds(int k) { bwt_set_big_rounds(k); }
-BZIP3_API int bz3_hip_debug_cm_encode_trio(int on) { return cm_set_encode_trio(on); }
 
 BZIP3_API int bz3_hip_cm_variant_for(int device, int blocks, int encode) {
     DeviceCtx * c = get_ctx(device);

@@ -448,93 +448,12 @@ __device__ __forceinline__ u32 cm_rows_chunk(M & m, CmRowCache<R> & rc, CmRowSta
     return rowv;
 }
 
-// The model wave of one block (`jobs[jb]`) with the block's LDS objects: the chain and event loops over chunks of 32 bytes, the row cache,
-// the hand-off to the coder through the ring (s_prod / s_cons).
-template <int R, class M>
-__device__ __forceinline__ void cm_encode_model_wave(const CmEncodeJob * __restrict__ jobs, const u32 jb, M & m, CmRing & ring, CmEvent * __restrict__ ev, u32 & s_prod, u32 & s_cons,
-                                                     CmRowCache<R> & rc, const u32 debug) {
-    const u8 * __restrict__ in = global_ptr<const u8>(jobs[jb].in);
-    const u32 n = jobs[jb].n;
-    const int lane = lane_id();
-    if (debug == 1) return;
-    // ---- model wave ------------------------------------------------------------------------------
-    // Lanes 0..7 walk the counter chain, one tree LEVEL each: the node of a level is picked by the byte (hibit | byte >> shr), its
-    // three counters are read from LDS, updated and written back in program order -- the LDS serves a wave's requests in order,
-    // so a counter that is hit again by the next byte needs no forwarding.  (Rounds 1-2 gave every NODE a lane and C0 a
-    // register, which took three waves of which 8 lanes were busy; at three blocks per CU those ~125 wave instructions per
-    // byte, not the coder's ~60, were what the SIMDs ran out of: round 3.)
-    const u32 lvl = (u32)lane & 7u;
-    const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
-    const bool chain_lane = lane < 8;
-    u32 cons_seen = 0;
-    u32 hist = 0;  // the 4 bytes before the chunk, oldest in the top byte (zeros before the block starts)
-    CmRowState rs;
-    u16 * __restrict__ spill = global_ptr<u16>(jobs[jb].spill);
-    const u32 miss_base = jobs[jb].miss_base, miss_shift = jobs[jb].miss_shift;
-    // In-place coding: giving a block up is only possible while the coded bytes cannot have reached the input
-    // yet (the full-model kernel will read that input again): output <= bz3_bound(position) < gap.
-    const u32 gap = jobs[jb].gap;
-    const u32 abort_limit = gap == CM_NO_GAP ? 0xFFFFFFFFu : (gap > 4096u ? (u32)(((u64)(gap - 2048u) * 32u) / 33u) : 0u);
-    u32 hrow1 = 0, hrow2 = 0;  // slots of bytes -1 and -2 (byte value 0 before the block starts: slot 0)
-    if (R) cm_rows_init<R>(rc);
-    for (u32 base = 0; base < n; base += CM_CHUNK) {
-        const u32 cnt = (n - base < CM_CHUNK) ? n - base : CM_CHUNK;
-        while (debug != 2 && base + cnt - cons_seen > CM_RING) {  // ring full: wait for the coder
-            cons_seen = LDS_PEEK(s_cons);
-            if (base + cnt - cons_seen > CM_RING) BZ3_SPIN_PAUSE();
-        }
-        // lane r holds byte r of the chunk together with its 4 predecessors
-        const u32 mine = ((u32)lane < cnt) ? in[base + lane] : 0u;
-        u32 rowv = 0;
-        if (R) {
-            rowv = cm_rows_chunk<R, 4>(m, rc, rs, spill, mine, cnt, hrow1, hrow2, (u32)lane);  // (the wave moves whole rows: four cells per lane)
-            if (__builtin_expect(rs.misses > miss_base + (base >> miss_shift) && base < abort_limit, 0)) {
-                // the working set does not fit: give the block up
-                if (lane == 0) *global_ptr<u32>(jobs[jb].status) = 1u;
-                LDS_POKE(s_prod, CM_ABORT_MARK);
-                return;
-            }
-        }
-        u32 prev4 = 0;  // bytes r-1, r-2, r-3, r-4 in bits 0-7, 8-15, 16-23, 24-31
-#pragma unroll
-        for (int d = 1; d <= 4; d++) {
-            const u32 up = __shfl_up(mine, (unsigned)d);
-            // lanes < d reach back into the previous chunk: hist holds byte -1 in bits 0-7 ... byte -4 in bits 24-31
-            const u32 h = (hist >> (8u * (((u32)d - 1u - (u32)lane) & 3u))) & 0xFFu;
-            prev4 |= (((u32)lane >= (u32)d) ? up : h) << (8 * (d - 1));
-        }
-        u32 packed = mine | ((prev4 & 0xFFFFu) << 8);
-        if (R) {  // the chain indexes C1 by slot, not by byte value
-            u32 r1 = __shfl_up(rowv, 1u), r2 = __shfl_up(rowv, 2u);
-            r1 = lane >= 1 ? r1 : hrow1;
-            r2 = lane >= 2 ? r2 : (lane == 1 ? hrow1 : hrow2);
-            packed = mine | (r1 << 8) | (r2 << 16);
-        }
-        // run flag of byte i (:367-372): set iff i >= 2 and the four preceding bytes are equal
-        const u32 i = base + (u32)lane;
-        const bool fr = (u32)lane < cnt && i >= 2 && (prev4 & 0xFFu) == ((prev4 >> 8) & 0xFFu) && (prev4 & 0xFFFFu) == (prev4 >> 16);
-        const u32 fmask = (u32)__ballot(fr);
-        if (cnt == CM_CHUNK) cm_model_chunk<true>(m, ev, ring, packed, fmask, cnt, base, chain_lane, hibit, shr, bitpos, lvl);
-        else cm_model_chunk<false>(m, ev, ring, packed, fmask, cnt, base, chain_lane, hibit, shr, bitpos, lvl);
-        // history for the next chunk (only needed after a full chunk): byte -d of the next chunk = byte cnt-d of this one
-        if (cnt == CM_CHUNK) {
-            hist = cm_readlane(mine, (int)CM_CHUNK - 1) | (cm_readlane(mine, (int)CM_CHUNK - 2) << 8) | (cm_readlane(mine, (int)CM_CHUNK - 3) << 16) |
-                   (cm_readlane(mine, (int)CM_CHUNK - 4) << 24);
-            if (R) {
-                hrow1 = cm_readlane(rowv, (int)CM_CHUNK - 1);
-                hrow2 = cm_readlane(rowv, (int)CM_CHUNK - 2);
-            }
-        }
-        lds_release();
-        if (lane == 0) LDS_POKE(s_prod, base + cnt);
-    }
-}
-
 // One block.  R = 0: whole model in LDS; R > 0: row cache (see above).
 template <int R>
 __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__ jobs) {
     static_assert(R == 0 || R >= (int)CM_CHUNK + 4, "a chunk pins up to CM_CHUNK + 2 rows: the cache must hold more than that");
     // one workgroup per block: blockIdx.x selects the job
+    const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 n = jobs[blockIdx.x].n;
     u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
     u32 * __restrict__ out_size = global_ptr<u32>(jobs[blockIdx.x].out_size);
@@ -560,7 +479,78 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     // its batches are small.)
     const u32 role = cm_uniform((u32)wave_id()) ^ ((blockIdx.x >> CM_ENC_SWAP_SHIFT) & 1u);
     if (role != 0) {
-        cm_encode_model_wave<R>(jobs, blockIdx.x, m, ring, ev, s_prod, s_cons, rc, debug);
+        if (debug == 1) return;
+        // ---- model wave ------------------------------------------------------------------------------
+        // Lanes 0..7 walk the counter chain, one tree LEVEL each: the node of a level is picked by the byte (hibit | byte >> shr), its
+        // three counters are read from LDS, updated and written back in program order -- the LDS serves a wave's requests in order,
+        // so a counter that is hit again by the next byte needs no forwarding.  (Rounds 1-2 gave every NODE a lane and C0 a
+        // register, which took three waves of which 8 lanes were busy; at three blocks per CU those ~125 wave instructions per
+        // byte, not the coder's ~60, were what the SIMDs ran out of: round 3.)
+        const u32 lvl = (u32)lane & 7u;
+        const u32 hibit = 1u << lvl, shr = 8u - lvl, bitpos = 7u - lvl;
+        const bool chain_lane = lane < 8;
+        u32 cons_seen = 0;
+        u32 hist = 0;  // the 4 bytes before the chunk, oldest in the top byte (zeros before the block starts)
+        CmRowState rs;
+        u16 * __restrict__ spill = global_ptr<u16>(jobs[blockIdx.x].spill);
+        const u32 miss_base = jobs[blockIdx.x].miss_base, miss_shift = jobs[blockIdx.x].miss_shift;
+        // In-place coding: giving a block up is only possible while the coded bytes cannot have reached the input
+        // yet (the full-model kernel will read that input again): output <= bz3_bound(position) < gap.
+        const u32 gap = jobs[blockIdx.x].gap;
+        const u32 abort_limit = gap == CM_NO_GAP ? 0xFFFFFFFFu : (gap > 4096u ? (u32)(((u64)(gap - 2048u) * 32u) / 33u) : 0u);
+        u32 hrow1 = 0, hrow2 = 0;  // slots of bytes -1 and -2 (byte value 0 before the block starts: slot 0)
+        if (R) cm_rows_init<R>(rc);
+        for (u32 base = 0; base < n; base += CM_CHUNK) {
+            const u32 cnt = (n - base < CM_CHUNK) ? n - base : CM_CHUNK;
+            while (debug != 2 && base + cnt - cons_seen > CM_RING) {  // ring full: wait for the coder
+                cons_seen = LDS_PEEK(s_cons);
+                if (base + cnt - cons_seen > CM_RING) BZ3_SPIN_PAUSE();
+            }
+            // lane r holds byte r of the chunk together with its 4 predecessors
+            const u32 mine = ((u32)lane < cnt) ? in[base + lane] : 0u;
+            u32 rowv = 0;
+            if (R) {
+                rowv = cm_rows_chunk<R, 4>(m, rc, rs, spill, mine, cnt, hrow1, hrow2, (u32)lane);  // (the wave moves whole rows: four cells per lane)
+                if (__builtin_expect(rs.misses > miss_base + (base >> miss_shift) && base < abort_limit, 0)) {
+                    // the working set does not fit: give the block up
+                    if (lane == 0) *global_ptr<u32>(jobs[blockIdx.x].status) = 1u;
+                    LDS_POKE(s_prod, CM_ABORT_MARK);
+                    return;
+                }
+            }
+            u32 prev4 = 0;  // bytes r-1, r-2, r-3, r-4 in bits 0-7, 8-15, 16-23, 24-31
+#pragma unroll
+            for (int d = 1; d <= 4; d++) {
+                const u32 up = __shfl_up(mine, (unsigned)d);
+                // lanes < d reach back into the previous chunk: hist holds byte -1 in bits 0-7 ... byte -4 in bits 24-31
+                const u32 h = (hist >> (8u * (((u32)d - 1u - (u32)lane) & 3u))) & 0xFFu;
+                prev4 |= (((u32)lane >= (u32)d) ? up : h) << (8 * (d - 1));
+            }
+            u32 packed = mine | ((prev4 & 0xFFFFu) << 8);
+            if (R) {  // the chain indexes C1 by slot, not by byte value
+                u32 r1 = __shfl_up(rowv, 1u), r2 = __shfl_up(rowv, 2u);
+                r1 = lane >= 1 ? r1 : hrow1;
+                r2 = lane >= 2 ? r2 : (lane == 1 ? hrow1 : hrow2);
+                packed = mine | (r1 << 8) | (r2 << 16);
+            }
+            // run flag of byte i (:367-372): set iff i >= 2 and the four preceding bytes are equal
+            const u32 i = base + (u32)lane;
+            const bool fr = (u32)lane < cnt && i >= 2 && (prev4 & 0xFFu) == ((prev4 >> 8) & 0xFFu) && (prev4 & 0xFFFFu) == (prev4 >> 16);
+            const u32 fmask = (u32)__ballot(fr);
+            if (cnt == CM_CHUNK) cm_model_chunk<true>(m, ev, ring, packed, fmask, cnt, base, chain_lane, hibit, shr, bitpos, lvl);
+            else cm_model_chunk<false>(m, ev, ring, packed, fmask, cnt, base, chain_lane, hibit, shr, bitpos, lvl);
+            // history for the next chunk (only needed after a full chunk): byte -d of the next chunk = byte cnt-d of this one
+            if (cnt == CM_CHUNK) {
+                hist = cm_readlane(mine, (int)CM_CHUNK - 1) | (cm_readlane(mine, (int)CM_CHUNK - 2) << 8) | (cm_readlane(mine, (int)CM_CHUNK - 3) << 16) |
+                       (cm_readlane(mine, (int)CM_CHUNK - 4) << 24);
+                if (R) {
+                    hrow1 = cm_readlane(rowv, (int)CM_CHUNK - 1);
+                    hrow2 = cm_readlane(rowv, (int)CM_CHUNK - 2);
+                }
+            }
+            lds_release();
+            if (lane == 0) LDS_POKE(s_prod, base + cnt);
+        }
         return;
     }
     // ---- coder wave: ONE active lane (an LDS read then returns 16 bytes, not 64 x 16) ------------------------
@@ -671,191 +661,9 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     out_size[1] = sink.sw;
 }
 
-// ------------------------------------------------------------------------------------------------
-// encode, three blocks per WORKGROUP ("trio", round 4): the coder's recurrence is one lane's work, and a wave's instruction costs the
-// same whether one lane or three are live -- so the three blocks that share a CU's LDS anyway share ONE coder wave, lane b coding
-// block b, beside their three model waves.  Per byte the lone coder wave of a block issues ~57 instructions (~77 with the one byte
-// in four that is coded again in halves); three lanes in one wave pay them once per byte TRIPLE (and the slow path whenever any of
-// the three needs it).  The coder lanes are plain SIMT code: every lane has its own position, ring offset, published limit and sink,
-// a lane without published bytes sits the round out, and the model waves are the ones of the per-block kernels (cm_encode_model_wave).
-// ------------------------------------------------------------------------------------------------
-template <int R>
-struct alignas(16) CmEncBlockLds {  // what one block of a trio keeps in LDS
-    CmLdsT<R> m;
-    CmRing ring;                    // (16-byte aligned: sizeof(CmLdsT<R>) is a multiple of 16)
-    CmEvent ev[8 * CM_CHUNK];
-    u32 s_prod, s_cons;
-    CmRowCache<R> rc;
-};
-
-// cm_code_bits_checked for several live lanes: every lane renormalises on its own condition.
-template <int K0, int CNT>
-__device__ __forceinline__ void cm_code_bits_checked_lanes(const CmByteEvents & ev, u32 & range, u32 & low, CmSink & sink, u32 i) {
-#pragma unroll
-    for (int kk = K0; kk < K0 + CNT; kk++) {
-        const uint2 ek = ev.k[kk];
-        const u64 prod = (u64)range * ev.m[kk] + (((u64)ek.y << 32) | ek.x);
-        const u32 r2 = (u32)(prod >> 18);
-        low += (range - r2) & ek.x;
-        range = r2;
-        if (range < (1u << 24)) {  // necessary for (low ^ high) < 2^24
-            while ((low ^ (low + range)) < (1u << 24)) {  // :390-394
-                sink.put(low >> 24, i);
-                low <<= 8;
-                range = (range << 8) | 0xFFu;
-            }
-        }
-    }
-}
-
-template <int R>
-__device__ __forceinline__ void cm_encode_coder_lanes(const CmEncodeJob * __restrict__ jobs, const u32 job0, const u32 here, CmEncBlockLds<R> * __restrict__ blk) {
-    const int lane = lane_id();
-    if ((u32)lane >= here) return;
-    const CmEncodeJob * __restrict__ job = jobs + job0 + (u32)lane;
-    if ((job->debug & 15u) != 0u) return;  // profiling: the model waves alone (2); no lone-coder mode here (1: the workgroup does nothing)
-    cm_raise_priority();
-    CmEncBlockLds<R> & b = blk[lane];
-    const u32 n = job->n;
-    u32 * __restrict__ out_size = global_ptr<u32>(job->out_size);
-    CmSink sink{global_ptr<u8>(job->out), global_ptr<u8>(job->side), job->gap, job->side_cap, n};
-    u32 range = 0xFFFFFFFFu, low = 0u;
-    u32 koff = 0u;  // byte offset of the NEXT byte's events in the lane's ring.k (see cm_encode_block)
-    auto fetch = [&](CmByteEvents & e) __attribute__((always_inline)) {
-        const uint4 * __restrict__ pk = reinterpret_cast<const uint4 *>(reinterpret_cast<const u8 *>(b.ring.k) + koff);
-        const uint4 * __restrict__ pm = reinterpret_cast<const uint4 *>(reinterpret_cast<const u8 *>(b.ring.m) + (koff >> 1));
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint4 q = pk[j];
-            e.k[2 * j] = make_uint2(q.x, q.y);
-            e.k[2 * j + 1] = make_uint2(q.z, q.w);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const uint4 q = pm[j];
-            e.m[4 * j] = q.x; e.m[4 * j + 1] = q.y; e.m[4 * j + 2] = q.z; e.m[4 * j + 3] = q.w;
-        }
-    };
-    auto bucket_or_zero = [](u32 l, u32 r, u32 rmin) __attribute__((always_inline)) -> bool { return (l ^ (l + r)) < (1u << 24) || rmin == 0u; };
-    // One byte of every lane that calls it (cf. cm_encode_block's code_byte: 8 bits without a test, one bucket test, coded again in halves when it fires).
-    auto code_byte = [&](const CmByteEvents & ev, CmByteEvents & next, const u32 i) __attribute__((always_inline)) {
-        u32 r = range, l = low, rmin = 0xFFFFFFFFu;
-        cm_code_bits_raw<0, 4>(ev, r, l, rmin);
-        cm_sched_fence();
-        koff = (koff + 64u) & (CM_RING * 64u - 1u);
-        fetch(next);  // unconditional: a byte that is not there yet is fetched again once it has been published
-        cm_sched_fence();
-        const u32 r4 = r, l4 = l, rmin4 = rmin;
-        cm_code_bits_raw<4, 4>(ev, r, l, rmin);
-        const bool bad = bucket_or_zero(l, r, rmin);
-        const u32 range_old = range, low_old = low;
-        range = r;
-        low = l;
-        if (__builtin_expect(__ballot(bad) != 0ull, 0)) {  // some lane's byte: out of line
-            if (bad) {
-                range = range_old;
-                low = low_old;
-                if (!bucket_or_zero(l4, r4, rmin4)) {
-                    range = r4;
-                    low = l4;
-                } else {
-                    cm_code_bits_checked_lanes<0, 4>(ev, range, low, sink, i);
-                }
-                r = range, l = low, rmin = 0xFFFFFFFFu;
-                cm_code_bits_raw<4, 4>(ev, r, l, rmin);
-                if (!bucket_or_zero(l, r, rmin)) {
-                    range = r;
-                    low = l;
-                } else {
-                    cm_code_bits_checked_lanes<4, 4>(ev, range, low, sink, i);
-                }
-            }
-        }
-    };
-    CmByteEvents eva, evb;
-    u32 i = 0u, lim = 0u;  // bytes below lim are published (whole chunks of 32, the block's last one apart)
-    bool alive = true, gave_up = false;
-    for (;;) {
-        const bool edge = alive && i >= lim;  // this lane is through with what it knew of: once per chunk
-        if (__builtin_expect(__ballot(edge) != 0ull, 0)) {
-            if (edge) {
-                if (i >= n) {
-                    alive = false;
-                } else {
-                    const u32 p = LDS_PEEK(b.s_prod);
-                    if (R && p == CM_ABORT_MARK) {  // the model wave gave the block up
-                        alive = false;
-                        gave_up = true;
-                    } else if (p > i) {
-                        lds_acquire();
-                        lim = p < n ? p : n;
-                        fetch(eva);  // (again: the fetch behind the previous pair came before the chunk was published)
-                    }
-                }
-            }
-        }
-        const bool one = alive && i + 1u == lim;  // the last byte of a block of odd length (lim == n)
-        if (__builtin_expect(__ballot(one) != 0ull, 0)) {
-            if (one) {
-                code_byte(eva, evb, i);
-                i++;
-            }
-            continue;
-        }
-        if (__ballot(alive) == 0ull) break;
-        const bool pair0 = alive && i + 2u <= lim;
-        if (__ballot(pair0) == 0ull) {
-            BZ3_SPIN_PAUSE();
-            continue;
-        }
-        // The hot loop: pairs of bytes for as long as every lane that entered it with published bytes still has a pair -- a plain loop, the
-        // two register sets alternating.  Lanes that wait for their model wave are looked after every fourth trip.
-        const bool some_wait = __ballot(alive && !pair0) != 0ull;
-        bool pair = pair0;
-        u32 trips = 0;
-        do {
-            if (pair) {
-                code_byte(eva, evb, i);
-                code_byte(evb, eva, i + 1u);
-                i += 2u;
-                if ((i & 15u) == 0u) LDS_POKE(b.s_cons, i);
-            }
-            pair = pair0 && i + 2u <= lim;
-            trips++;
-        } while (__ballot(pair0 && !pair) == 0ull && !(some_wait && (trips & 3u) == 0u));
-    }
-    if (gave_up) return;
-    for (int j = 0; j < 4; j++) {  // flush (:425-432)
-        sink.put(low >> 24, n - 1u);
-        low <<= 8;
-    }
-    out_size[0] = sink.failed ? 0xFFFFFFFFu : sink.op;
-    out_size[1] = sink.sw;
-}
-
-// Blocks 3 * blockIdx.x .. + 2 of the batch (the last workgroup may hold fewer).
-template <int R>
-__device__ __forceinline__ void cm_encode_trio(const CmEncodeJob * __restrict__ jobs, const u32 njobs) {
-    static_assert(R >= (int)CM_CHUNK + 4, "a chunk pins up to CM_CHUNK + 2 rows: the cache must hold more than that");
-    __shared__ CmEncBlockLds<R> blk[3];
-    const u32 job0 = blockIdx.x * 3u;
-    const u32 here = njobs - job0 < 3u ? njobs - job0 : 3u;
-    if (threadIdx.x < 3u) {
-        blk[threadIdx.x].s_prod = 0;
-        blk[threadIdx.x].s_cons = 0;
-    }
-    for (u32 k = 0; k < 3u; k++) cm_model_init(blk[k].m);
-    const u32 role = cm_uniform((u32)wave_id());
-    if (role == 0u) return cm_encode_coder_lanes<R>(jobs, job0, here, blk);
-    const u32 k = role - 1u;
-    if (k >= here) return;
-    cm_encode_model_wave<R>(jobs, job0 + k, blk[k].m, blk[k].ring, blk[k].ev, blk[k].s_prod, blk[k].s_cons, blk[k].rc, jobs[job0 + k].debug & 15u);
-}
-
 constexpr int CM_ROWS_ENC = 96;   // 48 KiB of C1 rows: 79.5 KB of LDS per workgroup, two workgroups per CU
 constexpr int CM_ROWS_DEC = 96;   // 48 KiB of C1 rows: 72.1 KB of LDS per workgroup (112 rows = 80.6 KB: measured, two of those do NOT share a CU)
 constexpr int CM_ROWS3_ENC = 44;  // 22 KiB of C1 rows: 52.9 KB of LDS per workgroup, three workgroups per CU (a chunk pins up to 34 rows)
-constexpr int CM_ROWS3_TRIO = 52; // the trio kernel: three blocks of 53.2 KB in ONE workgroup (159.7 KB of the CU's 160)
 constexpr int CM_ROWS3_DEC = 56;  // 28 KiB of C1 rows: 50.8 KB of LDS per workgroup
 #ifdef BZ3_EMU
 constexpr int CM_ROWS_TEST = 40;  // emulator tests: small enough that short inputs recycle slots all the time
@@ -864,10 +672,8 @@ constexpr int CM_ROWS_TEST = 40;  // emulator tests: small enough that short inp
 __global__ void __launch_bounds__(128) k_cm_encode(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<0>(jobs); }
 __global__ void __launch_bounds__(128) k_cm_encode_rows(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<CM_ROWS_ENC>(jobs); }
 __global__ void __launch_bounds__(128) k_cm_encode_rows3(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<CM_ROWS3_ENC>(jobs); }
-__global__ void __launch_bounds__(256) k_cm_encode_trio(const CmEncodeJob * __restrict__ jobs, u32 njobs) { cm_encode_trio<CM_ROWS3_TRIO>(jobs, njobs); }
 #ifdef BZ3_EMU
 __global__ void __launch_bounds__(128) k_cm_encode_rows_test(const CmEncodeJob * __restrict__ jobs) { cm_encode_block<CM_ROWS_TEST>(jobs); }
-__global__ void __launch_bounds__(256) k_cm_encode_trio_test(const CmEncodeJob * __restrict__ jobs, u32 njobs) { cm_encode_trio<CM_ROWS_TEST>(jobs, njobs); }
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -1380,23 +1186,12 @@ __global__ void __launch_bounds__(320) k_cm_decode_sync3_prof(const CmDecodeJob 
 #ifdef BZ3_EMU
 __global__ void __launch_bounds__(320) k_cm_decode_sync_test(const CmDecodeJob * __restrict__ jobs) { cm_decode_sync_entry<CM_ROWS_TEST>(jobs); }
 #endif
-static std::atomic<int> g_cm_encode_trio{0};  // the three-per-CU encoder as the trio kernel (bz3_hip_debug_cm_encode_trio)
-static std::atomic<int> g_cm_trio_launches{0};
-int cm_set_encode_trio(int on) {
-    if (on >= 0) g_cm_encode_trio.store(on);
-    return g_cm_trio_launches.load();
-}
-
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant) {
     if (!njobs) return;
-    const bool trio = g_cm_encode_trio.load() != 0 && (variant == CM_VARIANT_ROWS3 || variant == CM_VARIANT_ROWS_TEST);
-    if (trio) g_cm_trio_launches.fetch_add(1);
 #ifdef BZ3_EMU
-    if (variant == CM_VARIANT_ROWS_TEST && trio) return launch(k_cm_encode_trio_test, dim3((njobs + 2u) / 3u), dim3(256), 0, s, d_jobs, njobs);
     if (variant == CM_VARIANT_ROWS_TEST) return launch(k_cm_encode_rows_test, dim3(njobs), dim3(128), 0, s, d_jobs);
 #endif
-    if (variant == CM_VARIANT_ROWS3 && trio) launch(k_cm_encode_trio, dim3((njobs + 2u) / 3u), dim3(256), 0, s, d_jobs, njobs);
-    else if (variant == CM_VARIANT_ROWS3) launch(k_cm_encode_rows3, dim3(njobs), dim3(128), 0, s, d_jobs);
+    if (variant == CM_VARIANT_ROWS3) launch(k_cm_encode_rows3, dim3(njobs), dim3(128), 0, s, d_jobs);
     else if (variant == CM_VARIANT_ROWS) launch(k_cm_encode_rows, dim3(njobs), dim3(128), 0, s, d_jobs);
     else launch(k_cm_encode, dim3(njobs), dim3(128), 0, s, d_jobs);
 }

@@ -137,7 +137,6 @@ constexpr size_t CM_SPILL_BYTES = 256 * 256 * 2;
 // round 4 found every block of such a batch coded twice.  Binary data misses on most bytes and is still given up within its first KiB.
 constexpr u32 CM_MISS_BASE = 1024, CM_MISS_SHIFT = 5;
 void cm_encode_batch(const CmEncodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL);
-int cm_set_encode_trio(int on);    // CM_VARIANT_ROWS3 encodes through the trio kernel (three blocks per workgroup sharing one coder wave)
 void cm_decode_batch(const CmDecodeJob * d_jobs, u32 njobs, hipStream_t s, int variant = CM_VARIANT_FULL, bool prof = false);  // prof: the sync decoders' cycle-counter build
 
 }  // namespace bz3

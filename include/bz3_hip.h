@@ -41,10 +41,6 @@ BZIP3_API int bz3_hip_set_cm_mode(int mode);
 /* Test hook: how many more code windows the suffix sorter gives groups that are too large for its in-LDS kernels before rank doubling
  * takes them (0 = none: straight to the deep path; k < 0 = the default, 1).  Output bytes do not depend on it. */
 BZIP3_API void bz3_hip_debug_bwt_big_rounds(int k);
-/* Experiment switch (round 4): variant 2 ENCODES through the "trio" kernel -- the three blocks that share a CU's LDS form one workgroup
- * and share ONE coder wave (lane b codes block b) beside their three model waves -- instead of three workgroups of two waves.
- * 0 = off (default), 1 = on, negative = leave as it is.  Returns the number of trio launches so far.  Output bytes do not depend on it. */
-BZIP3_API int bz3_hip_debug_cm_encode_trio(int on);
 /* Number of blocks the row-cache kernels have handed back to the full-model kernels so far (statistics). */
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void);
 
