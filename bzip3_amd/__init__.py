@@ -52,6 +52,7 @@ def _declare(L, strict=True):
         "bz3_hip_debug_bwt_big_rounds": (None, [C.c_int]),
         "bz3_hip_debug_peak_concurrent_groups": (C.c_int, [C.c_int]),
         "bz3_hip_debug_front_end_ring": (C.c_int, []),
+        "bz3_hip_debug_arena_swap_buffers": (C.c_int, [C.c_int]),
         "bz3_hip_cm_variant_for": (C.c_int, [C.c_int, C.c_int, C.c_int]),
         "bz3_hip_set_lean_states": (C.c_int, [C.c_int]),
         "bz3_hip_release_cached_memory": (None, []),

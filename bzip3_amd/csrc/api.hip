@@ -155,6 +155,7 @@ std::atomic<int> g_bound_device{-2};  // -2 = not initialised from the environme
 std::atomic<unsigned> g_rr{0};
 std::atomic<int> g_lean{-1};  // -1 = not read from the environment yet; see bz3_hip_set_lean_states
 std::atomic<int> g_front_end_ring{0};  // window | slots << 16 of the last encode_group (bz3_hip_debug_front_end_ring)
+std::atomic<int> g_arena_swaps{0};  // swap buffers served from the arena (bz3_hip_debug_arena_swap_buffers)
 std::atomic<unsigned> g_cm_given_up{0};  // blocks the row-cache CM kernels handed back to the full-model kernels (statistics)
 
 int device_count() {
@@ -428,6 +429,16 @@ inline bool sizes_fit(size_t buffer_size, s32 lzp_size, s32 rle_size, s32 orig_s
 }
 
 // Lean states own no swap buffer: they borrow one from the device's pool while a stage sequence needs it.
+// BZ3_HIP_KEEP_WS=1 (experiment, round 5's first measurement): a lean batch's workspace survives the call -- the decode call that follows reuses the
+// encode call's arena and carves the swap buffers of its tail windows from it -- instead of one hipFree and two multi-GB hipMallocs per round trip
+// (30-45 ms per GiB: profiles/r04_first_touch.txt).  Read once.
+inline bool keep_workspace() {
+    static const bool on = [] {
+        const char * e = getenv("BZ3_HIP_KEEP_WS");
+        return e && atoi(e) != 0;
+    }();
+    return on;
+}
 inline void lean_borrow(bz3_state * st) {
     if (st->lean && !st->d_swap) st->d_swap = st->ctx->temp_get(st->cap);
 }
@@ -755,7 +766,7 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     // device-synchronising hipFree per call would cost more than the memory is worth.
     size_t slack = (size_t)16 << 30;
     if (const char * e = getenv("BZ3_HIP_WS_KEEP_MB")) slack = (size_t)strtoull(e, nullptr, 10) << 20;  // tests only
-    if (lead->ctx->ws_cap > 2 * need + slack) {  // mostly LZP contexts of a large batch: hand the memory back (see above)
+    if (lead->ctx->ws_cap > 2 * need + slack && !(keep_workspace() && lead->lean)) {  // mostly LZP contexts of a large batch: hand the memory back (see above)
         HIP_CHECK(hipStreamSynchronize(s));  // the side streams are idle: every driver launch has been waited for
         (void)hipFree(lead->ctx->ws);
         lead->ctx->ws = nullptr;
@@ -1018,6 +1029,40 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
         tw[k].d_lz = lzp_in_window ? arena.take<LzpDecodeJob>(lzp_in_window) : nullptr;
         tw[k].luts = lzp_in_window ? arena.take<u32>(lzp_in_window * LZP_LUT_WORDS) : nullptr;
     }
+    // keep-workspace mode: the swap buffers the lean states of the windows in flight borrow come out of the arena -- the staging area of the CM
+    // rounds is free again by now -- as long as the per-block scratch of the stages (`need`) still fits behind them; the pool serves the rest
+    std::vector<u8 *> arena_swaps;
+    size_t swap_cap = 0;
+    if (keep_workspace() && any_lean) {
+        for (s32 i = 0; i < n; i++)
+            if (sts[i]->lean && sts[i]->cap > swap_cap) swap_cap = sts[i]->cap;
+        const size_t want = (size_t)tail_slots * (size_t)tail_window;
+        const size_t step = (swap_cap + 255) & ~(size_t)255;
+        const size_t keep_free = need + need / 32 + 65536;  // the per-block scratch of the stages and half of the slack arena_for adds
+        while (swap_cap && arena_swaps.size() < want && arena.cap - arena.used >= keep_free + step) arena_swaps.push_back(arena.take<u8>(swap_cap));
+    }
+    std::vector<char> from_arena((size_t)n, 0);
+    auto borrow = [&](s32 i) {
+        bz3_state * st = sts[i];
+        if (st->lean && !st->d_swap && !arena_swaps.empty() && st->cap <= swap_cap) {
+            st->d_swap = arena_swaps.back();
+            arena_swaps.pop_back();
+            from_arena[(size_t)i] = 1;
+            g_arena_swaps.fetch_add(1);
+        } else {
+            lean_borrow(st);
+        }
+    };
+    auto give_back = [&](s32 i) {
+        bz3_state * st = sts[i];
+        if (from_arena[(size_t)i]) {
+            if (st->d_swap) arena_swaps.push_back(st->d_swap);  // (a failure path may have dropped it already: lean_return of a buffer the pool does not know is a no-op)
+            st->d_swap = nullptr;
+            from_arena[(size_t)i] = 0;
+        } else {
+            lean_return(st);
+        }
+    };
     lead->ctx->ensure_aux();
     DrainOnUnwind drain{s, lead->ctx->aux, DeviceCtx::AUX};
     const s32 nwin = (n + tail_window - 1) / tail_window;
@@ -1041,7 +1086,7 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
                     continue;
                 }
                 if (st->pending != bz3_state::DEC_CODED) continue;
-                lean_borrow(st);
+                borrow(i);
                 if (!decode_unbwt(st, arena, cm_ms)) continue;
                 w.alive[(size_t)(i - w.w0)] = 1;
                 if (st->model & 2) {
@@ -1096,7 +1141,7 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
             }
             for (s32 i = w.w0; i < w.w1; i++) {
                 if (w.alive[(size_t)(i - w.w0)]) decode_finish(sts[i], arena);
-                lean_return(sts[i]);
+                give_back(i);
             }
         }
     }
@@ -1683,6 +1728,7 @@ BZIP3_API int bz3_hip_cm_variant_for(int device, int blocks, int encode) {
 }
 
 BZIP3_API int bz3_hip_debug_front_end_ring(void) { return g_front_end_ring.load(); }
+BZIP3_API int bz3_hip_debug_arena_swap_buffers(int reset) { return reset ? g_arena_swaps.exchange(0) : g_arena_swaps.load(); }
 
 BZIP3_API int bz3_hip_debug_peak_concurrent_groups(int reset) {
     const int v = g_groups_peak.load();

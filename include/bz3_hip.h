@@ -56,6 +56,9 @@ BZIP3_API int bz3_hip_debug_peak_concurrent_groups(int reset);
  * blocks per window | context slots << 16 | (workspace handed back when the call ended) << 30 (0 before the first call).  The serial LZP drivers of a window run on a side stream
  * while the whole-GPU stages of the other slots' windows run on the group's stream; the shape follows the free memory. */
 BZIP3_API int bz3_hip_debug_front_end_ring(void);
+/* Statistics of the keep-workspace experiment (environment BZ3_HIP_KEEP_WS=1: a lean batch's workspace survives the call and the decoder's tail carves
+ * its swap buffers from it): swap buffers served from the arena instead of the pool since the last reset. */
+BZIP3_API int bz3_hip_debug_arena_swap_buffers(int reset);
 
 /* Lean states (process-wide switch, read by bz3_new; environment BZ3_HIP_LEAN=1 has the same effect).  A state
  * normally owns its swap buffer (the reference's swap_buffer, bz3_bound(block_size) bytes of HBM) for life, so a

@@ -638,6 +638,62 @@ print("ok")
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-300:], r.stderr[-1200:])
 
 
+def test_keep_workspace_mode_reuses_the_arena_across_a_round_trip():
+    """BZ3_HIP_KEEP_WS=1 (experiment for round 5, api.hip keep_workspace): a lean batch's workspace is NOT handed back when the encode call ends, the
+    decode call that follows reuses it and carves the swap buffers of its tail windows from it (the pool serves what does not fit); blocks and
+    error codes are what they are without the switch.  Two round trips of 7 small lean blocks through windows of 2 x 3 (BZ3_HIP_TAIL_PIPE), a
+    failing block among them on the second.  (That the workspace of a LARGE batch stays is the `released` bit of
+    test_front_end_ring_follows_the_memory_and_shrinks_when_the_arena_does_not_fit; here the arena is small and stays either way.)"""
+    import subprocess
+
+    code = r'''
+import os, sys, ctypes as C
+sys.path[:0] = [%r, %r, %r]
+import bzip3_amd, datagen
+from build_emu import build
+from oracle_lib import Oracle
+lib = bzip3_amd._declare(C.CDLL(build()))
+o = Oracle()
+bs = 65 * 1024
+t = datagen.shakespeare()
+lib.bz3_hip_set_lean_states(1)
+os.environ["BZ3_HIP_WS_KEEP_MB"] = "0"
+n = 7
+blocks = [t[i * 700 : i * 700 + 2500 + 11 * i] for i in range(n)]
+states = (C.c_void_p * n)(*[lib.bz3_new(bs) for _ in range(n)])
+cap = lib.bz3_bound(bs) + 64
+for trip in range(2):
+    bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+    for b, d in zip(bufs, blocks):
+        C.memmove(b, d, len(d))
+    ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+    lib.bz3_encode_blocks(states, ptrs, sizes, n)
+    want = [o.encode_block(d, bs)[2] for d in blocks]
+    for i in range(n):
+        assert lib.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: sizes[i]]) == want[i], (trip, i)
+    if trip == 1:
+        bufs[4][sizes[4] // 2] ^= 0x55  # a corrupted payload: this block fails its CRC, its neighbours do not
+    bsz = (C.c_size_t * n)(*[cap] * n)
+    orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+    lib.bz3_hip_debug_arena_swap_buffers(1)
+    lib.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+    carved = lib.bz3_hip_debug_arena_swap_buffers(0)
+    assert (carved > 0) == (os.environ.get("BZ3_HIP_KEEP_WS") == "1"), carved
+    for i, d in enumerate(blocks):
+        if trip == 1 and i == 4:
+            assert lib.bz3_last_error(states[i]) != 0
+        else:
+            assert lib.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: len(d)]) == d, (trip, i)
+for s in states:
+    lib.bz3_free(s)
+print("ok")
+''' % (os.path.dirname(HERE), HERE, os.path.join(HERE, "emu"))
+    for keep in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BZ3_HIP_KEEP_WS=keep, BZ3_HIP_TAIL_PIPE="2,3"), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (keep, r.stdout[-300:], r.stderr[-1200:])
+
+
 def test_auto_cm_policy_and_encode_many_hook(oracle):
     """The automatic CM policy by batch size (api.hip cm_variant_for; BZ3_HIP_CUS=2 pretends the GPU has two CUs): up to one block per CU
     the whole-model kernels (0), up to two per CU the 96-row pair (1), beyond that the three-per-CU pair (2); a forced mode wins.  And the profiling hook that launches N copies of one CM encode job returns the oracle's bytes."""
