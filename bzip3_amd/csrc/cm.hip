@@ -144,7 +144,7 @@ constexpr u32 CM_ENC_SWAP_SHIFT = 0;
 #else
 constexpr u32 CM_ENC_SWAP_SHIFT = 9;
 #endif
-constexpr u32 CM_RING = 64;   // bytes of look-ahead between the model waves and the coder wave (8 KiB of LDS)
+constexpr u32 CM_RING = 64;   // bytes of look-ahead between the model waves and the coder wave (6 KiB of LDS: 8 events of 12 bytes per byte)
 constexpr u32 CM_CHUNK = 32;  // bytes per model-wave chunk
 
 #ifdef BZ3_EMU
@@ -661,9 +661,9 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     out_size[1] = sink.sw;
 }
 
-constexpr int CM_ROWS_ENC = 96;   // 48 KiB of C1 rows: 79.5 KB of LDS per workgroup, two workgroups per CU
+constexpr int CM_ROWS_ENC = 96;   // 48 KiB of C1 rows: 76,008 B of LDS per workgroup, two workgroups per CU
 constexpr int CM_ROWS_DEC = 96;   // 48 KiB of C1 rows: 72.1 KB of LDS per workgroup (112 rows = 80.6 KB: measured, two of those do NOT share a CU)
-constexpr int CM_ROWS3_ENC = 44;  // 22 KiB of C1 rows: 52.9 KB of LDS per workgroup, three workgroups per CU (a chunk pins up to 34 rows)
+constexpr int CM_ROWS3_ENC = 44;  // 22 KiB of C1 rows: 49,124 B of LDS per workgroup, three workgroups per CU (a chunk pins up to 34 rows)
 constexpr int CM_ROWS3_DEC = 56;  // 28 KiB of C1 rows: 50.8 KB of LDS per workgroup
 #ifdef BZ3_EMU
 constexpr int CM_ROWS_TEST = 40;  // emulator tests: small enough that short inputs recycle slots all the time
