@@ -573,14 +573,17 @@ __global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const LzpDecodeJob * __re
                 // hash context of o2: the 4 bytes before it are stage[lit .. lit+3]
                 const u32 ctx = ((u32)stage[12 + lit] << 24) | ((u32)stage[13 + lit] << 16) | ((u32)stage[14 + lit] << 8) | (u32)stage[15 + lit];
                 const u32 cand = atomicExch(&lut[lz_hash(ctx)], o2);  // read the slot (at L2, where the atomics landed) and visit o2
+                // the bytes behind the 0xF2 are normally part of the staged chunk: LDS instead of dependent ~1.5 us loads from HBM on the
+                // block's serial path (41 k sequencing points in a 256 MiB text block)
+                auto rd = [&](u32 x) -> u8 { return x - ip < chunk ? stage[16u + (x - ip)] : in[x]; };
                 if (cand > 0) {
                     i2++;
                     if (i2 == n) s_fail = 1;  // :215
-                    else if (in[i2] != 255) {
+                    else if (rd(i2) != 255) {
                         u32 len = LZ_MIN;
                         for (;;) {  // :218-222
                             if (i2 == n) { s_fail = 1; break; }
-                            const u8 b = in[i2++];
+                            const u8 b = rd(i2++);
                             len += b;
                             if (b != 254) break;
                         }
@@ -595,7 +598,7 @@ __global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const LzpDecodeJob * __re
                         out[o2++] = LZ_ESC;
                     }
                 } else {
-                    out[o2++] = in[i2++];
+                    out[o2++] = rd(i2++);
                 }
             }
             s_ip = i2;
