@@ -500,7 +500,16 @@ s32 lzp_encode(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s) {
 // ---- decode -------------------------------------------------------------------------------------
 constexpr int LZD_CHUNK = 16384;  // input bytes staged in LDS per iteration (16 per lane)
 
-__global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const LzpDecodeJob * __restrict__ jobs) {
+__device__ __forceinline__ u64 lz_clock() {
+#ifdef BZ3_EMU
+    return 0;
+#else
+    return (u64)__builtin_readcyclecounter();
+#endif
+}
+// PROF (BZ3_LZP_PROF=1, profiling only): lane 0 sums the cycles of a trip's four phases and prints them when the block is done.
+template <bool PROF>
+__device__ __forceinline__ void lzp_decode_block(const LzpDecodeJob * __restrict__ jobs) {
     const u8 * __restrict__ in = global_ptr<const u8>(jobs[blockIdx.x].in);
     const u32 n = jobs[blockIdx.x].n;
     u8 * __restrict__ out = global_ptr<u8>(jobs[blockIdx.x].out);
@@ -515,7 +524,10 @@ __global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const LzpDecodeJob * __re
     if (tid == 0) { s_ip = 4; s_op = 4; s_fail = 0; }
     __threadfence_block();
     __syncthreads();
+    u64 pc_stage = 0, pc_lits = 0, pc_lane0 = 0, pc_copy = 0, pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
+    u32 pc_trips = 0, pc_matches = 0;
     for (;;) {
+        if (PROF) pt0 = lz_clock();
         const u32 ip = s_ip, op = s_op;
         if (s_fail || ip >= n || op >= max_out) break;
         const u32 chunk = (n - ip > (u32)LZD_CHUNK) ? (u32)LZD_CHUNK : n - ip;
@@ -542,6 +554,7 @@ __global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const LzpDecodeJob * __re
         }
         if (first != 0xFFFFFFFFu && first >= chunk) first = 0xFFFFFFFFu;  // (the zero padding of a ragged lane holds no 0xF2, but be exact)
         first = block_min<LZ_DRV>(first, red);  // (also orders the LDS staging)
+        if (PROF) pt1 = lz_clock();
         const bool hit = first != 0xFFFFFFFFu;
         u32 lit = hit ? first : chunk;
         bool room = true;
@@ -566,6 +579,7 @@ __global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const LzpDecodeJob * __re
         }
         __threadfence_block();
         __syncthreads();
+        if (PROF) pt2 = lz_clock();
         if (tid == 0) {
             u32 i2 = ip + lit, o2 = op + lit;
             s_copy_cnt = 0;
@@ -606,6 +620,7 @@ __global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const LzpDecodeJob * __re
         }
         __threadfence_block();
         __syncthreads();
+        if (PROF) pt3 = lz_clock();
         const u32 cnt = s_copy_cnt;
         if (cnt) {
             const u32 dst = s_op, src = s_copy_src;
@@ -616,15 +631,28 @@ __global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const LzpDecodeJob * __re
             if (tid == 0) s_op = dst + cnt;
             __syncthreads();
         }
+        if (PROF) {
+            const u64 pt4 = lz_clock();
+            pc_stage += pt1 - pt0; pc_lits += pt2 - pt1; pc_lane0 += pt3 - pt2; pc_copy += pt4 - pt3;
+            pc_trips++;
+            pc_matches += cnt ? 1u : 0u;
+        }
     }
     if (tid == 0) *result = s_fail ? -1 : (s32)s_op;
+    if (PROF && tid == 0)
+        printf("[bz3 lzp-decode prof] n=%u trips=%u matches=%u cycles: stage+search %llu  literals+inserts+fence %llu  lane0+fence %llu  copy %llu\n", n, pc_trips, pc_matches,
+               (unsigned long long)pc_stage, (unsigned long long)pc_lits, (unsigned long long)pc_lane0, (unsigned long long)pc_copy);
 }
+__global__ void __launch_bounds__(LZ_DRV) k_lzp_decode(const LzpDecodeJob * __restrict__ jobs) { lzp_decode_block<false>(jobs); }
+__global__ void __launch_bounds__(LZ_DRV) k_lzp_decode_prof(const LzpDecodeJob * __restrict__ jobs) { lzp_decode_block<true>(jobs); }
 
 void lzp_decode_batch(const LzpDecodeJob * h_jobs, LzpDecodeJob * d_jobs, u32 njobs, hipStream_t s) {
     if (!njobs) return;
     for (u32 i = 0; i < njobs; i++) HIP_CHECK(hipMemsetAsync(reinterpret_cast<void *>(h_jobs[i].lut), 0, LZP_LUT_WORDS * sizeof(u32), s));
     HIP_CHECK(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LzpDecodeJob) * njobs, hipMemcpyHostToDevice, s));
-    launch(k_lzp_decode, dim3(njobs), dim3(LZ_DRV), 0, s, (const LzpDecodeJob *)d_jobs);
+    static const bool prof = [] { const char * e = getenv("BZ3_LZP_PROF"); return e && atoi(e) != 0; }();  // (profiling only, read once)
+    if (prof) launch(k_lzp_decode_prof, dim3(njobs), dim3(LZ_DRV), 0, s, (const LzpDecodeJob *)d_jobs);
+    else launch(k_lzp_decode, dim3(njobs), dim3(LZ_DRV), 0, s, (const LzpDecodeJob *)d_jobs);
 }
 
 }  // namespace bz3
