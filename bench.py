@@ -319,6 +319,24 @@ def cpu_quota():
         return None
 
 
+def effective_cpus(threads):
+    """CPUs that `threads` busy threads really get: the thread count, capped by the cgroup quota and the logical CPUs."""
+    q = cpu_quota()
+    cap = min(float(os.cpu_count() or 1), q if q else float("inf"))
+    e = min(float(threads), cap)
+    return int(e) if e == int(e) else round(e, 2)
+
+
+def sharding_model(world):
+    """Block sharding quantises (block k -> GPU k mod G, a GPU's time = its block count x one block's latency when the
+    blocks are fewer than fill it): predicted efficiency of BASELINE's multi-GPU configs = blocks / (G x ceil(blocks / G))."""
+    def eff(blocks, g):
+        return round(blocks / (g * -(-blocks // g)), 4)
+    return {"this_run": f"weak scaling: every rank codes its own GPU-filling batch, so the predicted efficiency at {world} GPU(s) is 1.0 (no collective, no shared resource but the host)",
+            "cfg4_linux_tarball_5_blocks_8_gpus": eff(5, 8), "cfg5_8GiB_17_blocks_8_gpus": eff(17, 8),
+            "note": "few-block inputs are bound by ONE block's CM latency on one CU whatever the GPU count: 5 blocks on 8 GPUs = 62.5 %, 17 on 8 = 70.8 % (17 / 24)"}
+
+
 def host_mem_available():
     try:
         with open("/proc/meminfo") as fh:
@@ -408,7 +426,11 @@ def reference_round_trip(sample_blocks, block_size, keep_encoded=False, lib_path
             L.bz3_free(s)
         assert ok, "reference round trip failed"
         t_enc, t_dec = t1 - t0, t2 - t1b
-        rec = {"value": round(total / 2 ** 20 / (t_enc + t_dec), 3), "unit": "MiB/s", "cores": n, "kind": "reference",
+        v = total / 2 ** 20 / (t_enc + t_dec)
+        eff = effective_cpus(n)
+        # "cores" = the CPUs that did the work: n threads, but never more than the container's cgroup quota lets run at once
+        # (64 threads on a 16-CPU quota are 16 CPUs' worth of the reference, not 64)
+        rec = {"value": round(v, 3), "unit": "MiB/s", "cores": eff, "threads": n, "effective_cpus": eff, "MiBps_per_cpu": round(v / eff, 3), "kind": "reference",
                "sample": f"{n} x {len(sample_blocks[0]) / 2 ** 20:.0f} MiB blocks (the GPU's blocks 0..{n - 1}), one pass of bz3_encode_blocks + "
                          f"bz3_decode_blocks of the {label} reference, one thread per block",
                "t_enc_s": round(t_enc, 2), "t_dec_s": round(t_dec, 2), "host_cpu": model, "host_cores": ncpu, "cpu_quota_cpus": cpu_quota()}
@@ -420,7 +442,7 @@ def reference_round_trip(sample_blocks, block_size, keep_encoded=False, lib_path
     k, err2, back = o.decode_block(blk, len(d), max(len(d), 65 * 1024))
     t1 = time.perf_counter()
     assert err == 0 and err2 == 0 and back == d
-    return {"value": round(len(d) / 2 ** 20 / (t1 - t0), 3), "unit": "MiB/s", "cores": 1, "kind": "port",
+    return {"value": round(len(d) / 2 ** 20 / (t1 - t0), 3), "unit": "MiB/s", "cores": 1, "threads": 1, "effective_cpus": 1, "MiBps_per_cpu": round(len(d) / 2 ** 20 / (t1 - t0), 3), "kind": "port",
             "sample": "one 4 MiB text block through oracle/bz3_oracle.c (oracle/_ref absent)", "host_cpu": model, "host_cores": ncpu}, None
 
 
@@ -829,6 +851,8 @@ def main():
                 "block_bytes": block_size,
                 "blocks_per_gpu": nblk,
                 "parallelism": f"blocks sharded over {world} GPU(s), no collective",
+                "sharding_model": sharding_model(world),
+                "legs": {},  # the scalars of the extra legs (filled as they finish; the driver's record keeps `config`, not `configs`)
                 "compressed_ratio": round((nblk * block_size) / max(1, comp_total), 3),
                 "cm_mode": a.cm_mode,
                 "lean_states": bool(lean),
@@ -866,10 +890,17 @@ def main():
             "cpu_baseline": {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": "not run (budget, --no-cpu-baseline, --leg or N > 1)"},
         }
         RESULT["line"] = out
+        if a.leg == "cfg5":
+            out["config"]["legs"]["cfg5_round_trip_MiBps"] = out["value"]
 
     # ---- extra legs (rank 0 at N=1; the watchdog prints the line without them if they overrun) ----------------------------
     def left_s():
         return a.budget_s - elapsed()
+
+    def leg(name, v):
+        """a leg's scalar where the driver's record keeps it (config.legs)"""
+        if RESULT["line"] is not None and v is not None:
+            RESULT["line"]["config"]["legs"][name] = v
 
     def round_trip(sel, sizes_in, host=None):
         """encode + decode of blocks `sel` of the batch (device pointers; host: a list of host buffers instead, through
@@ -919,6 +950,7 @@ def main():
 
     live_states = nblk
     random_host = None
+    mixed_host = None
     if extras_wanted and a.kind == "text" and left_s() > 200.0:
         # ---- random: incompressible blocks, as many as the timed batch had (LZP and RLE decline, model 0, ~1.004 bytes per byte) ----
         rb = int(a.random_block_mib * (1 << 20))
@@ -945,6 +977,8 @@ def main():
                 "value": round(nr * rb / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
                 "compressed_ratio": round(nr * rb / sum(coded), 4),
                 "cm_blocks_given_up": "all (256 live order-1 rows: the row-cache kernels hand every block to the whole-model kernels, up to one per CU at a time)"}
+            leg("random_MiBps", RESULT["line"]["configs"]["random"]["value"])
+            leg("random_block_MiB", a.random_block_mib)
             progress(f"random: {RESULT['line']['configs']['random']['value']} MiB/s")
 
     if extras_wanted and a.kind == "text" and nblk > 160 and left_s() > 60.0:
@@ -963,6 +997,10 @@ def main():
             bufs[k][:mb] = walk.view(torch.uint8)
             bufs[sel[2 * per + j]][:mb] = torch.randint(0, 256, (mb,), dtype=torch.uint8, generator=g, device=device)
         fpm = [fingerprint(torch, bufs[k][:mb]) for k in sel]
+        if want_cpu and host_mem_available() > 3 * len(sel) * mb:  # the same 96 blocks for the reference (run later, when the host is free again)
+            mixed_host = SharedBlocks("bz3_bench_mixed", [mb] * len(sel))
+            for j, k in enumerate(sel):
+                mixed_host.put_tensor(torch, j, bufs[k])
         before = int(lib.bz3_hip_cm_blocks_given_up())
         te, td, coded = round_trip(sel, [mb] * len(sel))
         assert all(fingerprint(torch, bufs[k][:mb]) == f for k, f in zip(sel, fpm)), "mixed: round trip changed the data"
@@ -972,6 +1010,7 @@ def main():
             "compressed_ratio": {"text": round(per * mb / sum(coded[:per]), 3), "binary": round(per * mb / sum(coded[per : 2 * per]), 3),
                                  "random": round(per * mb / sum(coded[2 * per :]), 4)},
             "cm_blocks_given_up": int(lib.bz3_hip_cm_blocks_given_up()) - before}
+        leg("mixed_MiBps", RESULT["line"]["configs"]["mixed"]["value"])
         progress(f"mixed: {RESULT['line']['configs']['mixed']['value']} MiB/s, {RESULT['line']['configs']['mixed']['cm_blocks_given_up']} blocks given up by the row-cache kernels")
 
     # ---- cpu_baseline: started after the timed steps, collected here (the legs above used the GPU only) ----------------
@@ -981,15 +1020,20 @@ def main():
             rec = res["rec"]
             ref_choice.update(label=res.get("ref_label") or "gcc -O2", path=res.get("ref_path"))
             rec["build_probe_1_thread_8MiB_MiBps"] = res.get("probe", {})
-            rec["threads_note"] = ("64 threads: the reference's CLI caps -j at 64 (src/main.c:213); one thread per block as in bz3_encode_blocks (src/libbz3.c:845-856).  "
-                                   "cpu_quota_cpus is what the container may use at once (cgroup): on the round-4 GPU boxes 16 of the 256 logical CPUs, where 64, 32 and 16 threads "
-                                   "give the same rate within 8 % (profiles/r04_cpu_threads_probe.json)")
+            rec["threads_note"] = ("threads = 64: the reference's CLI caps -j at 64 (src/main.c:213); one thread per block as in bz3_encode_blocks (src/libbz3.c:845-856).  "
+                                   "cores = effective_cpus = min(threads, cpu_quota_cpus): what the container may run at once (cgroup) -- on the round-4 GPU boxes 16 of the 256 "
+                                   "logical CPUs, where 64, 32 and 16 threads give the same rate within 8 % (profiles/r04_cpu_threads_probe.json).  gpu_over_cpu compares with those "
+                                   "effective CPUs, not with an unthrottled -j 64; gpu_equivalent_cpus = GPU MiB/s / (reference MiB/s per effective CPU)")
             rec["process"] = f"a process of its own (no torch, no HIP runtime), pinned to {res.get('pinned_to_cpus', 0)} cores; started after the timed steps, while the GPU ran legs that use no host cores"
             rec["gpu_over_cpu"] = round(RESULT["line"]["value"] / rec["value"], 3) if rec.get("value") else None
+            # one MI355X with a GPU-filling batch in flight = this many of the host's CPUs running the reference
+            rec["gpu_equivalent_cpus"] = round(RESULT["line"]["value"] / rec["MiBps_per_cpu"], 1) if rec.get("MiBps_per_cpu") else None
+            leg("gpu_over_cpu_threads", rec["gpu_over_cpu"])
+            leg("gpu_equivalent_cpus", rec["gpu_equivalent_cpus"])
             if "parity_same" in res:
                 rec["parity"] = f"{res['parity_same']} of {res['parity_of']} blocks of {cpu_block >> 20} MiB: the GPU's coded bytes are identical to the reference's"
             RESULT["line"]["cpu_baseline"] = rec
-            progress(f"cpu_baseline: {rec['value']} MiB/s on {rec['cores']} threads ({ref_choice['label']}); {rec.get('parity', '')}")
+            progress(f"cpu_baseline: {rec['value']} MiB/s on {rec['threads']} threads = {rec['effective_cpus']} effective CPUs ({ref_choice['label']}); {rec.get('parity', '')}")
             assert res.get("parity_same") == res.get("parity_of"), "GPU output differs from the reference: " + rec.get("parity", "")
         else:
             RESULT["line"]["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": "not run: " + res.get("err", "?")}
@@ -1004,10 +1048,25 @@ def main():
         if "rec" in res:
             rec["cpu"] = res["rec"]
             rec["vs_cpu"] = round(rec["value"] / res["rec"]["value"], 3)
-            progress(f"random: reference on {res['rec']['cores']} threads: {res['rec']['value']} MiB/s")
+            leg("random_vs_cpu", rec["vs_cpu"])
+            progress(f"random: reference on {res['rec']['threads']} threads: {res['rec']['value']} MiB/s")
         else:
             rec["cpu"] = {"value": None, "sample": "failed: " + res.get("err", "?")}
         random_host.close()
+
+    if mixed_host is not None and "mixed" in RESULT["line"]["configs"] and left_s() > 150.0:
+        res = ref_beside(mixed_host.meta(), 32 << 20).result()
+        rec = RESULT["line"]["configs"]["mixed"]
+        if "rec" in res:
+            rec["cpu"] = res["rec"]
+            rec["vs_cpu"] = round(rec["value"] / res["rec"]["value"], 3)
+            leg("mixed_vs_cpu", rec["vs_cpu"])
+            progress(f"mixed: reference on {res['rec']['threads']} threads: {res['rec']['value']} MiB/s")
+        else:
+            rec["cpu"] = {"value": None, "sample": "failed: " + res.get("err", "?")}
+    if mixed_host is not None:
+        mixed_host.close()
+        mixed_host = None
 
     if extras_wanted and a.kind == "text" and left_s() > 200.0:
         # (after the reference process has finished: the stage hooks wait for the stream between launches, and a host whose CPU quota 64
@@ -1033,6 +1092,7 @@ def main():
                 "value": round(ALG_BYTES_BWT * n5 / (ms_inv * 1e-3) / 1e9, 3), "unit": "GB/s (11 algorithmic bytes per byte, SURVEY.md 8d)",
                 "ms": round(ms_inv, 2), "MiBps": round(511.0 / (ms_inv * 1e-3), 1), "frac_of_hbm_peak": round(ALG_BYTES_BWT * n5 / (ms_inv * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                 "forward_bwt_ms": round(ms_fwd, 2), "forward_bwt_GBps": round(ALG_BYTES_BWT * n5 / (ms_fwd * 1e-3) / 1e9, 3)}
+            leg("cfg5_unbwt_GBps", RESULT["line"]["configs"]["cfg5_unbwt"]["value"])
             progress(f"cfg5_unbwt: inverse BWT of a 511 MiB block in {ms_inv:.1f} ms (forward {ms_fwd:.1f} ms)")
             del src5, u5, back5
             lib.bz3_hip_release_cached_memory()
@@ -1054,6 +1114,7 @@ def main():
                "value": round(total_bytes_ / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
                "compressed_ratio": round(total_bytes_ / sum(coded), 3)}
         RESULT["line"]["configs"][name] = rec
+        leg(f"{name}_MiBps", rec["value"])
         progress(f"{name}: {rec['value']} MiB/s (enc {te:.1f}s dec {td:.1f}s)")
         if w is not None:
             res = w.result()
@@ -1062,6 +1123,7 @@ def main():
                 r["sample"] = f"reference -j {nb} ({ref_choice['label']}): bz3_encode_blocks + bz3_decode_blocks on the same {nb} blocks, {nb} threads of a process of its own, timed while the GPU coded them"
                 rec[f"cpu_j{nb}"] = r
                 rec[f"vs_cpu_j{nb}"] = round(rec["value"] / r["value"], 3)
+                leg(f"{name}_vs_cpu_j{nb}", rec[f"vs_cpu_j{nb}"])
                 progress(f"{name}: reference -j {nb} on the host: {r['value']} MiB/s")
             else:
                 rec[f"cpu_j{nb}"] = {"value": None, "sample": "failed: " + res.get("err", "?")}
@@ -1111,6 +1173,7 @@ def main():
                 "value": round(nh * hb / 2 ** 20 / (te_h + td_h), 3), "unit": "MiB/s", "t_enc_s": round(te_h, 2), "t_dec_s": round(td_h, 2),
                 "device_resident": {"value": round(nh * hb / 2 ** 20 / (te_d + td_d), 3), "t_enc_s": round(te_d, 2), "t_dec_s": round(td_d, 2)},
                 "pcie_inclusive_over_device_resident": round((te_d + td_d) / (te_h + td_h), 4)}
+            leg("host_api_ratio", RESULT["line"]["configs"]["host_api"]["pcie_inclusive_over_device_resident"])
             progress(f"host_api: {RESULT['line']['configs']['host_api']['value']} MiB/s through host buffers, x{RESULT['line']['configs']['host_api']['pcie_inclusive_over_device_resident']} of device-resident")
             del host
         else:

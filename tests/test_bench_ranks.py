@@ -31,6 +31,10 @@ def _check(d, world):
     nbytes = world * 2 * int(0.003 * (1 << 20)) * d["steps"]  # every rank's blocks count: the whole job's aggregate
     assert abs(d["value"] - nbytes / 2 ** 20 / sum(d["step_s"])) <= 0.02 * d["value"] + 1e-3
     assert d["config"]["blocks_per_gpu"] == 2 and d["cpu_baseline"]["value"] is None
+    # what the driver's record keeps of the legs and of the sharding model lives under `config`
+    sm = d["config"]["sharding_model"]
+    assert sm["cfg4_linux_tarball_5_blocks_8_gpus"] == 0.625 and sm["cfg5_8GiB_17_blocks_8_gpus"] == round(17 / 24, 4)
+    assert d["config"]["legs"] == {} and str(world) in sm["this_run"]
 
 
 def test_bench_spawns_its_own_ranks_and_rank_0_reports_the_aggregate():
@@ -48,6 +52,18 @@ def test_bench_under_torch_distributed_run_as_the_driver_launches_it():
     _check(d, 2)
 
 
+def test_bench_eight_ranks_as_on_the_8_gpu_node():
+    """World 8 (the node the driver's SCALE run uses): eight ranks under torch.distributed.run, gloo, the emulated kernels -- the control
+    flow of the N = 8 line (barriers, max-over-ranks, rank 0's aggregate), nothing measured."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    d, err = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                   "bench.py", "--gpus", "8"] + ARGS)
+    _check(d, 8)
+    assert "8 GPU(s)" in d["config"]["parallelism"] and err.count("encode_blocks done") == 2
+
+
 def test_bench_single_rank_on_the_emulator():
     d, _ = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS)
     _check(d, 1)
@@ -61,3 +77,4 @@ def test_bench_cfg5_leg_control_flow_on_the_emulator():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert "leg cfg5" in d["metric"] and d["steps"] == 1 and d["cpu_baseline"]["value"] is None and d["configs"] == {}
+    assert d["config"]["legs"] == {"cfg5_round_trip_MiBps": d["value"]}
