@@ -1941,6 +1941,29 @@ BZIP3_API int32_t bz3_hip_stage_unbwt(const uint8_t * in, uint8_t * out, int32_t
     });
 }
 
+// Tests only: the stable LSD radix sort of sort.hip on host buffers -- (keys[i], i) sorted over key bits [0, key_bits) with digits of
+// digit_bits (8 or 9) bits; passes of up to RS_RAW_TILES tiles take the scatter that reads the raw count table (round 5), larger ones
+// the scanned table.  Returns the number of passes, -1 on bad arguments.
+BZIP3_API int32_t bz3_hip_debug_sort_u32(const uint32_t * keys, uint32_t n, int key_bits, int digit_bits, uint32_t * sorted_keys, uint32_t * sorted_index) {
+    return stage_guard([&]() -> s32 {
+        if ((digit_bits != 8 && digit_bits != 9) || key_bits < 1 || key_bits > 32 || n == 0) return -1;
+        StageEnv e;
+        u32 * k[2] = {(u32 *)e.dev((size_t)n * 4 + 64, keys, (size_t)n * 4), (u32 *)e.dev((size_t)n * 4 + 64)};
+        u32 * v[2] = {(u32 *)e.dev((size_t)n * 4 + 64), (u32 *)e.dev((size_t)n * 4 + 64)};
+        Arena a = e.ctx->arena_for(radix_temp_bytes(n, digit_bits) + (1u << 20));
+        int cur = 0, passes = 0;
+        for (int shift = 0; shift < key_bits; shift += digit_bits, passes++) {
+            const u32 * vin = passes ? v[cur] : nullptr;  // the first pass generates the indices
+            if (digit_bits == 9) radix_pass_bits<u32, 9>(k[cur], k[cur ^ 1], vin, v[cur ^ 1], n, shift, 0xFFFFFFFFu, 0u, a, e.s);
+            else radix_pass<u32>(k[cur], k[cur ^ 1], vin, v[cur ^ 1], n, shift, 0xFFFFFFFFu, 0u, a, e.s);
+            cur ^= 1;
+        }
+        e.down(sorted_keys, k[cur], (size_t)n * 4);
+        e.down(sorted_index, v[cur], (size_t)n * 4);
+        return passes;
+    });
+}
+
 // One CM job through the variant the current mode selects (auto = full model for a single block); a block the
 // row-cache kernel gives up is coded again by the full-model kernel, as in run_cm_jobs.
 extern "C++" template <class Job, class Launch>

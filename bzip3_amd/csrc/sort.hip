@@ -132,19 +132,23 @@ __device__ __forceinline__ u32 rs_tile_of_block(u32 b, u32 tiles, bool xcd) {
 }
 inline u32 rs_grid(u32 tiles, bool xcd) { return xcd ? 8u * ((tiles + 7u) / 8u) : tiles; }
 
-template <typename K>
+template <typename K, int BITS>
 __device__ __forceinline__ u32 rs_digit(K key, int shift) {
-    return (u32)(key >> shift) & 0xFFu;
+    return (u32)(key >> shift) & ((1u << BITS) - 1u);
 }
 
-template <typename K>
+// BITS = digit width: 8 (256 bins, the default) or 9 (512 bins: the LZP predecessor build sorts its 18-bit hashes in two passes
+// instead of three, round 5).  A thread owns RADIX / RS_BLOCK neighbouring digits wherever a digit needs a thread.
+template <typename K, int BITS>
 __global__ void __launch_bounds__(RS_BLOCK) k_rs_hist(const K * __restrict__ keys, u64 n, int shift, u32 * __restrict__ hist, u32 tiles, u32 xcd) {
-    __shared__ u32 bins[RS_RADIX];
+    constexpr int RADIX = 1 << BITS;
+    __shared__ u32 bins[RADIX];
     // same tile assignment as the scatter: the counts of neighbouring tiles are neighbouring words of the digit-major table, so
     // the tiles of one XCD fill whole lines of it in that XCD's L2 (and the scatter finds its tile's keys in the L2 that read them)
     const u32 tile = rs_tile_of_block(blockIdx.x, tiles, xcd != 0u);
     if (tile >= tiles) return;
-    bins[threadIdx.x] = 0;
+#pragma unroll
+    for (int d = threadIdx.x; d < RADIX; d += RS_BLOCK) bins[d] = 0;
     __syncthreads();
     const u64 tile_base = (u64)tile * RS_TILE;
     const u64 wbase = tile_base + (u64)wave_id() * RS_WAVE_SPAN + lane_id();
@@ -158,10 +162,11 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_hist(const K * __restrict__ key
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const u64 i = wbase + (u64)r * WAVE;
-        if (i < n) atomicAdd(&bins[rs_digit(key[r], shift)], 1u);
+        if (i < n) atomicAdd(&bins[rs_digit<K, BITS>(key[r], shift)], 1u);
     }
     __syncthreads();
-    hist[(u64)threadIdx.x * tiles + tile] = bins[threadIdx.x];
+#pragma unroll
+    for (int d = threadIdx.x; d < RADIX; d += RS_BLOCK) hist[(u64)d * tiles + tile] = bins[d];
 }
 
 // The tile is first put in digit order in LDS, then written out with consecutive lanes on consecutive destinations -- a digit's ~16
@@ -170,13 +175,22 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_hist(const K * __restrict__ key
 // (profiles/r03_kernel_stats_stages_256MiB_staged.txt), so the direct scatter is gone.
 // Slot of a key inside the tile = start of its digit + keys of that digit in earlier waves + rank in its own wave, which is the
 // stable order.  LDS: sizeof(K) * 4096 + 16 KiB + 6 KiB (54 KiB for 8-byte keys: two workgroups per CU).
-template <typename K, bool IOTA, bool WKEYS>
+//
+// RAW (round 5): `offs` is the hist kernel's table as it left it -- per-tile COUNTS, not scanned -- and every workgroup derives its own
+// 2^BITS offsets from it: digit d of tile t starts at (keys of smaller digits in all tiles) + (keys of digit d in earlier tiles), two
+// sums over one row of the digit-major table per digit.  For a pass of up to RS_RAW_TILES tiles that is cheaper than the three to
+// five launches of the recursive scan it replaces (415 k scan launches per bench run, most of them for the sorter's
+// ~50 small passes per block); larger passes keep the scanned table.
+template <typename K, bool IOTA, bool WKEYS, int BITS, bool RAW>
 __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const K * __restrict__ kin, K * __restrict__ kout, const u32 * __restrict__ vin,
                                                                u32 * __restrict__ vout, u64 n, int shift, const u32 * __restrict__ offs, u32 tiles,
                                                                u32 iota_split, u32 out_base, u32 xcd) {
-    __shared__ u32 cnt[RS_WAVES][RS_RADIX];
-    __shared__ u32 dstart[RS_RADIX];   // first slot of a digit inside the tile
-    __shared__ u32 gdelta[RS_RADIX];   // global destination of a digit's first key - dstart (mod 2^32)
+    constexpr int RADIX = 1 << BITS;
+    constexpr int DPT = RADIX / RS_BLOCK;  // digits per thread: d = DPT * threadIdx.x + j
+    static_assert(RADIX % RS_BLOCK == 0 && DPT >= 1, "a thread owns whole digits");
+    __shared__ u32 cnt[RS_WAVES][RADIX];
+    __shared__ u32 dstart[RADIX];   // first slot of a digit inside the tile
+    __shared__ u32 gdelta[RADIX];   // global destination of a digit's first key - dstart (mod 2^32)
     __shared__ u32 scan_lds[RS_BLOCK / WAVE + 1];
     __shared__ K skey[RS_TILE];
     __shared__ u32 sval[RS_TILE];
@@ -184,7 +198,9 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const K * __restrict__ 
     if (tile >= tiles) return;
     const int w = wave_id(), l = lane_id();
 #pragma unroll
-    for (int k = 0; k < RS_WAVES; k++) cnt[k][threadIdx.x] = 0;
+    for (int k = 0; k < RS_WAVES; k++)
+#pragma unroll
+        for (int d = threadIdx.x; d < RADIX; d += RS_BLOCK) cnt[k][d] = 0;
     __syncthreads();
 
     const u64 tile_base = (u64)tile * RS_TILE;
@@ -198,14 +214,31 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const K * __restrict__ 
         const u64 i = wbase + (u64)r * WAVE;
         key[r] = kin[i < n ? i : last];
     }
+    // RAW: this thread's digits' rows of the count table, requested before the ranking below so that their latency hides behind it
+    u32 row_total[DPT], row_before[DPT];
+    if (RAW) {
+#pragma unroll
+        for (int j = 0; j < DPT; j++) {
+            const u32 * __restrict__ row = offs + (u64)(DPT * threadIdx.x + j) * tiles;
+            u32 tot = 0, bef = 0;
+#pragma unroll 4
+            for (u32 t = 0; t < tiles; t++) {
+                const u32 c = row[t];
+                tot += c;
+                bef += t < tile ? c : 0u;
+            }
+            row_total[j] = tot;
+            row_before[j] = bef;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const u64 i = wbase + (u64)r * WAVE;
         const bool valid = i < n;
-        const u32 d = rs_digit(key[r], shift);
+        const u32 d = rs_digit<K, BITS>(key[r], shift);
         u64 peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < BITS; b++) {
             const bool bit = (d >> b) & 1u;
             const u64 bal = __ballot(bit);
             peers &= bit ? bal : ~bal;
@@ -225,23 +258,48 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const K * __restrict__ 
     }
     __syncthreads();
     {
-        const u32 d = threadIdx.x;
-        u32 run = 0;
+        u32 run[DPT];
+        u32 mine = 0;
 #pragma unroll
-        for (int k = 0; k < RS_WAVES; k++) {
-            u32 c = cnt[k][d];
-            cnt[k][d] = run;
-            run += c;
+        for (int j = 0; j < DPT; j++) {
+            const u32 d = DPT * threadIdx.x + j;
+            u32 acc = 0;
+#pragma unroll
+            for (int k = 0; k < RS_WAVES; k++) {
+                u32 c = cnt[k][d];
+                cnt[k][d] = acc;
+                acc += c;
+            }
+            run[j] = acc;
+            mine += acc;
         }
         u32 total;
-        const u32 start = block_excl_add<RS_BLOCK>(run, scan_lds, total);  // ends with a barrier
-        dstart[d] = start;
-        gdelta[d] = offs[(u64)d * tiles + tile] + out_base - start;
+        u32 start = block_excl_add<RS_BLOCK>(mine, scan_lds, total);  // ends with a barrier
+        u32 gbase = 0;
+        if (RAW) {
+            u32 rt = 0;
+#pragma unroll
+            for (int j = 0; j < DPT; j++) rt += row_total[j];
+            u32 all;
+            gbase = block_excl_add<RS_BLOCK>(rt, scan_lds, all);  // keys of smaller digits, all tiles
+        }
+#pragma unroll
+        for (int j = 0; j < DPT; j++) {
+            const u32 d = DPT * threadIdx.x + j;
+            dstart[d] = start;
+            if (RAW) {
+                gdelta[d] = gbase + row_before[j] + out_base - start;
+                gbase += row_total[j];
+            } else {
+                gdelta[d] = offs[(u64)d * tiles + tile] + out_base - start;
+            }
+            start += run[j];
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
-        const u32 d = rs_digit(key[r], shift);
+        const u32 d = rs_digit<K, BITS>(key[r], shift);
         local[r] += dstart[d] + cnt[w][d];
     }
 #pragma unroll
@@ -260,38 +318,52 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const K * __restrict__ 
         const u32 j = (u32)q * RS_BLOCK + threadIdx.x;
         if (j < count) {
             const K k = skey[j];
-            const u32 pos = gdelta[rs_digit(k, shift)] + j;
+            const u32 pos = gdelta[rs_digit<K, BITS>(k, shift)] + j;
             if (WKEYS) kout[pos] = k;
             vout[pos] = sval[j];
         }
     }
 }
 
-template <typename K>
-void radix_pass(const K * kin, K * kout, const u32 * vin, u32 * vout, u64 n, int shift, u32 iota_split, u32 out_base, Arena & tmp,
-                hipStream_t s) {
+// Passes of up to this many tiles (512 Ki keys) skip the scan: the scatter's workgroups read the count table themselves (RAW above).
+// Every workgroup reads the whole table -- tiles * 2^BITS words from L2 -- so the bound keeps that at 128 KiB (8-bit digits) per workgroup.
+constexpr u32 RS_RAW_TILES = 128;
+
+template <typename K, int BITS>
+void radix_pass_bits(const K * kin, K * kout, const u32 * vin, u32 * vout, u64 n, int shift, u32 iota_split, u32 out_base, Arena & tmp,
+                     hipStream_t s) {
     if (n == 0) return;
+    constexpr int RADIX = 1 << BITS;
     const u32 tiles = (u32)((n + RS_TILE - 1) / RS_TILE);
     size_t m = tmp.mark();
-    u32 * hist = tmp.take<u32>((size_t)tiles * RS_RADIX);
+    u32 * hist = tmp.take<u32>((size_t)tiles * RADIX);
     const u32 xcd = 1u;  // contiguous tiles per XCD (measured round 3: 2.37 against 3.58 ms per full-n pass with tile = blockIdx)
     const dim3 sgrid(rs_grid(tiles, xcd != 0u));
-    launch(k_rs_hist<K>, sgrid, dim3(RS_BLOCK), 0, s, kin, n, shift, hist, tiles, xcd);
-    exclusive_scan_u32(hist, (u64)tiles * RS_RADIX, nullptr, tmp, s);
+    launch(k_rs_hist<K, BITS>, sgrid, dim3(RS_BLOCK), 0, s, kin, n, shift, hist, tiles, xcd);
+    static const bool no_raw = getenv("BZ3_RS_NO_RAW") != nullptr;  // (experiments: the scanned table for every pass, as up to round 4; read once)
+    const bool raw = tiles <= RS_RAW_TILES && !no_raw;
+    if (!raw) exclusive_scan_u32(hist, (u64)tiles * RADIX, nullptr, tmp, s);
     const bool iota = vin == nullptr, wkeys = kout != nullptr;
-#define BZ3_RS_LAUNCH(KERNEL, I, W) \
-    launch(KERNEL<K, I, W>, sgrid, dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base, xcd)
-#define BZ3_RS_DISPATCH(KERNEL)                           \
-    do {                                                  \
-        if (iota && wkeys) BZ3_RS_LAUNCH(KERNEL, true, true);        \
-        else if (iota) BZ3_RS_LAUNCH(KERNEL, true, false);           \
-        else if (wkeys) BZ3_RS_LAUNCH(KERNEL, false, true);          \
-        else BZ3_RS_LAUNCH(KERNEL, false, false);                    \
+#define BZ3_RS_LAUNCH(I, W, R) \
+    launch(k_rs_scatter<K, I, W, BITS, R>, sgrid, dim3(RS_BLOCK), 0, s, kin, kout, vin, vout, n, shift, (const u32 *)hist, tiles, iota_split, out_base, xcd)
+#define BZ3_RS_DISPATCH(R)                                   \
+    do {                                                     \
+        if (iota && wkeys) BZ3_RS_LAUNCH(true, true, R);     \
+        else if (iota) BZ3_RS_LAUNCH(true, false, R);        \
+        else if (wkeys) BZ3_RS_LAUNCH(false, true, R);       \
+        else BZ3_RS_LAUNCH(false, false, R);                 \
     } while (0)
-    BZ3_RS_DISPATCH(k_rs_scatter);
+    if (raw) BZ3_RS_DISPATCH(true);
+    else BZ3_RS_DISPATCH(false);
 #undef BZ3_RS_DISPATCH
 #undef BZ3_RS_LAUNCH
     tmp.release(m);
+}
+
+template <typename K>
+void radix_pass(const K * kin, K * kout, const u32 * vin, u32 * vout, u64 n, int shift, u32 iota_split, u32 out_base, Arena & tmp,
+                hipStream_t s) {
+    radix_pass_bits<K, 8>(kin, kout, vin, vout, n, shift, iota_split, out_base, tmp, s);
 }
 
 template <typename K>
@@ -310,6 +382,7 @@ int radix_sort_pairs(K * k0, K * k1, u32 * v0, u32 * v1, u64 n, int bit_lo, int 
 template void radix_pass<u8>(const u8 *, u8 *, const u32 *, u32 *, u64, int, u32, u32, Arena &, hipStream_t);
 template void radix_pass<u32>(const u32 *, u32 *, const u32 *, u32 *, u64, int, u32, u32, Arena &, hipStream_t);
 template void radix_pass<u64>(const u64 *, u64 *, const u32 *, u32 *, u64, int, u32, u32, Arena &, hipStream_t);
+template void radix_pass_bits<u32, 9>(const u32 *, u32 *, const u32 *, u32 *, u64, int, u32, u32, Arena &, hipStream_t);
 template int radix_sort_pairs<u32>(u32 *, u32 *, u32 *, u32 *, u64, int, int, Arena &, hipStream_t);
 template int radix_sort_pairs<u64>(u64 *, u64 *, u32 *, u32 *, u64, int, int, Arena &, hipStream_t);
 

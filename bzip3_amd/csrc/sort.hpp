@@ -35,9 +35,9 @@ inline size_t scan_temp_words(u64 n) {  // words of scratch the recursive scan n
     }
     return w + 64;
 }
-inline size_t radix_temp_bytes(u64 n) {
+inline size_t radix_temp_bytes(u64 n, int bits = 8) {  // scratch of one pass with 2^bits bins
     u64 tiles = (n + RS_TILE - 1) / RS_TILE;
-    u64 hist = tiles * RS_RADIX;
+    u64 hist = tiles << bits;
     return (hist + scan_temp_words(hist) + 256) * 4 + 4096;
 }
 
@@ -52,6 +52,11 @@ void exclusive_scan_u32(u32 * d_data, u64 n, u32 * d_total, Arena & tmp, hipStre
 template <typename K>
 void radix_pass(const K * kin, K * kout, const u32 * vin, u32 * vout, u64 n, int shift, u32 iota_split, u32 out_base,
                 Arena & tmp, hipStream_t s);
+
+// The same with digits of BITS bits (8 or 9): digit = (key >> shift) & (2^BITS - 1).
+template <typename K, int BITS>
+void radix_pass_bits(const K * kin, K * kout, const u32 * vin, u32 * vout, u64 n, int shift, u32 iota_split, u32 out_base,
+                     Arena & tmp, hipStream_t s);
 
 // Full LSD sort over key bits [bit_lo, bit_hi) in 8-bit digits, ping-ponging (k0,v0) <-> (k1,v1).
 // Returns 0 if the sorted data ends in (k0,v0), 1 if in (k1,v1).
