@@ -209,7 +209,7 @@ int pick_device() {
 
 size_t workspace_bytes_for(u64 n) {
     size_t a = bwt_workspace_bytes(n), b = unbwt_workspace_bytes(n);
-    size_t c = (size_t)n * 26 + radix_temp_bytes(n) + (4u << 20);  // LZP: prev, mlen, bitmap, sort buffers
+    size_t c = (size_t)n * 30 + radix_temp_bytes(n, 9) + scan_temp_words(n / 8 + 4096) * 4 + (4u << 20);  // LZP: links, mlen, bitmaps, the hash sort's buffers + the binned link records (lzp.hip)
     size_t m = a > b ? a : b;
     return m > c ? m : c;
 }

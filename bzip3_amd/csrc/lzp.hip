@@ -64,6 +64,171 @@ __global__ void __launch_bounds__(LZ_BLOCK) k_lzp_links(const u32 * __restrict__
     *reinterpret_cast<uint2 *>(link + lz_lk(p)) = l;  // the array is 8-byte aligned (Arena::take)
 }
 
+// ---- 1b. the same links through POSITION BINS (round 5) ------------------------------------------------------------------------
+// k_lzp_links above costs 11.5 ms per 256 MiB block: 268 M scattered 8-byte stores all over a 2 GB array, every one a partial line that
+// HBM reads, merges and writes back.  The suffix sorter's ISA scatter (bwt.hip k_isa_scatter) met the same wall and went round it: first
+// bucket the records by the top bits of their destination with one pass of the radix scatter (coalesced), then scatter bucket by bucket
+// -- a bucket's destinations lie in a window of a few MB, and with a contiguous range of tiles per XCD that XCD's L2 absorbs the random
+// stores and writes whole lines back.  Here: k_lzp_bin_scatter walks the hash-sorted (key, position) list, forms (p, prev, next) of every
+// element from its two neighbours and delivers the 12-byte record to the bin of p's top 9 bits; k_lzp_links_local then stores
+// link[2p] = (prev, next) bin by bin.  Bytes per position: 4 (bin histogram) + 8 + 12 (binning) + 12 + 8 (local scatter) = 44,
+// all but the last 8 streamed.
+struct LzLinkRec {
+    u32 p, prev, next;
+};
+constexpr int LZB_BITS = 9;
+constexpr int LZB_RADIX = 1 << LZB_BITS;
+constexpr int LZB_WAVES = RS_BLOCK / WAVE;
+constexpr int LZB_ROUNDS = RS_TILE / RS_BLOCK;
+constexpr int LZB_SPAN = RS_TILE / LZB_WAVES;
+constexpr int LZB_DPT = LZB_RADIX / RS_BLOCK;
+
+__device__ __forceinline__ u32 lzb_tile_of_block(u32 b, u32 tiles) {  // a contiguous range of tiles per XCD (sort.hip rs_tile_of_block)
+    const u32 per = (tiles + 7u) / 8u;
+    return (b & 7u) * per + (b >> 3);
+}
+
+// keys / vals: the hash-sorted list (vals[k] = position - 4); offs: the scanned digit-major table of k_rs_hist<u32, 9>(vals, shift).
+__global__ void __launch_bounds__(RS_BLOCK) k_lzp_bin_scatter(const u32 * __restrict__ keys, const u32 * __restrict__ vals, u32 m, int shift,
+                                                             const u32 * __restrict__ offs, u32 tiles, LzLinkRec * __restrict__ out) {
+    __shared__ u32 cnt[LZB_WAVES][LZB_RADIX];
+    __shared__ u32 dstart[LZB_RADIX];
+    __shared__ u32 gdelta[LZB_RADIX];
+    __shared__ u32 scan_lds[RS_BLOCK / WAVE + 1];
+    // the tile's keys and values with one element of halo on either side, then (the same LDS) its records in bin order
+    __shared__ __attribute__((aligned(16))) u32 stage[3 * RS_TILE + 8];
+    u32 * const in_k = stage;                    // [RS_TILE + 2]
+    u32 * const in_v = stage + RS_TILE + 4;      // [RS_TILE + 2]
+    const u32 tile = lzb_tile_of_block(blockIdx.x, tiles);
+    if (tile >= tiles) return;
+    const int w = wave_id(), l = lane_id();
+#pragma unroll
+    for (int k = 0; k < LZB_WAVES; k++)
+#pragma unroll
+        for (int d = threadIdx.x; d < LZB_RADIX; d += RS_BLOCK) cnt[k][d] = 0;
+    const u64 tile_base = (u64)tile * RS_TILE;
+    const u64 wbase = tile_base + (u64)w * LZB_SPAN + l;
+    const u64 last = (u64)m - 1;
+    u32 key[LZB_ROUNDS], val[LZB_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < LZB_ROUNDS; r++) {  // all loads in flight before the first use (cf. sort.hip)
+        const u64 i = wbase + (u64)r * WAVE;
+        key[r] = keys[i < m ? i : last];
+        val[r] = vals[i < m ? i : last];
+    }
+    if (threadIdx.x < 2u) {  // halo: the element before the tile / behind it (a key no hash has where there is none)
+        const bool left = threadIdx.x == 0u;
+        const u64 i = left ? tile_base - 1 : tile_base + RS_TILE;
+        const bool there = left ? tile_base > 0 : i < m;
+        in_k[left ? 0 : RS_TILE + 1] = there ? keys[i] : 0xFFFFFFFFu;
+        in_v[left ? 0 : RS_TILE + 1] = there ? vals[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < LZB_ROUNDS; r++) {
+        const u32 j = (u32)w * LZB_SPAN + (u32)r * WAVE + (u32)l;
+        const bool valid = wbase + (u64)r * WAVE < m;
+        in_k[1 + j] = valid ? key[r] : 0xFFFFFFFFu;
+        in_v[1 + j] = val[r];
+    }
+    __syncthreads();
+    u32 prev[LZB_ROUNDS], next[LZB_ROUNDS], local[LZB_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < LZB_ROUNDS; r++) {
+        const u32 j = (u32)w * LZB_SPAN + (u32)r * WAVE + (u32)l;
+        prev[r] = in_k[j] == key[r] ? in_v[j] + 4u : 0u;          // (as k_lzp_links)
+        next[r] = in_k[j + 2] == key[r] ? in_v[j + 2] + 4u : 0u;
+    }
+    const u64 lt = lanemask_lt();
+#pragma unroll
+    for (int r = 0; r < LZB_ROUNDS; r++) {
+        const bool valid = wbase + (u64)r * WAVE < m;
+        const u32 d = (val[r] >> shift) & (LZB_RADIX - 1u);
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < LZB_BITS; b++) {
+            const bool bit = (d >> b) & 1u;
+            const u64 bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const u32 below = (u32)__popcll(peers & lt);
+        const u32 pre = valid ? cnt[w][d] : 0u;
+        wave_sync();
+        if (valid && below == 0) cnt[w][d] = pre + (u32)__popcll(peers);
+        wave_sync();
+        local[r] = pre + below;
+    }
+    __syncthreads();  // (also: every neighbour read of the staged tile is done -- the records overwrite it below)
+    {
+        u32 run[LZB_DPT];
+        u32 mine = 0;
+#pragma unroll
+        for (int j = 0; j < LZB_DPT; j++) {
+            const u32 d = LZB_DPT * threadIdx.x + j;
+            u32 acc = 0;
+#pragma unroll
+            for (int k = 0; k < LZB_WAVES; k++) {
+                const u32 c = cnt[k][d];
+                cnt[k][d] = acc;
+                acc += c;
+            }
+            run[j] = acc;
+            mine += acc;
+        }
+        u32 total;
+        u32 start = block_excl_add<RS_BLOCK>(mine, scan_lds, total);
+#pragma unroll
+        for (int j = 0; j < LZB_DPT; j++) {
+            const u32 d = LZB_DPT * threadIdx.x + j;
+            dstart[d] = start;
+            gdelta[d] = offs[(u64)d * tiles + tile] - start;
+            start += run[j];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < LZB_ROUNDS; r++) {
+        const u32 d = (val[r] >> shift) & (LZB_RADIX - 1u);
+        local[r] += dstart[d] + cnt[w][d];
+    }
+#pragma unroll
+    for (int r = 0; r < LZB_ROUNDS; r++) {
+        if (wbase + (u64)r * WAVE < m) {
+            stage[3u * local[r]] = val[r] + 4u;
+            stage[3u * local[r] + 1u] = prev[r];
+            stage[3u * local[r] + 2u] = next[r];
+        }
+    }
+    __syncthreads();
+    const u64 left = (u64)m - tile_base;
+    const u32 count = left < (u64)RS_TILE ? (u32)left : (u32)RS_TILE;
+#pragma unroll
+    for (int q = 0; q < LZB_ROUNDS; q++) {
+        const u32 j = (u32)q * RS_BLOCK + threadIdx.x;
+        if (j < count) {
+            LzLinkRec rec{stage[3u * j], stage[3u * j + 1u], stage[3u * j + 2u]};
+            out[gdelta[((rec.p - 4u) >> shift) & (LZB_RADIX - 1u)] + j] = rec;
+        }
+    }
+}
+
+// link[2p] = (prev, next) from the binned records: a contiguous range of tiles per XCD, so that the random 8-byte stores of the bin an
+// XCD is working on meet in that XCD's L2 (cf. bwt.hip k_isa_scatter).
+constexpr int LZL_ITEMS = 8;
+__global__ void __launch_bounds__(LZ_BLOCK) k_lzp_links_local(const LzLinkRec * __restrict__ rec, u32 m, u32 tiles, u32 * __restrict__ link) {
+    const u32 tile = lzb_tile_of_block(blockIdx.x, tiles);
+    if (tile >= tiles) return;
+    const u64 base = (u64)tile * (LZ_BLOCK * LZL_ITEMS) + threadIdx.x;
+    LzLinkRec x[LZL_ITEMS];
+#pragma unroll
+    for (int k = 0; k < LZL_ITEMS; k++) {
+        const u64 i = base + (u64)k * LZ_BLOCK;
+        x[k] = rec[i < m ? i : (u64)m - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < LZL_ITEMS; k++)
+        if (base + (u64)k * LZ_BLOCK < m) *reinterpret_cast<uint2 *>(link + lz_lk(x[k].p)) = make_uint2(x[k].prev, x[k].next);
+}
+
 // Nearest visited ancestor of p in its hash chain (0 = none).  Swallowed positions are never un-swallowed, so
 // every link of the walked path may be short-cut to the answer (path compression): without it a phrase that
 // recurs k times costs O(k) per later occurrence, because all but its first copy sit inside earlier matches.
@@ -420,16 +585,44 @@ void lzp_encode_prepare(const u8 * d_in, u32 n, LzpEncodeCtx & c, Arena & ctx, A
     {
         const size_t mk2 = tmp.mark();
         u32 * k0 = tmp.take<u32>(m);
-        u32 * k1 = tmp.take<u32>(m);
         u32 * v0 = tmp.take<u32>(m);
-        u32 * v1 = tmp.take<u32>(m);
+        u32 * k1 = tmp.take<u32>(3 * (size_t)m + 64);  // (k1, v1) and a third buffer in one piece: the binned link records (12 bytes each) overlay them
+        u32 * v1 = k1 + (((size_t)m + 63) & ~(size_t)63);
         launch(k_lzp_hash, dim3((m + LZ_BLOCK - 1) / LZ_BLOCK), dim3(LZ_BLOCK), 0, s, d_in, n, k0);
-        radix_pass<u32>(k0, k1, (const u32 *)nullptr, v1, m, 0, 0xFFFFFFFFu, 0u, tmp, s);
-        radix_pass<u32>(k1, k0, (const u32 *)v1, v0, m, 8, 0xFFFFFFFFu, 0u, tmp, s);
-        radix_pass<u32>(k0, k1, (const u32 *)v0, v1, m, 16, 0xFFFFFFFFu, 0u, tmp, s);
         HIP_CHECK(hipMemsetAsync(c.prev, 0, 32, s));  // positions 0..3 have no context: no links
-        launch(k_lzp_links, dim3((m + LZ_BLOCK - 1) / LZ_BLOCK), dim3(LZ_BLOCK), 0, s, (const u32 *)k1, (const u32 *)v1, m, c.prev);
-        tmp.release(mk2);  // the sort buffers are dead once k_lzp_links has run (stream order protects them)
+        static const int form = [] { const char * e = getenv("BZ3_LZP_LINKS"); return e ? atoi(e) : 2; }();  // (experiments, read once) 0 = round 4's build, 1 = two 9-bit passes, 2 = + binned links
+        if (form == 0) {
+            radix_pass<u32>(k0, k1, (const u32 *)nullptr, v1, m, 0, 0xFFFFFFFFu, 0u, tmp, s);
+            radix_pass<u32>(k1, k0, (const u32 *)v1, v0, m, 8, 0xFFFFFFFFu, 0u, tmp, s);
+            radix_pass<u32>(k0, k1, (const u32 *)v0, v1, m, 16, 0xFFFFFFFFu, 0u, tmp, s);
+            launch(k_lzp_links, dim3((m + LZ_BLOCK - 1) / LZ_BLOCK), dim3(LZ_BLOCK), 0, s, (const u32 *)k1, (const u32 *)v1, m, c.prev);
+        } else {
+            // the 18-bit hashes in TWO stable passes of 9-bit digits (rounds 1-4: three of 8 bits, the third for two bits)
+            static_assert(LZ_HASH_BITS == 2 * LZB_BITS, "two digits cover the hash");
+            radix_pass_bits<u32, LZB_BITS>(k0, k1, (const u32 *)nullptr, v1, m, 0, 0xFFFFFFFFu, 0u, tmp, s);
+            radix_pass_bits<u32, LZB_BITS>(k1, k0, (const u32 *)v1, v0, m, LZB_BITS, 0xFFFFFFFFu, 0u, tmp, s);
+            if (form == 1 || m <= 2u * RS_TILE) {  // (a tile or two: nothing to bin)
+                launch(k_lzp_links, dim3((m + LZ_BLOCK - 1) / LZ_BLOCK), dim3(LZ_BLOCK), 0, s, (const u32 *)k0, (const u32 *)v0, m, c.prev);
+            } else {
+                // records binned by the top 9 bits of the position, over (k1, v1) and the third buffer, then the local scatter
+                LzLinkRec * rec = reinterpret_cast<LzLinkRec *>(k1);
+                static_assert(sizeof(LzLinkRec) == 12, "three words");
+                int nbits = 0;
+                for (u32 x = m - 1; x; x >>= 1) nbits++;
+                const int shift = nbits > LZB_BITS ? nbits - LZB_BITS : 0;
+                const u32 tiles = (m + RS_TILE - 1) / RS_TILE;
+                const size_t mk3 = tmp.mark();
+                u32 * hist = tmp.take<u32>((size_t)tiles * LZB_RADIX);
+                const dim3 sgrid(8u * ((tiles + 7u) / 8u));
+                radix_hist_bits9(v0, m, shift, hist, tiles, s);
+                exclusive_scan_u32(hist, (u64)tiles * LZB_RADIX, nullptr, tmp, s);
+                launch(k_lzp_bin_scatter, sgrid, dim3(RS_BLOCK), 0, s, (const u32 *)k0, (const u32 *)v0, m, shift, (const u32 *)hist, tiles, rec);
+                const u32 ltiles = (m + LZ_BLOCK * LZL_ITEMS - 1) / (LZ_BLOCK * LZL_ITEMS);
+                launch(k_lzp_links_local, dim3(8u * ((ltiles + 7u) / 8u)), dim3(LZ_BLOCK), 0, s, (const LzLinkRec *)rec, m, ltiles, c.prev);
+                tmp.release(mk3);
+            }
+        }
+        tmp.release(mk2);  // the sort buffers are dead once the links are written (stream order protects them)
     }
     HIP_CHECK(hipMemsetAsync(c.skip, 0, (size_t)c.nwords * 4, s));
     HIP_CHECK(hipMemsetAsync(c.mstart, 0, (size_t)c.nwords * 4, s));

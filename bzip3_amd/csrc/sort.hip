@@ -360,6 +360,10 @@ void radix_pass_bits(const K * kin, K * kout, const u32 * vin, u32 * vout, u64 n
     tmp.release(m);
 }
 
+void radix_hist_bits9(const u32 * keys, u64 n, int shift, u32 * hist, u32 tiles, hipStream_t s) {
+    launch(k_rs_hist<u32, 9>, dim3(rs_grid(tiles, true)), dim3(RS_BLOCK), 0, s, keys, n, shift, hist, tiles, 1u);
+}
+
 template <typename K>
 void radix_pass(const K * kin, K * kout, const u32 * vin, u32 * vout, u64 n, int shift, u32 iota_split, u32 out_base, Arena & tmp,
                 hipStream_t s) {

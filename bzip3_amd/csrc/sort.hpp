@@ -58,6 +58,9 @@ template <typename K, int BITS>
 void radix_pass_bits(const K * kin, K * kout, const u32 * vin, u32 * vout, u64 n, int shift, u32 iota_split, u32 out_base,
                      Arena & tmp, hipStream_t s);
 
+// The per-tile digit-major count table of a 9-bit pass alone (lzp.hip bins its link records with a scatter kernel of its own).
+void radix_hist_bits9(const u32 * keys, u64 n, int shift, u32 * hist, u32 tiles, hipStream_t s);
+
 // Full LSD sort over key bits [bit_lo, bit_hi) in 8-bit digits, ping-ponging (k0,v0) <-> (k1,v1).
 // Returns 0 if the sorted data ends in (k0,v0), 1 if in (k1,v1).
 template <typename K>
