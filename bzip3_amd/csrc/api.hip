@@ -108,6 +108,9 @@ struct DeviceCtx {
         if (hipMalloc((void **)&p, cap) != hipSuccess) {
             // (the ring's budget is an estimate: before the block fails, give back what the pool holds idle -- buffers of other sizes -- and ask again)
             (void)hipGetLastError();
+            // A buffer goes back to the pool by STREAM ORDER (encode_front_b): kernels already queued on the group's stream may still read it.
+            // Every borrower launches on that one stream, which is what protects a re-borrowed buffer; a FREE is not a stream operation, so wait.
+            (void)hipDeviceSynchronize();
             for (auto & t : temps_free) (void)hipFree(t.first);
             temps_free.clear();
             HIP_CHECK(hipMalloc((void **)&p, cap));
@@ -127,8 +130,16 @@ struct DeviceCtx {
     }
     void temp_trim() {  // hand the idle swap buffers back to the driver
         std::lock_guard<std::mutex> lk(temp_mu);
+        if (temps_free.empty()) return;
+        (void)hipDeviceSynchronize();  // (see temp_get: a pooled buffer may still be read by kernels in flight; hipFree's own synchronisation is not documented)
         for (auto & t : temps_free) (void)hipFree(t.first);
         temps_free.clear();
+    }
+    size_t temp_idle_bytes() {
+        std::lock_guard<std::mutex> lk(temp_mu);
+        size_t b = 0;
+        for (auto & t : temps_free) b += t.second;
+        return b;
     }
 
     Arena arena_for(size_t bytes) {  // caller holds mu
@@ -661,8 +672,15 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         // Swap buffers the previous call left idle in the pool (a decode call's tail ring holds up to 4 x 16 of them, 17 GB at 256 MiB)
         // are memory this call's ring of LZP contexts cannot use: round 4's full-size run had a ring of 4 x 4 contexts and an encode
         // front end 14 s longer in its SECOND step than in its first for this.  What the front end borrows again is a few dozen buffers.
-        if (lead->lean) lead->ctx->temp_trim();
+        // Round 5: only when that memory is MISSING -- an ordinary lean batch whose ring gets its full shape beside the pool keeps the
+        // buffers it is about to borrow again (a free + malloc cycle per buffer and call otherwise, 30-45 ms per GiB).
         size_t free_b = 0, total_b = 0;
+        if (lead->lean && lead->ctx->temp_idle_bytes() > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t full_ring = (size_t)DeviceCtx::RING_SLOTS * 8u * (ctx_bytes + lead->cap);  // 4 slots x 8 blocks: what pipeline_shape grants at most
+            const size_t wanted = (size_t)(n < DeviceCtx::RING_SLOTS * 8 ? n : DeviceCtx::RING_SLOTS * 8) * (ctx_bytes + lead->cap);
+            const size_t have0 = lead->ctx->ws_cap;
+            if (free_b + have0 < need + ((size_t)6 << 30) + (wanted < full_ring ? wanted : full_ring)) lead->ctx->temp_trim();
+        }
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t have = lead->ctx->ws_cap;  // the arena already holds this much
             budget = (free_b + have > need) ? (free_b + have - need) / 10 * 7 : 0;
@@ -1496,7 +1514,10 @@ void collect(int kind, SingleReq & r) {
         try {
             run_collected(kind, batch);
         } catch (...) {  // (the batch calls do not throw; belt and braces: nobody may wait for ever)
-            for (SingleReq * q : batch) on_failure(q->st);
+            for (SingleReq * q : batch) {
+                on_failure(q->st);
+                if (kind == 0) q->size = -1;  // bz3_encode_block returns this: the request's input size must not pass for a coded size
+            }
         }
         lk.lock();
         for (SingleReq * q : batch) q->done = true;

@@ -1485,16 +1485,21 @@ static int sort_iota(const K * kin, K * k0, K * k1, u32 * v0, u32 * v1, u64 n, i
 //                          within a process: bz3_hip_debug_bwt_big_rounds(k), k < 0 = default
 struct BwtSwitches {
     bool trace;
+    int big_rounds_default;  // BZ3_BWT_BIG_ROUNDS as read at load (1 without it)
     std::atomic<int> big_rounds;
 };
 static BwtSwitches & bwt_switches() {
-    static BwtSwitches sw{getenv("BZ3_BWT_TRACE") != nullptr, {getenv("BZ3_BWT_BIG_ROUNDS") ? atoi(getenv("BZ3_BWT_BIG_ROUNDS")) : 1}};
+    static BwtSwitches sw{getenv("BZ3_BWT_TRACE") != nullptr, getenv("BZ3_BWT_BIG_ROUNDS") ? atoi(getenv("BZ3_BWT_BIG_ROUNDS")) : 1,
+                          {getenv("BZ3_BWT_BIG_ROUNDS") ? atoi(getenv("BZ3_BWT_BIG_ROUNDS")) : 1}};
     return sw;
 }
-void bwt_set_big_rounds(int k) { bwt_switches().big_rounds.store(k < 0 ? 1 : k); }  // tests: bz3_hip_debug_bwt_big_rounds
-// Grids of the wide / tail kernels: fixed by the block's size (their work lists' lengths stay on the device), a quarter of what the
-// longest possible list would take so that a wave walks at most four strides -- call 3 measured a grid of 24,576 waves, dozens of strides
-// per wave, 13 % slower than the exactly sized launch of rounds 1-3.  BZ3_BWT_GRIDS="wide,tail" (read once) overrides: experiments.
+void bwt_set_big_rounds(int k) { bwt_switches().big_rounds.store(k < 0 ? bwt_switches().big_rounds_default : k); }  // tests: bz3_hip_debug_bwt_big_rounds (k < 0: the default as read at load)
+// Grids of the wide / tail kernels: fixed by the block's size (their work lists' lengths stay on the device).  Tail: n / 256 waves, a
+// quarter of what the longest possible list (n entries, 64 per wave) would take: at most four strides per wave.  Wide: n / 4096
+// workgroups of WR_WAVES waves; the list holds at most n / 65 descriptors, so the worst case is ~16 strides per wave -- the lists of
+// real blocks are far shorter (text: a few 10^5 descriptors at 256 MiB, one or two strides).  Call 3 of round 4 measured a tail grid of
+// 24,576 waves, dozens of strides per wave, 13 % slower than the exactly sized launch of rounds 1-3.  BZ3_BWT_GRIDS="wide,tail" (read
+// once) overrides: experiments.
 struct BwtGrids {
     u32 wide, tail;
 };

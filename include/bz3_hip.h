@@ -80,7 +80,10 @@ BZIP3_API void bz3_hip_encode_blocks_device(struct bz3_state * states[], void * 
 BZIP3_API void bz3_hip_decode_blocks_device(struct bz3_state * states[], void * buffers[], size_t buffer_sizes[], int32_t sizes[],
                                             int32_t orig_sizes[], int32_t n);
 
-/* Stage timings (milliseconds) of the last block processed by `state`. */
+/* Stage timings (milliseconds) of the last block processed by `state`.  Timing a stage means waiting for the stream, so since round 4 only
+ * the FIRST state of a batch (per GPU) is timed: its CRC / RLE / BWT entries are stage times, its LZP entry includes the window's driver
+ * launch; for every other state of the batch CRC / BWT read 0 and RLE / LZP are launch (enqueue) times, not kernel times.  CM is the batch's
+ * launch on every state. */
 enum {
     BZ3_HIP_T_CRC = 0,
     BZ3_HIP_T_RLE = 1,
@@ -118,7 +121,11 @@ BZIP3_API void bz3_hip_stage_cm_decode(const uint8_t * in, int32_t in_size, uint
  * from in_fd, codes `blocks_per_batch` of them at a time on the GPU(s) while the next batch is being read and the previous
  * one written, writes the reference's file format to out_fd ("BZ3v1", u32le block size, then per block u32le coded size,
  * u32le original size, block bytes -- byte-identical to `bzip3 -e -b`, decodable by `bzip3 -d`, and vice versa).
- * Returns 0, or a BZ3_ERR_* code (of the first failing block; the blocks before it have been written), or BZ3_HIP_ERR_IO. */
+ * Returns 0, or a BZ3_ERR_* code (of the first failing block; the blocks before it have been written), or BZ3_HIP_ERR_IO.
+ * Host buffers: page-locked up to BZ3_HIP_STREAM_PINNED_MIB MiB in total (environment, read once per process; default 4096 = 4 GiB), plain
+ * malloc'ed buffers beyond that or when the host refuses -- larger configurations (blocks_per_batch x block size x 3 buffers above the
+ * budget) therefore mix pinned and pageable buffers and copy the pageable ones through the runtime's staging at roughly half the rate;
+ * raise the variable where the host has the lockable memory. */
 #define BZ3_HIP_ERR_IO (-100)
 BZIP3_API int bz3_hip_encode_stream(int in_fd, int out_fd, int32_t block_size, int32_t blocks_per_batch);
 BZIP3_API int bz3_hip_decode_stream(int in_fd, int out_fd, int32_t blocks_per_batch);
