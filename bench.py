@@ -78,6 +78,10 @@ ALG_BYTES_BWT = 11.0
 CFG3_BYTES = 1_000_000_000  # BASELINE.json configs[2]: "enwik9 (1 GB), -b 256, single MI355X"
 CM_MODES = {"auto": -1, "full": 0, "rows": 1, "rows3": 2}
 
+# More hardware queues than the HIP runtime's default 4: the codec's rings use the group's stream + four side streams (api.hip device_count()
+# explains; it sets the same default when it initialises the runtime itself -- here torch does, so it has to be in the environment before that).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 T_START = time.perf_counter()
 RANK = int(os.environ.get("RANK", "0"))
 WORLD = int(os.environ.get("WORLD_SIZE", "1"))

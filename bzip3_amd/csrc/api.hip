@@ -172,6 +172,14 @@ std::atomic<unsigned> g_cm_given_up{0};  // blocks the row-cache CM kernels hand
 int device_count() {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_device_count < 0) {
+#ifndef BZ3_EMU
+        // The rings run a group's whole-GPU kernels on one stream and the serial one-workgroup-per-block kernels (LZP drivers / decoders) of up to
+        // four windows on side streams.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and
+        // streams that share a queue do not overlap: with five streams on four queues the tail of 256 x 64 MiB blocks measured 3.23 s, with 16
+        // queues 3.08 s (profiles/r05_tail_hw_queues.txt).  Only effective if the runtime has not been initialised yet (a host program that
+        // initialises HIP first -- bench.py through torch -- sets the variable itself); never overrides the user's setting.
+        (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+#endif
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
         g_device_count = n;
@@ -730,7 +738,10 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     std::vector<CmEncodeJob> jobs;
     const s32 nwin = (n + window - 1) / window;
     const s32 lag = ns - 1;  // window k is finished in iteration k + lag
+    static const bool trace_rings = getenv("BZ3_HIP_TRACE_RINGS") != nullptr;  // (diagnosis, read once: see decode_group)
+    double tr_prep = 0, tr_wait = 0, tr_fin = 0, tr_t0 = now_ms();
     for (s32 k = 0; k < nwin + lag; k++) {
+        const double tr_a = now_ms();
         if (k < nwin) {  // prepare window k, then start its drivers on the slot's side stream
             const int q = (int)(k % ns);
             Window & w = win[q];
@@ -752,6 +763,8 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
                 HIP_CHECK(hipEventRecord(lead->ctx->ev_d1[q], sq));
             }
         }
+        const double tr_b = now_ms();
+        tr_prep += tr_b - tr_a;
         if (k >= lag) {  // finish window k-lag: its drivers have had the whole-GPU work of `lag` other windows to hide behind
             const int q = (int)((k - lag) % ns);
             Window & w = win[q];
@@ -759,6 +772,7 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
             if (!w.lz.empty()) {
                 HIP_CHECK(hipEventSynchronize(lead->ctx->ev_d1[q]));
                 (void)hipEventElapsedTime(&driver_ms, lead->ctx->ev_d0[q], lead->ctx->ev_d1[q]);
+                tr_wait += now_ms() - tr_b;
             }
             for (s32 i = w.w0; i < w.w1; i++) {
                 encode_front_b(sts[i], arena, w.ctxs[(size_t)(i - w.w0)], driver_ms);
@@ -775,7 +789,11 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
                 lean_return(sts[i]);  // blocks that left the pipeline early (stored, failed) still hold their swap buffer
             }
         }
+        tr_fin += now_ms() - tr_b;
     }
+    if (trace_rings)
+        fprintf(stderr, "[bz3 rings] encode front end: %d blocks, %d windows of %d x %d slots: %.1f ms = CRC / mRLE / LZP prepare %.1f + waiting for a window's LZP drivers %.1f + LZP emit / BWT / header %.1f\n",
+                (int)n, (int)nwin, (int)window, (int)ns, now_ms() - tr_t0, tr_prep, tr_wait, tr_fin - tr_wait);
     const float cm_ms = run_cm_jobs(lead->ctx, arena, jobs, d_jobs, lead->stream, lead->ev0, lead->ev1,
                                     [](const CmEncodeJob * j, u32 nj, hipStream_t st, int variant) { cm_encode_batch(j, nj, st, variant); });
     for (s32 i = 0; i < n; i++) encode_finish(sts[i], cm_ms);
@@ -1085,7 +1103,11 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     DrainOnUnwind drain{s, lead->ctx->aux, DeviceCtx::AUX};
     const s32 nwin = (n + tail_window - 1) / tail_window;
     const s32 lag = tail_slots - 1;  // window k is finished in iteration k + lag
+    // BZ3_HIP_TRACE_RINGS=1 (diagnosis, read once): where this thread's wall time goes in the ring -- a line on stderr when the call ends
+    static const bool trace_rings = getenv("BZ3_HIP_TRACE_RINGS") != nullptr;
+    double tr_unbwt = 0, tr_wait = 0, tr_finish = 0, tr_t0 = now_ms();
     for (s32 k = 0; k < nwin + lag; k++) {
+        const double tr_a = now_ms();
         if (k < nwin) {  // window k: inverse BWTs on the group's stream, then its LZP decoders on the slot's side stream
             const int q = (int)(k % tail_slots);
             hipStream_t s2 = lead->ctx->aux[q];
@@ -1131,11 +1153,14 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
                 HIP_CHECK(hipEventRecord(lead->ctx->ev_d1[q], s2));
             }
         }
+        const double tr_b = now_ms();
+        tr_unbwt += tr_b - tr_a;
         if (k >= lag) {  // finish window k-lag: its LZP decoders have had the inverse BWTs of `lag` other windows to hide behind
             const int q = (int)((k - lag) % tail_slots);
             TailWindow & w = tw[q];
             if (!w.lz_jobs.empty()) {
                 HIP_CHECK(hipEventSynchronize(lead->ctx->ev_d1[q]));
+                tr_wait += now_ms() - tr_b;
                 float ms = 0.f;
                 (void)hipEventElapsedTime(&ms, lead->ctx->ev_d0[q], lead->ctx->ev_d1[q]);
                 for (s32 i : w.lz_owner) sts[i]->t[BZ3_HIP_T_LZP] = ms;
@@ -1162,7 +1187,11 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
                 give_back(i);
             }
         }
+        tr_finish += now_ms() - tr_b;
     }
+    if (trace_rings)
+        fprintf(stderr, "[bz3 rings] decode tail: %d blocks, %d windows of %d x %d slots: %.1f ms = inverse BWTs + LZP launches %.1f + waiting for a window's LZP decoders %.1f + mRLE / CRC / hand-back %.1f\n",
+                (int)n, (int)nwin, (int)tail_window, (int)tail_slots, now_ms() - tr_t0, tr_unbwt, tr_wait, tr_finish - tr_wait);
     for (s32 i = 0; i < n; i++) sts[i]->pending = bz3_state::NONE;
 }
 
