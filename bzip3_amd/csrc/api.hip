@@ -60,21 +60,78 @@ struct DeviceCtx {
     hipStream_t aux[AUX] = {};
     hipEvent_t ev_prep = nullptr, ev_d0[AUX] = {}, ev_d1[AUX] = {};
     bool aux_ready = false;
+    // CU partition (round 5).  The serial kernels on the side streams hold a CU each for the better part of a second (an LZP decoder: 1024 lanes, ~0.5 s per
+    // 256 MiB block), and a whole-GPU kernel that finds half of such a CU's wave slots taken runs its workgroups there at a fraction of the pace -- the
+    // inverse BWT's walk kernels, whose launch lasts as long as their slowest workgroup, measured 2.5x their stand-alone time beside the decoders of three
+    // windows (profiles/r05_rings_256x64MiB.txt: the tail's host thread spent 82 % of its time in the inverse-BWT loop, 0.6 % waiting for LZP decoders).
+    // So the side streams are created on `reserve` CUs of their own and the tail's whole-GPU kernels run on a stream masked to the OTHER CUs
+    // (hipExtStreamCreateWithCUMask); the CM launches keep the group's unmasked stream (they need every CU).  BZ3_HIP_CU_RESERVE=<CUs> (read once;
+    // default 32, 0 = no partition).  Falls back to plain streams when the runtime refuses.
+    hipStream_t rest = nullptr;   // whole-GPU kernels beside the side streams' serial kernels: every CU but the reserved ones (null: no partition)
+    int reserved_cus = 0;
+    static int cu_reserve_setting() {
+        static const int v = [] {
+            const char * e = getenv("BZ3_HIP_CU_RESERVE");
+            return e ? atoi(e) : 32;
+        }();
+        return v;
+    }
+    // Mask bit i of the reserved set: 32 a + 8 t + ((a + 2 t) mod 8) for a < 8, t < reserve / 8 -- one CU in four of every block of 32 bits AND of every
+    // residue class mod 8, so that each XCD gives up the same number of CUs whether the driver deals the mask bits to the XCDs in blocks or round robin.
+    static void cu_masks(int cus, int reserve, std::vector<uint32_t> & side, std::vector<uint32_t> & main) {
+        const int words = (cus + 31) / 32;
+        side.assign((size_t)words, 0u);
+        main.assign((size_t)words, 0u);
+        for (int i = 0; i < cus; i++) main[(size_t)(i >> 5)] |= 1u << (i & 31);
+        const int per = reserve / 8 > 0 ? reserve / 8 : 1;
+        for (int a = 0; a < 8 && a * 32 < cus; a++)
+            for (int t = 0; t < per && t < 4; t++) {
+                const int i = 32 * a + 8 * t + ((a + 2 * t) & 7);
+                if (i < cus) {
+                    side[(size_t)(i >> 5)] |= 1u << (i & 31);
+                    main[(size_t)(i >> 5)] &= ~(1u << (i & 31));
+                }
+            }
+    }
     void ensure_aux() {  // caller holds mu
         if (aux_ready) return;
         // built into locals and committed only when everything exists: a failure half way must not leave a context whose first
         // stream is there and whose events are not (every later call would record on null events)
-        hipStream_t st[AUX] = {};
+        hipStream_t st[AUX] = {}, rs = nullptr;
         hipEvent_t e0[AUX] = {}, e1[AUX] = {}, ep = nullptr;
+        int reserved = 0;
         try {
             HIP_CHECK(hipEventCreate(&ep));
+#ifndef BZ3_EMU
+            const int want = cu_reserve_setting();
+            int real_cus = 0;  // (the device's own count: `cus` may be a test's pretence, BZ3_HIP_CUS)
+            if (hipDeviceGetAttribute(&real_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) real_cus = 0;
+            if (want >= 8 && real_cus >= 64 && real_cus % 32 == 0) {
+                std::vector<uint32_t> side, mainm;
+                cu_masks(real_cus, want, side, mainm);
+                bool ok = hipExtStreamCreateWithCUMask(&rs, (uint32_t)mainm.size(), mainm.data()) == hipSuccess;
+                for (int k = 0; ok && k < AUX; k++) ok = hipExtStreamCreateWithCUMask(&st[k], (uint32_t)side.size(), side.data()) == hipSuccess;
+                if (!ok) {  // the runtime refuses: plain streams below
+                    (void)hipGetLastError();
+                    if (rs) (void)hipStreamDestroy(rs);
+                    rs = nullptr;
+                    for (int k = 0; k < AUX; k++) {
+                        if (st[k]) (void)hipStreamDestroy(st[k]);
+                        st[k] = nullptr;
+                    }
+                } else {
+                    for (uint32_t wd : side) reserved += __builtin_popcount(wd);
+                }
+            }
+#endif
             for (int k = 0; k < AUX; k++) {
-                HIP_CHECK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
+                if (!st[k]) HIP_CHECK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
                 HIP_CHECK(hipEventCreate(&e0[k]));
                 HIP_CHECK(hipEventCreate(&e1[k]));
             }
         } catch (...) {
             if (ep) (void)hipEventDestroy(ep);
+            if (rs) (void)hipStreamDestroy(rs);
             for (int k = 0; k < AUX; k++) {
                 if (st[k]) (void)hipStreamDestroy(st[k]);
                 if (e0[k]) (void)hipEventDestroy(e0[k]);
@@ -83,6 +140,8 @@ struct DeviceCtx {
             throw;
         }
         ev_prep = ep;
+        rest = rs;
+        reserved_cus = reserved;
         for (int k = 0; k < AUX; k++) {
             aux[k] = st[k];
             ev_d0[k] = e0[k];
@@ -707,6 +766,13 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     lead->ctx->ensure_aux();
     hipStream_t s = lead->stream;
     DrainOnUnwind drain{s, lead->ctx->aux, DeviceCtx::AUX};
+    // BZ3_HIP_FRONT_REST=1 (experiment, read once): the front end's whole-GPU kernels also keep off the CUs reserved for the side streams' LZP drivers
+    static const bool front_rest = [] { const char * e = getenv("BZ3_HIP_FRONT_REST"); return e && atoi(e) != 0; }();
+    if (front_rest && lead->ctx->rest && n > 1) {
+        s = lead->ctx->rest;
+        for (s32 i = 0; i < n; i++) sts[i]->xs = s;
+    }
+    DrainOnUnwind drain_rest{s == lead->stream ? nullptr : s, nullptr, 0};
     Arena arena;
     for (;;) {  // hipMemGetInfo's figure is not a promise (fragmentation, another process on the device): shrink the ring before giving up
         try {
@@ -794,6 +860,11 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     if (trace_rings)
         fprintf(stderr, "[bz3 rings] encode front end: %d blocks, %d windows of %d x %d slots: %.1f ms = CRC / mRLE / LZP prepare %.1f + waiting for a window's LZP drivers %.1f + LZP emit / BWT / header %.1f\n",
                 (int)n, (int)nwin, (int)window, (int)ns, now_ms() - tr_t0, tr_prep, tr_wait, tr_fin - tr_wait);
+    if (s != lead->stream) {  // the CM launch needs every CU: back to the group's unmasked stream, behind the front end
+        HIP_CHECK(hipStreamSynchronize(s));
+        s = lead->stream;
+        for (s32 i = 0; i < n; i++) sts[i]->xs = s;
+    }
     const float cm_ms = run_cm_jobs(lead->ctx, arena, jobs, d_jobs, lead->stream, lead->ev0, lead->ev1,
                                     [](const CmEncodeJob * j, u32 nj, hipStream_t st, int variant) { cm_encode_batch(j, nj, st, variant); });
     for (s32 i = 0; i < n; i++) encode_finish(sts[i], cm_ms);
@@ -1101,6 +1172,14 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     };
     lead->ctx->ensure_aux();
     DrainOnUnwind drain{s, lead->ctx->aux, DeviceCtx::AUX};
+    // The tail's whole-GPU kernels keep off the CUs the side streams' LZP decoders sit on (DeviceCtx::rest), when the device is partitioned
+    hipStream_t s_cm = s;
+    if (lead->ctx->rest && (size_t)n > 1) {
+        HIP_CHECK(hipStreamSynchronize(s));  // headers, stored blocks' CRCs and the CM launches ran on the group's stream
+        s = lead->ctx->rest;
+        for (s32 i = 0; i < n; i++) sts[i]->xs = s;
+    }
+    DrainOnUnwind drain_rest{s == s_cm ? nullptr : s, nullptr, 0};
     const s32 nwin = (n + tail_window - 1) / tail_window;
     const s32 lag = tail_slots - 1;  // window k is finished in iteration k + lag
     // BZ3_HIP_TRACE_RINGS=1 (diagnosis, read once): where this thread's wall time goes in the ring -- a line on stderr when the call ends
