@@ -49,6 +49,7 @@ def _declare(L, strict=True):
         "bz3_hip_state_device": (C.c_int, [vp]),
         "bz3_hip_set_cm_mode": (C.c_int, [C.c_int]),
         "bz3_hip_cm_blocks_given_up": (C.c_uint, []),
+        "bz3_hip_cm_blocks_routed_full": (C.c_uint, []),
         "bz3_hip_debug_bwt_big_rounds": (None, [C.c_int]),
         "bz3_hip_debug_peak_concurrent_groups": (C.c_int, [C.c_int]),
         "bz3_hip_debug_front_end_ring": (C.c_int, []),

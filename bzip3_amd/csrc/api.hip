@@ -68,6 +68,8 @@ struct DeviceCtx {
     // (hipExtStreamCreateWithCUMask); the CM launches keep the group's unmasked stream (they need every CU).  BZ3_HIP_CU_RESERVE=<CUs> (read once;
     // default 32, 0 = no partition).  Falls back to plain streams when the runtime refuses.
     hipStream_t rest = nullptr;   // whole-GPU kernels beside the side streams' serial kernels: every CU but the reserved ones (null: no partition)
+    hipStream_t aux_m[RING_SLOTS] = {};  // the decoder's side streams, on the reserved CUs (the encoder's rings keep the plain ones: call 4 measured its
+                                         // front end 6 % SLOWER with its LZP drivers confined to 32 CUs, profiles/r05_cu_partition_256x64MiB.txt)
     int reserved_cus = 0;
     static int cu_reserve_setting() {
         static const int v = [] {
@@ -97,7 +99,7 @@ struct DeviceCtx {
         if (aux_ready) return;
         // built into locals and committed only when everything exists: a failure half way must not leave a context whose first
         // stream is there and whose events are not (every later call would record on null events)
-        hipStream_t st[AUX] = {}, rs = nullptr;
+        hipStream_t st[AUX] = {}, sm[RING_SLOTS] = {}, rs = nullptr;
         hipEvent_t e0[AUX] = {}, e1[AUX] = {}, ep = nullptr;
         int reserved = 0;
         try {
@@ -110,14 +112,14 @@ struct DeviceCtx {
                 std::vector<uint32_t> side, mainm;
                 cu_masks(real_cus, want, side, mainm);
                 bool ok = hipExtStreamCreateWithCUMask(&rs, (uint32_t)mainm.size(), mainm.data()) == hipSuccess;
-                for (int k = 0; ok && k < AUX; k++) ok = hipExtStreamCreateWithCUMask(&st[k], (uint32_t)side.size(), side.data()) == hipSuccess;
-                if (!ok) {  // the runtime refuses: plain streams below
+                for (int k = 0; ok && k < RING_SLOTS; k++) ok = hipExtStreamCreateWithCUMask(&sm[k], (uint32_t)side.size(), side.data()) == hipSuccess;
+                if (!ok) {  // the runtime refuses: plain streams only
                     (void)hipGetLastError();
                     if (rs) (void)hipStreamDestroy(rs);
                     rs = nullptr;
-                    for (int k = 0; k < AUX; k++) {
-                        if (st[k]) (void)hipStreamDestroy(st[k]);
-                        st[k] = nullptr;
+                    for (int k = 0; k < RING_SLOTS; k++) {
+                        if (sm[k]) (void)hipStreamDestroy(sm[k]);
+                        sm[k] = nullptr;
                     }
                 } else {
                     for (uint32_t wd : side) reserved += __builtin_popcount(wd);
@@ -125,13 +127,15 @@ struct DeviceCtx {
             }
 #endif
             for (int k = 0; k < AUX; k++) {
-                if (!st[k]) HIP_CHECK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
+                HIP_CHECK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
                 HIP_CHECK(hipEventCreate(&e0[k]));
                 HIP_CHECK(hipEventCreate(&e1[k]));
             }
         } catch (...) {
             if (ep) (void)hipEventDestroy(ep);
             if (rs) (void)hipStreamDestroy(rs);
+            for (int k = 0; k < RING_SLOTS; k++)
+                if (sm[k]) (void)hipStreamDestroy(sm[k]);
             for (int k = 0; k < AUX; k++) {
                 if (st[k]) (void)hipStreamDestroy(st[k]);
                 if (e0[k]) (void)hipEventDestroy(e0[k]);
@@ -141,6 +145,7 @@ struct DeviceCtx {
         }
         ev_prep = ep;
         rest = rs;
+        for (int k = 0; k < RING_SLOTS; k++) aux_m[k] = sm[k];
         reserved_cus = reserved;
         for (int k = 0; k < AUX; k++) {
             aux[k] = st[k];
@@ -227,6 +232,7 @@ std::atomic<int> g_lean{-1};  // -1 = not read from the environment yet; see bz3
 std::atomic<int> g_front_end_ring{0};  // window | slots << 16 of the last encode_group (bz3_hip_debug_front_end_ring)
 std::atomic<int> g_arena_swaps{0};  // swap buffers served from the arena (bz3_hip_debug_arena_swap_buffers)
 std::atomic<unsigned> g_cm_given_up{0};  // blocks the row-cache CM kernels handed back to the full-model kernels (statistics)
+std::atomic<unsigned> g_cm_routed_full{0};  // blocks sent straight to the full-model kernels by their histogram / payload size (statistics)
 
 int device_count() {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -342,9 +348,33 @@ size_t cm_scratch_bytes(size_t njobs) { return njobs * (CM_SPILL_BYTES + 256) + 
 
 // Runs the CM kernel over `jobs` (host copies; d_jobs has room for all of them) and returns the kernel time in ms.
 // Row-cache variants: blocks the kernel gave up are coded again by the full-model kernel in a second launch.
+// to_full (optional, one flag per job): blocks known not to fit the row cache -- many live byte values (encode: from the BWT's histogram), or a
+// payload that hardly shrank (decode) -- skip the row-cache kernels and go straight into the whole-model launch (round 5; g_cm_given_up counts only
+// blocks the row-cache kernels really handed back).
 template <class Job, class Launch>
-float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs, Job * d_jobs, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, Launch && go) {
+float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs, Job * d_jobs, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, Launch && go,
+                  const std::vector<char> * to_full = nullptr) {
     if (jobs.empty()) return 0.f;
+    std::vector<Job> direct;  // straight to the whole-model kernel
+    if (to_full && cm_mode() < 0) {
+        std::vector<Job> keep;
+        for (size_t i = 0; i < jobs.size(); i++) ((*to_full)[i] ? direct : keep).push_back(jobs[i]);
+        if (!direct.empty()) {
+            g_cm_routed_full.fetch_add((unsigned)direct.size());
+            jobs.swap(keep);
+        }
+    }
+    if (jobs.empty()) {  // everything is whole-model work: one launch
+        float ms0 = 0.f;
+        HIP_CHECK(hipMemcpyAsync(d_jobs, direct.data(), sizeof(Job) * direct.size(), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipEventRecord(ev0, s));
+        go(d_jobs, (u32)direct.size(), s, (int)CM_VARIANT_FULL);
+        HIP_CHECK(hipEventRecord(ev1, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        (void)hipEventElapsedTime(&ms0, ev0, ev1);
+        jobs.swap(direct);
+        return ms0;
+    }
     const int variant = cm_variant_for(ctx, jobs.size(), std::is_same<Job, CmEncodeJob>::value);
     const size_t mk = arena.mark();
     u32 * d_status = nullptr;
@@ -374,6 +404,8 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
         for (size_t i = 0; i < jobs.size(); i++)
             if (status[i]) again.push_back(jobs[i]);
         g_cm_given_up.fetch_add((unsigned)again.size());
+        again.insert(again.end(), direct.begin(), direct.end());
+        direct.clear();
         if (!again.empty()) {
             HIP_CHECK(hipMemcpyAsync(d_jobs, again.data(), sizeof(Job) * again.size(), hipMemcpyHostToDevice, s));
             HIP_CHECK(hipEventRecord(ev0, s));
@@ -382,6 +414,16 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
             HIP_CHECK(hipStreamSynchronize(s));
             (void)hipEventElapsedTime(&ms2, ev0, ev1);
         }
+    }
+    if (!direct.empty()) {  // (the variant had no row cache: nothing was handed back, the routed blocks still wait)
+        HIP_CHECK(hipMemcpyAsync(d_jobs, direct.data(), sizeof(Job) * direct.size(), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipEventRecord(ev0, s));
+        go(d_jobs, (u32)direct.size(), s, (int)CM_VARIANT_FULL);
+        HIP_CHECK(hipEventRecord(ev1, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        float ms3 = 0.f;
+        (void)hipEventElapsedTime(&ms3, ev0, ev1);
+        ms2 += ms3;
     }
     arena.release(mk);
     return ms + ms2;
@@ -609,16 +651,17 @@ void encode_front_b(bz3_state * st, Arena & arena, const LzpEncodeCtx & c, float
 
     t0 = now_ms();
     u32 * const d_idx = st->d_words + 6;  // the primary index never visits the host
+    u32 * const d_out8 = st->d_words + 8;  // bytes outside the block's 40 most frequent values: decides the CM kernel variant (run_cm_jobs)
     if (!st->lean) {
-        (void)bwt_forward(b1, n, b2, arena, s, &st->bwt, d_idx);  // :623-627
+        (void)bwt_forward(b1, n, b2, arena, s, &st->bwt, d_idx, d_out8);  // :623-627
     } else {
         // Lean state: the coder will work IN PLACE in the caller's buffer (capacity bz3_bound(size), libbz3.h:172-174):
         // the BWT output goes to the END of that buffer, the coded bytes grow from its start (cm.hip CmSink).
         u8 * tail = st->user + bz3_bound((size_t)st->size) - n;
         if (b1 != st->user) {
-            (void)bwt_forward(b1, n, tail, arena, s, &st->bwt, d_idx);
+            (void)bwt_forward(b1, n, tail, arena, s, &st->bwt, d_idx, d_out8);
         } else {
-            (void)bwt_forward(b1, n, b2, arena, s, &st->bwt, d_idx);
+            (void)bwt_forward(b1, n, b2, arena, s, &st->bwt, d_idx, d_out8);
             HIP_CHECK(hipMemcpyAsync(tail, b2, n, hipMemcpyDeviceToDevice, s));
         }
         b1 = st->user;  // receives header + coded bytes
@@ -802,6 +845,7 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         win[k].d_lz = arena.take<LzpDriverJob>((size_t)window);
     }
     std::vector<CmEncodeJob> jobs;
+    std::vector<s32> job_owner;
     const s32 nwin = (n + window - 1) / window;
     const s32 lag = ns - 1;  // window k is finished in iteration k + lag
     static const bool trace_rings = getenv("BZ3_HIP_TRACE_RINGS") != nullptr;  // (diagnosis, read once: see decode_group)
@@ -851,6 +895,7 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
                         j.side_cap = CM_SIDE_BYTES;
                     }
                     jobs.push_back(j);
+                    job_owner.push_back(i);
                 }
                 lean_return(sts[i]);  // blocks that left the pipeline early (stored, failed) still hold their swap buffer
             }
@@ -865,8 +910,19 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         s = lead->stream;
         for (s32 i = 0; i < n; i++) sts[i]->xs = s;
     }
+    // which blocks do not fit a row cache: the bytes outside the block's 40 most frequent values (bwt.hip k_bwt_outside) -- one small read-back per
+    // block, all behind the one synchronisation the CM launch needs anyway
+    std::vector<char> to_full(jobs.size(), 0);
+    if (jobs.size() > (size_t)lead->ctx->cus) {  // (only batches that would take a row-cache variant)
+        std::vector<u32> outside(jobs.size(), 0u);
+        for (size_t k = 0; k < jobs.size(); k++) HIP_CHECK(hipMemcpyAsync(&outside[k], sts[job_owner[k]]->d_words + 8, 4, hipMemcpyDeviceToHost, lead->stream));
+        HIP_CHECK(hipStreamSynchronize(lead->stream));
+        // (half of what the row-cache kernels tolerate before they give a block up -- CM_MISS_BASE + position >> CM_MISS_SHIFT row misses, and a byte
+        // outside the cached values costs about one)
+        for (size_t k = 0; k < jobs.size(); k++) to_full[k] = outside[k] > CM_MISS_BASE / 2u + (jobs[k].n >> (CM_MISS_SHIFT + 1u)) ? 1 : 0;
+    }
     const float cm_ms = run_cm_jobs(lead->ctx, arena, jobs, d_jobs, lead->stream, lead->ev0, lead->ev1,
-                                    [](const CmEncodeJob * j, u32 nj, hipStream_t st, int variant) { cm_encode_batch(j, nj, st, variant); });
+                                    [](const CmEncodeJob * j, u32 nj, hipStream_t st, int variant) { cm_encode_batch(j, nj, st, variant); }, &to_full);
     for (s32 i = 0; i < n; i++) encode_finish(sts[i], cm_ms);
     // Hand-back only where it matters: a workspace that a GPU-filling batch grew to tens of GB (the decode call that follows needs the
     // room).  A stream of ordinary batches (the CLI, bz3_hip_encode_stream) keeps its workspace: a multi-GB hipMalloc plus a
@@ -1108,8 +1164,10 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     for (size_t r = 0, k0 = 0; r < round_end.size(); k0 = round_end[r++]) {
         const size_t mk = arena.mark();
         std::vector<CmDecodeJob> cm_jobs;
+        std::vector<char> to_full;  // a payload that hardly shrank has (nearly) every byte value live: no row cache holds that
         for (size_t k = k0; k < round_end[r]; k++) {
             bz3_state * st = sts[coded[k]];
+            to_full.push_back((u64)st->cm_in_size * 10u >= (u64)(u32)st->size_before_bwt * 9u ? 1 : 0);
             const u8 * in = st->cm_in;
             if (st->lean) {
                 u8 * stage = arena.take<u8>(stage_bytes(coded[k]));
@@ -1120,7 +1178,7 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
         }
         CmDecodeJob * d_jobs = arena.take<CmDecodeJob>(cm_jobs.size());
         cm_ms += run_cm_jobs(lead->ctx, arena, cm_jobs, d_jobs, s, lead->ev0, lead->ev1,
-                             [](const CmDecodeJob * j, u32 nj, hipStream_t st, int variant) { cm_decode_batch(j, nj, st, variant); });
+                             [](const CmDecodeJob * j, u32 nj, hipStream_t st, int variant) { cm_decode_batch(j, nj, st, variant); }, &to_full);
         arena.release(mk);
     }
     // ---- phases 3-5 per tail window: inverse BWT per block, ONE LZP-decode launch (one workgroup per block), mRLE + CRC ----
@@ -1174,12 +1232,14 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     DrainOnUnwind drain{s, lead->ctx->aux, DeviceCtx::AUX};
     // The tail's whole-GPU kernels keep off the CUs the side streams' LZP decoders sit on (DeviceCtx::rest), when the device is partitioned
     hipStream_t s_cm = s;
-    if (lead->ctx->rest && (size_t)n > 1) {
+    hipStream_t * side_streams = lead->ctx->aux;
+    if (lead->ctx->rest && (size_t)n > 1 && tail_slots <= DeviceCtx::RING_SLOTS) {
+        side_streams = lead->ctx->aux_m;
         HIP_CHECK(hipStreamSynchronize(s));  // headers, stored blocks' CRCs and the CM launches ran on the group's stream
         s = lead->ctx->rest;
         for (s32 i = 0; i < n; i++) sts[i]->xs = s;
     }
-    DrainOnUnwind drain_rest{s == s_cm ? nullptr : s, nullptr, 0};
+    DrainOnUnwind drain_rest{s == s_cm ? nullptr : s, side_streams == lead->ctx->aux ? nullptr : side_streams, side_streams == lead->ctx->aux ? 0 : DeviceCtx::RING_SLOTS};
     const s32 nwin = (n + tail_window - 1) / tail_window;
     const s32 lag = tail_slots - 1;  // window k is finished in iteration k + lag
     // BZ3_HIP_TRACE_RINGS=1 (diagnosis, read once): where this thread's wall time goes in the ring -- a line on stderr when the call ends
@@ -1189,7 +1249,7 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
         const double tr_a = now_ms();
         if (k < nwin) {  // window k: inverse BWTs on the group's stream, then its LZP decoders on the slot's side stream
             const int q = (int)(k % tail_slots);
-            hipStream_t s2 = lead->ctx->aux[q];
+            hipStream_t s2 = side_streams[q];
             TailWindow & w = tw[q];
             w.w0 = k * tail_window;
             w.w1 = (w.w0 + tail_window < n) ? w.w0 + tail_window : n;
@@ -1637,6 +1697,7 @@ void collect(int kind, SingleReq & r) {
 }
 }  // namespace
 
+BZIP3_API unsigned bz3_hip_cm_blocks_routed_full(void) { return g_cm_routed_full.load(); }
 BZIP3_API void bz3_hip_set_collect_window_us(int us) { g_collect_window_us.store(us < 0 ? 200 : us); }
 BZIP3_API unsigned bz3_hip_debug_collected_batches(int reset, unsigned * largest) {  // batches run for single-block callers; *largest = blocks in the largest
     if (largest) *largest = g_collect_largest.load();

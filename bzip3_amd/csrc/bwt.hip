@@ -48,6 +48,22 @@ constexpr int BW_BLOCK = 256;
 constexpr u32 V_HEAD = 0x80000000u;  // slot starts a group
 constexpr u32 V_MASK = 0x3FFFFFFFu;  // suffix number (n < 2^30: bz3_bound(511 MiB) = 546.5 M)
 
+// Bytes of the block that are NOT among its `keep` most frequent byte values (one workgroup of 256: thread c ranks the count of byte value c).
+// The BWT output has the block's histogram, and the CM stage's row-cache kernels hold ~40 order-1 rows per block: api.hip routes a block
+// whose rarer values make up more than half of the row misses those kernels tolerate straight to the whole-model kernels (round 5; before, the row-cache kernels had to give it up first).
+__global__ void __launch_bounds__(256) k_bwt_outside(const u32 * __restrict__ hist, u32 keep, u32 * __restrict__ out) {
+    __shared__ u32 h[256];
+    __shared__ u32 red[256 / WAVE + 1];
+    const u32 c = threadIdx.x;
+    h[c] = hist[c];
+    __syncthreads();
+    const u32 mine = h[c];
+    u32 rank = 0;  // byte values that come before c in (count descending, value ascending) order
+    for (u32 k = 0; k < 256u; k++) rank += (h[k] > mine || (h[k] == mine && k < c)) ? 1u : 0u;
+    const u32 tot = block_sum<256>(rank >= keep ? mine : 0u, red);
+    if (c == 0) *out = tot;
+}
+
 // ---- the order-preserving code ----------------------------------------------------------------------------------------------
 // vlc[c] = code << 4 | len (1 <= len <= 8) for byte values present in the block, 0 otherwise.
 constexpr int VLC_MAXLEN = 8;
@@ -1518,7 +1534,8 @@ __global__ void k_bwt_set_word(u32 * p, u32 v) { *p = v; }
 
 // d_idx == nullptr: synchronous, returns the primary index.  d_idx != nullptr: the primary index is left THERE (a device word that outlives
 // the arena) and the call returns 0 without waiting for the stream -- the block's header is written by a kernel that reads it (round 4).
-s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, BwtStats * stats, u32 * d_idx) {
+s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, BwtStats * stats, u32 * d_idx, u32 * d_outside) {
+    if (d_outside && n < 2) HIP_CHECK(hipMemsetAsync(d_outside, 0, 4, s));
     if (n == 0) {
         if (d_idx) launch(k_bwt_set_word, dim3(1), dim3(1), 0, s, d_idx, 0u);
         return 0;
@@ -1557,6 +1574,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
     HIP_CHECK(hipMemsetAsync(d_words, 0, 16 * sizeof(u32), s));
     HIP_CHECK(hipMemsetAsync(d_words + 5, 0xFF, sizeof(u32), s));
     launch(k_bwt_sym_hist, grid(((u64)n + 63) / 64), dim3(BW_BLOCK), 0, s, d_in, n, d_hist);
+    if (d_outside) launch(k_bwt_outside, dim3(1), dim3(256), 0, s, (const u32 *)d_hist, (u32)BWT_ROUTE_KEEP, d_outside);
     {
         const size_t vm = tmp.mark();
         vlc_build_device(d_hist, d_vlc, tmp, s);  // (stream order protects the scratch: what reuses it is launched after the last level)

@@ -83,7 +83,9 @@ struct BwtStats {
     u64 sorted_elements = 0;  // sum over rounds of elements that went through the radix sorter
     int radix_passes = 0;
 };
-s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, BwtStats * stats, u32 * d_idx = nullptr);
+// d_outside (optional device word): receives the number of bytes of the block outside its BWT_ROUTE_KEEP most frequent byte values.
+constexpr int BWT_ROUTE_KEEP = 40;
+s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, BwtStats * stats, u32 * d_idx = nullptr, u32 * d_outside = nullptr);
 size_t bwt_workspace_bytes(u64 n);
 void bwt_set_big_rounds(int k);  // tests only: more windows for the big groups before the deep path (k < 0: the default, 1)
 

@@ -42,6 +42,7 @@ BZIP3_API int bz3_hip_set_cm_mode(int mode);
  * takes them (0 = none: straight to the deep path; k < 0 = the default, 1).  Output bytes do not depend on it. */
 BZIP3_API void bz3_hip_debug_bwt_big_rounds(int k);
 /* Number of blocks the row-cache kernels have handed back to the full-model kernels so far (statistics). */
+BZIP3_API unsigned bz3_hip_cm_blocks_routed_full(void); /* statistics: blocks of GPU-filling batches sent straight to the whole-model CM kernels (many live byte values / a payload that hardly shrank) */
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void);
 
 /* The CM kernel variant (0..8, 12 as above) a batch of `blocks` blocks on `device` is coded (encode != 0) or decoded with under the

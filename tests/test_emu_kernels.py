@@ -376,15 +376,18 @@ print("ok")
         assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (seed, r.stdout[-300:], r.stderr[-800:])
 
 
-def test_cm_policy_by_batch_size_hands_blocks_back(oracle):
-    """The default policy picks the CM kernels by batch size (api.hip cm_variant_for): with BZ3_HIP_CUS=2 a batch of 3 blocks takes the
-    two-per-CU row-cache kernels, a batch of 5 the three-per-CU kernels; random blocks are handed back to the full-model kernel inside
-    the same call, both ways.  Subprocess: the CU count is read when the device context is created."""
+def test_cm_policy_by_batch_size_routes_and_hands_blocks_back(oracle):
+    """The default policy picks the CM kernels by batch size (api.hip cm_variant_for): with BZ3_HIP_CUS=2 a batch of 4 blocks takes the
+    two-per-CU row-cache kernels, a batch of 5 the three-per-CU kernels.  Round 5: blocks that cannot fit a row cache go STRAIGHT to the
+    whole-model kernel inside the same call -- on encode by the BWT's histogram (bytes outside the 40 most frequent values > 512 + n / 64: the random
+    block and the 112-value one), on decode by a payload that hardly shrank (the random block); the 112-value block, which shrinks by 14 %, still reaches
+    the row-cache decoder, is handed back by it and decoded again.  Subprocess: the CU count is read when the device context is created."""
     import subprocess
 
     code = r'''
 import sys, ctypes as C
 sys.path[:0] = [%r, %r, %r]
+import numpy as np
 import bzip3_amd, datagen
 from build_emu import build
 from oracle_lib import Oracle
@@ -394,8 +397,9 @@ assert lib.bz3_hip_set_cm_mode(-1) == 0
 assert [lib.bz3_hip_cm_variant_for(0, k, e) for k in (1, 2, 3, 4, 5) for e in (0, 1)] == [0, 0, 0, 0, 1, 1, 1, 1, 2, 2]
 bs = 65 * 1024
 t = datagen.shakespeare()
-for n in (3, 5):
-    blocks = [t[i * 900 : i * 900 + 700 + i] for i in range(n - 1)] + [datagen.random_bytes(6000, seed=n)]  # (given up once its misses pass 1024 + position / 32)
+walk = (np.random.default_rng(3).integers(0, 112, 30000)).astype(np.uint8).tobytes()  # 112 equally likely byte values: shrinks to ~0.86, but no row cache holds 112 rows
+for n in (4, 5):
+    blocks = [t[i * 900 : i * 900 + 700 + i] for i in range(n - 2)] + [datagen.random_bytes(6000, seed=n), walk]
     states = (C.c_void_p * n)(*[lib.bz3_new(bs) for _ in range(n)])
     cap = lib.bz3_bound(bs) + 64
     bufs = [(C.c_uint8 * cap)() for _ in range(n)]
@@ -403,18 +407,20 @@ for n in (3, 5):
         C.memmove(b, d, len(d))
     ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
     sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
-    g0 = lib.bz3_hip_cm_blocks_given_up()
+    g0, r0 = lib.bz3_hip_cm_blocks_given_up(), lib.bz3_hip_cm_blocks_routed_full()
     lib.bz3_encode_blocks(states, ptrs, sizes, n)
-    g1 = lib.bz3_hip_cm_blocks_given_up()
+    g1, r1 = lib.bz3_hip_cm_blocks_given_up(), lib.bz3_hip_cm_blocks_routed_full()
     for i, d in enumerate(blocks):
         assert bytes(bufs[i][: sizes[i]]) == o.encode_block(d, bs)[2], (n, i)
+    assert sizes[n - 1] * 10 < len(walk) * 9 and sizes[n - 2] * 10 >= 6000 * 9  # the 112-value block shrank by more than a tenth, the random one did not
     bsz = (C.c_size_t * n)(*[cap] * n)
     orig = (C.c_int32 * n)(*[len(d) for d in blocks])
     lib.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
-    g2 = lib.bz3_hip_cm_blocks_given_up()
+    g2, r2 = lib.bz3_hip_cm_blocks_given_up(), lib.bz3_hip_cm_blocks_routed_full()
     for i, d in enumerate(blocks):
         assert lib.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: len(d)]) == d, (n, i)
-    assert (g1 - g0, g2 - g1) == (1, 1), (n, g1 - g0, g2 - g1)  # the random block, given up by the row-cache launch both ways
+    assert (g1 - g0, r1 - r0) == (0, 2), (n, g1 - g0, r1 - r0)  # encode: both routed by their histograms, nothing handed back
+    assert (g2 - g1, r2 - r1) == (1, 1), (n, g2 - g1, r2 - r1)  # decode: the random block routed, the 112-value one handed back by the row-cache decoder
     for s in states:
         lib.bz3_free(s)
 print("ok")
