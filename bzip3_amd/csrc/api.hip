@@ -66,7 +66,7 @@ struct DeviceCtx {
     // windows (profiles/r05_rings_256x64MiB.txt: the tail's host thread spent 82 % of its time in the inverse-BWT loop, 0.6 % waiting for LZP decoders).
     // So the side streams are created on `reserve` CUs of their own and the tail's whole-GPU kernels run on a stream masked to the OTHER CUs
     // (hipExtStreamCreateWithCUMask); the CM launches keep the group's unmasked stream (they need every CU).  BZ3_HIP_CU_RESERVE=<CUs> (read once;
-    // default 32, 0 = no partition).  Falls back to plain streams when the runtime refuses.
+    // default 48, 0 = no partition).  Falls back to plain streams when the runtime refuses.
     hipStream_t rest = nullptr;   // whole-GPU kernels beside the side streams' serial kernels: every CU but the reserved ones (null: no partition)
     hipStream_t aux_m[RING_SLOTS] = {};  // the decoder's side streams, on the reserved CUs (the encoder's rings keep the plain ones: call 4 measured its
                                          // front end 6 % SLOWER with its LZP drivers confined to 32 CUs, profiles/r05_cu_partition_256x64MiB.txt)
@@ -74,12 +74,13 @@ struct DeviceCtx {
     static int cu_reserve_setting() {
         static const int v = [] {
             const char * e = getenv("BZ3_HIP_CU_RESERVE");
-            return e ? atoi(e) : 32;
+            return e ? atoi(e) : 48;  // three windows of 16 LZP decoders in flight, a CU each (two on a CU halve each other's table-insert rate)
         }();
         return v;
     }
-    // Mask bit i of the reserved set: 32 a + 8 t + ((a + 2 t) mod 8) for a < 8, t < reserve / 8 -- one CU in four of every block of 32 bits AND of every
-    // residue class mod 8, so that each XCD gives up the same number of CUs whether the driver deals the mask bits to the XCDs in blocks or round robin.
+    // Mask bit i of the reserved set: 32 a + 8 j + ((a + 2 j + t / 4) mod 8), j = t mod 4, for a < 8 and t < reserve / 8 (at most 8) -- the same number
+    // of CUs from every block of 32 bits AND from every residue class mod 8, so that each XCD gives up equally many whether the driver deals the mask
+    // bits to the XCDs in blocks or round robin.
     static void cu_masks(int cus, int reserve, std::vector<uint32_t> & side, std::vector<uint32_t> & main) {
         const int words = (cus + 31) / 32;
         side.assign((size_t)words, 0u);
@@ -87,8 +88,9 @@ struct DeviceCtx {
         for (int i = 0; i < cus; i++) main[(size_t)(i >> 5)] |= 1u << (i & 31);
         const int per = reserve / 8 > 0 ? reserve / 8 : 1;
         for (int a = 0; a < 8 && a * 32 < cus; a++)
-            for (int t = 0; t < per && t < 4; t++) {
-                const int i = 32 * a + 8 * t + ((a + 2 * t) & 7);
+            for (int t = 0; t < per && t < 8; t++) {
+                const int j = t & 3;
+                const int i = 32 * a + 8 * j + ((a + 2 * j + (t >> 2)) & 7);
                 if (i < cus) {
                     side[(size_t)(i >> 5)] |= 1u << (i & 31);
                     main[(size_t)(i >> 5)] &= ~(1u << (i & 31));
@@ -917,9 +919,11 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         std::vector<u32> outside(jobs.size(), 0u);
         for (size_t k = 0; k < jobs.size(); k++) HIP_CHECK(hipMemcpyAsync(&outside[k], sts[job_owner[k]]->d_words + 8, 4, hipMemcpyDeviceToHost, lead->stream));
         HIP_CHECK(hipStreamSynchronize(lead->stream));
-        // (half of what the row-cache kernels tolerate before they give a block up -- CM_MISS_BASE + position >> CM_MISS_SHIFT row misses, and a byte
-        // outside the cached values costs about one)
-        for (size_t k = 0; k < jobs.size(); k++) to_full[k] = outside[k] > CM_MISS_BASE / 2u + (jobs[k].n >> (CM_MISS_SHIFT + 1u)) ? 1 : 0;
+        // Only the hopeless: more than a QUARTER of the block outside its 40 most frequent values (random data: 84 %).  The histogram is global, a row
+        // cache lives on what the BWT output uses LOCALLY: the bench's calibrated text has 3 % of its bytes outside the top 40 and misses 0.3 % of its
+        // rows -- round 5's first form of this test (outside > 512 + n / 64) sent all 768 text blocks to the whole-model kernel, one per CU, 183 s instead
+        // of 65 (profiles/r05_full_size_call5_misrouted.txt).  What lies between is left to the kernels' own give-up test.
+        for (size_t k = 0; k < jobs.size(); k++) to_full[k] = outside[k] > jobs[k].n / 4u ? 1 : 0;
     }
     const float cm_ms = run_cm_jobs(lead->ctx, arena, jobs, d_jobs, lead->stream, lead->ev0, lead->ev1,
                                     [](const CmEncodeJob * j, u32 nj, hipStream_t st, int variant) { cm_encode_batch(j, nj, st, variant); }, &to_full);

@@ -713,9 +713,15 @@ __device__ __forceinline__ void lzp_decode_block(const LzpDecodeJob * __restrict
     __shared__ u32 red[LZ_DRV / WAVE + 1];
     __shared__ u32 s_ip, s_op, s_copy_src, s_copy_cnt, s_fail;
     const u32 tid = threadIdx.x;
+    // the table starts empty (:254): zeroed here, by the workgroup that owns it -- a hipMemsetAsync per block on the launching stream was sixteen
+    // more launches per window, each of which had to find free wave slots on the CUs reserved for these kernels (round 5, api.hip DeviceCtx)
+    {
+        uint4 * __restrict__ lz = reinterpret_cast<uint4 *>(lut);  // (256-byte aligned: Arena::take)
+        for (u32 k = tid; k < (u32)(LZP_LUT_WORDS / 4); k += LZ_DRV) lz[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
     if (tid < 4) out[tid] = in[tid];
     if (tid == 0) { s_ip = 4; s_op = 4; s_fail = 0; }
-    __threadfence_block();
+    __threadfence();  // the zeroes are in L2 before the first atomic of any lane gets there
     __syncthreads();
     u64 pc_stage = 0, pc_lits = 0, pc_lane0 = 0, pc_copy = 0, pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
     u32 pc_trips = 0, pc_matches = 0;
@@ -841,7 +847,6 @@ __global__ void __launch_bounds__(LZ_DRV) k_lzp_decode_prof(const LzpDecodeJob *
 
 void lzp_decode_batch(const LzpDecodeJob * h_jobs, LzpDecodeJob * d_jobs, u32 njobs, hipStream_t s) {
     if (!njobs) return;
-    for (u32 i = 0; i < njobs; i++) HIP_CHECK(hipMemsetAsync(reinterpret_cast<void *>(h_jobs[i].lut), 0, LZP_LUT_WORDS * sizeof(u32), s));
     HIP_CHECK(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LzpDecodeJob) * njobs, hipMemcpyHostToDevice, s));
     static const bool prof = [] { const char * e = getenv("BZ3_LZP_PROF"); return e && atoi(e) != 0; }();  // (profiling only, read once)
     if (prof) launch(k_lzp_decode_prof, dim3(njobs), dim3(LZ_DRV), 0, s, (const LzpDecodeJob *)d_jobs);

@@ -67,7 +67,7 @@ s32 lzp_encode(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s); 
 struct LzpDecodeJob {  // device addresses as integers: see prims.hpp global_ptr()
     u64 in;
     u64 out;
-    u64 lut;     // 2^18 words, zeroed by lzp_decode_batch
+    u64 lut;     // 2^18 words, 16-byte aligned (the kernel zeroes them)
     u64 result;  // s32 *: decoded size or -1
     u32 n, max_out;
 };

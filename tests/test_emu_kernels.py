@@ -379,7 +379,7 @@ print("ok")
 def test_cm_policy_by_batch_size_routes_and_hands_blocks_back(oracle):
     """The default policy picks the CM kernels by batch size (api.hip cm_variant_for): with BZ3_HIP_CUS=2 a batch of 4 blocks takes the
     two-per-CU row-cache kernels, a batch of 5 the three-per-CU kernels.  Round 5: blocks that cannot fit a row cache go STRAIGHT to the
-    whole-model kernel inside the same call -- on encode by the BWT's histogram (bytes outside the 40 most frequent values > 512 + n / 64: the random
+    whole-model kernel inside the same call -- on encode by the BWT's histogram (more than a quarter of the bytes outside the 40 most frequent values: the random
     block and the 112-value one), on decode by a payload that hardly shrank (the random block); the 112-value block, which shrinks by 14 %, still reaches
     the row-cache decoder, is handed back by it and decoded again.  Subprocess: the CU count is read when the device context is created."""
     import subprocess
