@@ -57,6 +57,7 @@ def _declare(L, strict=True):
         "bz3_hip_cm_variant_for": (C.c_int, [C.c_int, C.c_int, C.c_int]),
         "bz3_hip_set_lean_states": (C.c_int, [C.c_int]),
         "bz3_hip_release_cached_memory": (None, []),
+        "bz3_hip_set_keep_workspace": (C.c_int, [C.c_int]),
         "bz3_hip_encode_block_device": (i32, [vp, vp, i32]),
         "bz3_hip_decode_block_device": (i32, [vp, vp, sz, i32, i32]),
         "bz3_hip_encode_blocks_device": (None, [vp, vp, vp, i32]),

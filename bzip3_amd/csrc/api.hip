@@ -554,12 +554,14 @@ inline bool sizes_fit(size_t buffer_size, s32 lzp_size, s32 rle_size, s32 orig_s
 // BZ3_HIP_KEEP_WS=1 (experiment, round 5's first measurement): a lean batch's workspace survives the call -- the decode call that follows reuses the
 // encode call's arena and carves the swap buffers of its tail windows from it -- instead of one hipFree and two multi-GB hipMallocs per round trip
 // (30-45 ms per GiB: profiles/r04_first_touch.txt).  Read once.
+std::atomic<int> g_keep_ws{-1};  // bz3_hip_set_keep_workspace: -1 = the environment decides
 inline bool keep_workspace() {
-    static const bool on = [] {
+    static const bool env_on = [] {
         const char * e = getenv("BZ3_HIP_KEEP_WS");
         return e && atoi(e) != 0;
     }();
-    return on;
+    const int v = g_keep_ws.load();
+    return v < 0 ? env_on : v != 0;
 }
 inline void lean_borrow(bz3_state * st) {
     if (st->lean && !st->d_swap) st->d_swap = st->ctx->temp_get(st->cap);
@@ -1147,6 +1149,11 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     // of 8 on a 128-block batch (profiles/r03_gaps_128x256MiB.txt): no gain there, where the pool's first allocations set the pace.
     s32 tail_slots = n >= 128 ? 4 : 2;
     s32 tail_window = tail_slots == 4 ? 16 : 32;
+    lead->ctx->ensure_aux();
+    // With the CU partition a window's LZP decoders want a reserved CU EACH (two on a CU halve each other's table-insert rate): windows of
+    // reserved / 4, so that even the moment a fourth window starts before the oldest has ended finds room (48 CUs: 12; call 6 ran 16 x 4 on 48 CUs:
+    // k_lzp_decode 1.03 s per launch instead of 0.55, the tail waited 3.7 of its 19.4 s for them)
+    if (lead->ctx->rest && tail_slots == 4 && lead->ctx->reserved_cus >= 16) tail_window = lead->ctx->reserved_cus / 4;
     if (const char * e = getenv("BZ3_HIP_TAIL_PIPE")) {  // "window,slots": tests / experiments
         int w = 0, q = 0;
         if (sscanf(e, "%d,%d", &w, &q) == 2 && w >= 1 && q >= 2 && q <= DeviceCtx::AUX) {
@@ -1702,6 +1709,10 @@ void collect(int kind, SingleReq & r) {
 }  // namespace
 
 BZIP3_API unsigned bz3_hip_cm_blocks_routed_full(void) { return g_cm_routed_full.load(); }
+BZIP3_API int bz3_hip_set_keep_workspace(int on) {
+    g_keep_ws.store(on < 0 ? -1 : (on ? 1 : 0));
+    return 0;
+}
 BZIP3_API void bz3_hip_set_collect_window_us(int us) { g_collect_window_us.store(us < 0 ? 200 : us); }
 BZIP3_API unsigned bz3_hip_debug_collected_batches(int reset, unsigned * largest) {  // batches run for single-block callers; *largest = blocks in the largest
     if (largest) *largest = g_collect_largest.load();

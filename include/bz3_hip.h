@@ -57,6 +57,11 @@ BZIP3_API int bz3_hip_debug_peak_concurrent_groups(int reset);
  * blocks per window | context slots << 16 | (workspace handed back when the call ended) << 30 (0 before the first call).  The serial LZP drivers of a window run on a side stream
  * while the whole-GPU stages of the other slots' windows run on the group's stream; the shape follows the free memory. */
 BZIP3_API int bz3_hip_debug_front_end_ring(void);
+/* Keep-workspace mode for lean states (same as BZ3_HIP_KEEP_WS=1 in the environment, but switchable: 1 on, 0 off, -1 back to the environment):
+ * a GPU-filling lean batch's workspace survives the call, the decode call that follows reuses it and carves the swap buffers of its tail windows
+ * from it -- instead of a hipFree and two multi-GB hipMallocs per round trip (30-45 ms per GiB).  The memory stays with the library until
+ * bz3_hip_release_cached_memory().  bench.py turns it on for its timed steps. */
+BZIP3_API int bz3_hip_set_keep_workspace(int on);
 /* Statistics of the keep-workspace experiment (environment BZ3_HIP_KEEP_WS=1: a lean batch's workspace survives the call and the decoder's tail carves
  * its swap buffers from it): swap buffers served from the arena instead of the pool since the last reset. */
 BZIP3_API int bz3_hip_debug_arena_swap_buffers(int reset);
