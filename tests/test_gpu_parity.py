@@ -607,6 +607,59 @@ def test_lean_states_on_gpu(gpu_lib, oracle, text):
         gpu_lib.bz3_hip_release_cached_memory()
 
 
+def test_large_lean_batch_default_rings_and_kept_workspace_on_gpu(gpu_lib, oracle, text):
+    """Round 5's defaults for GPU-filling batches, at a size a test can afford: 140 lean blocks (>= 128: the decoder's tail takes its four-slot ring -- windows
+    of reserved CUs / 4 blocks on the CU partition, LZP decoders on the reserved CUs, whole-GPU kernels on the others) through the batch API, twice, with the
+    workspace KEPT between the calls (bz3_hip_set_keep_workspace(1): the decode call reuses the encode call's arena and carves the swap buffers of its tail
+    windows from it).  Blocks of text with long repeats (LZP and mRLE on), a random block (more than a quarter of its bytes outside the 40 most frequent
+    values: straight to the whole-model CM kernel when the batch takes a row-cache variant), a tiny and an empty one; on the second trip one payload is
+    corrupted: that block fails its CRC, its neighbours do not."""
+    n = 140
+    bs = 128 * 1024
+    blocks = []
+    for i in range(n):
+        if i == 7:
+            blocks.append(datagen.random_bytes(90000, seed=3))
+        elif i == 19:
+            blocks.append(b"tiny")
+        elif i == 23:
+            blocks.append(b"")
+        else:
+            o = (i * 37123) % 4000000
+            blocks.append(text[o : o + 40000 + 13 * i] + text[o + 100 : o + 20100] + b"\xf2" * (i % 5) + b"q" * (300 + i))
+    want = [oracle.encode_block(d, bs)[2] for d in blocks]
+    try:
+        assert gpu_lib.bz3_hip_set_lean_states(1) == 0 and gpu_lib.bz3_hip_set_keep_workspace(1) == 0
+        states = (C.c_void_p * n)(*[gpu_lib.bz3_new(bs) for _ in range(n)])
+        assert all(states)
+        cap = gpu_lib.bz3_bound(bs) + 64
+        for trip in range(2):
+            bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+            for b, d in zip(bufs, blocks):
+                C.memmove(b, d, len(d))
+            ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+            sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+            gpu_lib.bz3_encode_blocks(states, ptrs, sizes, n)
+            for i in range(n):
+                assert bytes(bufs[i][: sizes[i]]) == want[i], (trip, i)
+            if trip == 1:
+                bufs[50][sizes[50] // 2] ^= 0x41
+            bsz = (C.c_size_t * n)(*[cap] * n)
+            orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+            gpu_lib.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+            for i, d in enumerate(blocks):
+                if trip == 1 and i == 50:
+                    assert gpu_lib.bz3_last_error(states[i]) != 0
+                else:
+                    assert gpu_lib.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: len(d)]) == d, (trip, i)
+        for s_ in states:
+            gpu_lib.bz3_free(s_)
+    finally:
+        gpu_lib.bz3_hip_set_keep_workspace(-1)
+        gpu_lib.bz3_hip_set_lean_states(0)
+        gpu_lib.bz3_hip_release_cached_memory()
+
+
 def test_zz_three_blocks_per_cu_variants_on_gpu(gpu_lib, oracle, text):
     """The 44/56-row kernels (mode 2: three blocks per CU), the 96-row pair (1) and the whole-model pair (0) through the stage hooks:
     same bytes as the oracle on text, a source that recycles slots, random bytes (given up, recoded by the full-model kernel) and a
