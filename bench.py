@@ -606,7 +606,7 @@ def main():
         block_size = int(a.leg_block_mib * (1 << 20))
         if a.blocks <= 0:
             nblk = cus  # 256 x 511 MiB + workspace is what fits beside the swap-buffer pool
-    lean = a.lean == 1 or (a.lean < 0 and nblk > cus)
+    lean = a.lean == 1 or (a.lean < 0 and (nblk > cus or a.leg == "cfg5"))  # (cfg5: 256 x 511 MiB blocks with a swap buffer each would not fit)
     assert lib.bz3_hip_set_lean_states(1 if lean else 0) == 0
     cap = lib.bz3_bound(block_size) + 4096
     noise = a.noise

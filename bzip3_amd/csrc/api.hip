@@ -68,7 +68,7 @@ struct DeviceCtx {
     // (hipExtStreamCreateWithCUMask); the CM launches keep the group's unmasked stream (they need every CU).  BZ3_HIP_CU_RESERVE=<CUs> (read once;
     // default 48, 0 = no partition).  Falls back to plain streams when the runtime refuses.
     hipStream_t rest = nullptr;   // whole-GPU kernels beside the side streams' serial kernels: every CU but the reserved ones (null: no partition)
-    hipStream_t aux_m[RING_SLOTS] = {};  // the decoder's side streams, on the reserved CUs (the encoder's rings keep the plain ones: call 4 measured its
+    hipStream_t aux_m[AUX] = {};  // the decoder's side streams, on the reserved CUs (the encoder's rings keep the plain ones: call 4 measured its
                                          // front end 6 % SLOWER with its LZP drivers confined to 32 CUs, profiles/r05_cu_partition_256x64MiB.txt)
     int reserved_cus = 0;
     static int cu_reserve_setting() {
@@ -101,7 +101,7 @@ struct DeviceCtx {
         if (aux_ready) return;
         // built into locals and committed only when everything exists: a failure half way must not leave a context whose first
         // stream is there and whose events are not (every later call would record on null events)
-        hipStream_t st[AUX] = {}, sm[RING_SLOTS] = {}, rs = nullptr;
+        hipStream_t st[AUX] = {}, sm[AUX] = {}, rs = nullptr;
         hipEvent_t e0[AUX] = {}, e1[AUX] = {}, ep = nullptr;
         int reserved = 0;
         try {
@@ -114,12 +114,12 @@ struct DeviceCtx {
                 std::vector<uint32_t> side, mainm;
                 cu_masks(real_cus, want, side, mainm);
                 bool ok = hipExtStreamCreateWithCUMask(&rs, (uint32_t)mainm.size(), mainm.data()) == hipSuccess;
-                for (int k = 0; ok && k < RING_SLOTS; k++) ok = hipExtStreamCreateWithCUMask(&sm[k], (uint32_t)side.size(), side.data()) == hipSuccess;
+                for (int k = 0; ok && k < AUX; k++) ok = hipExtStreamCreateWithCUMask(&sm[k], (uint32_t)side.size(), side.data()) == hipSuccess;
                 if (!ok) {  // the runtime refuses: plain streams only
                     (void)hipGetLastError();
                     if (rs) (void)hipStreamDestroy(rs);
                     rs = nullptr;
-                    for (int k = 0; k < RING_SLOTS; k++) {
+                    for (int k = 0; k < AUX; k++) {
                         if (sm[k]) (void)hipStreamDestroy(sm[k]);
                         sm[k] = nullptr;
                     }
@@ -136,7 +136,7 @@ struct DeviceCtx {
         } catch (...) {
             if (ep) (void)hipEventDestroy(ep);
             if (rs) (void)hipStreamDestroy(rs);
-            for (int k = 0; k < RING_SLOTS; k++)
+            for (int k = 0; k < AUX; k++)
                 if (sm[k]) (void)hipStreamDestroy(sm[k]);
             for (int k = 0; k < AUX; k++) {
                 if (st[k]) (void)hipStreamDestroy(st[k]);
@@ -147,7 +147,7 @@ struct DeviceCtx {
         }
         ev_prep = ep;
         rest = rs;
-        for (int k = 0; k < RING_SLOTS; k++) aux_m[k] = sm[k];
+        for (int k = 0; k < AUX; k++) aux_m[k] = sm[k];
         reserved_cus = reserved;
         for (int k = 0; k < AUX; k++) {
             aux[k] = st[k];
@@ -1150,10 +1150,17 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     s32 tail_slots = n >= 128 ? 4 : 2;
     s32 tail_window = tail_slots == 4 ? 16 : 32;
     lead->ctx->ensure_aux();
-    // With the CU partition a window's LZP decoders want a reserved CU EACH (two on a CU halve each other's table-insert rate): windows of
-    // reserved / 4, so that even the moment a fourth window starts before the oldest has ended finds room (48 CUs: 12; call 6 ran 16 x 4 on 48 CUs:
-    // k_lzp_decode 1.03 s per launch instead of 0.55, the tail waited 3.7 of its 19.4 s for them)
-    if (lead->ctx->rest && tail_slots == 4 && lead->ctx->reserved_cus >= 16) tail_window = lead->ctx->reserved_cus / 4;
+    // With the CU partition the whole-GPU kernels run at their stand-alone pace and the LZP decoders become what the ring has to hide: ~1.0 s per launch
+    // at 256 MiB beside the streaming kernels (0.55 s alone: their 1 MiB tables do not stay in L2), whatever the window -- calls 6 / 7: 16 x 4 waited
+    // 3.7 s of the tail for them, 12 x 4 7.1 s.  (slots - 1) x window blocks of whole-GPU work (~21 ms each) must outlast that: eight slots of 8, the same 64
+    // blocks in flight, hide 1.18 s.  (Round 4 and call 1 had measured 8 x 8 as a loss -- while the stragglers, not the decoders, set the pace.)
+    if (lead->ctx->rest && tail_slots == 4) {
+        static const bool wide_ring = [] { const char * e = getenv("BZ3_HIP_TAIL_WIDE"); return !e || atoi(e) != 0; }();  // (experiments, read once: 0 = 16 x 4 as before)
+        if (wide_ring) {
+            tail_slots = 8;
+            tail_window = 8;
+        }
+    }
     if (const char * e = getenv("BZ3_HIP_TAIL_PIPE")) {  // "window,slots": tests / experiments
         int w = 0, q = 0;
         if (sscanf(e, "%d,%d", &w, &q) == 2 && w >= 1 && q >= 2 && q <= DeviceCtx::AUX) {
@@ -1244,13 +1251,13 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     // The tail's whole-GPU kernels keep off the CUs the side streams' LZP decoders sit on (DeviceCtx::rest), when the device is partitioned
     hipStream_t s_cm = s;
     hipStream_t * side_streams = lead->ctx->aux;
-    if (lead->ctx->rest && (size_t)n > 1 && tail_slots <= DeviceCtx::RING_SLOTS) {
+    if (lead->ctx->rest && (size_t)n > 1) {
         side_streams = lead->ctx->aux_m;
         HIP_CHECK(hipStreamSynchronize(s));  // headers, stored blocks' CRCs and the CM launches ran on the group's stream
         s = lead->ctx->rest;
         for (s32 i = 0; i < n; i++) sts[i]->xs = s;
     }
-    DrainOnUnwind drain_rest{s == s_cm ? nullptr : s, side_streams == lead->ctx->aux ? nullptr : side_streams, side_streams == lead->ctx->aux ? 0 : DeviceCtx::RING_SLOTS};
+    DrainOnUnwind drain_rest{s == s_cm ? nullptr : s, side_streams == lead->ctx->aux ? nullptr : side_streams, side_streams == lead->ctx->aux ? 0 : DeviceCtx::AUX};
     const s32 nwin = (n + tail_window - 1) / tail_window;
     const s32 lag = tail_slots - 1;  // window k is finished in iteration k + lag
     // BZ3_HIP_TRACE_RINGS=1 (diagnosis, read once): where this thread's wall time goes in the ring -- a line on stderr when the call ends
@@ -2142,6 +2149,21 @@ BZIP3_API int32_t bz3_hip_stage_unbwt(const uint8_t * in, uint8_t * out, int32_t
         HIP_CHECK(hipStreamSynchronize(e.s));
         g_stage_ms.store(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count());
         e.down(out, o, (size_t)n);
+        return 0;
+    });
+}
+
+// Tests only: sort.hip's device-wide exclusive scan on a host buffer (in place); returns the grand total through *total.
+BZIP3_API int32_t bz3_hip_debug_scan_u32(uint32_t * data, uint32_t n, uint32_t * total) {
+    return stage_guard([&]() -> s32 {
+        if (n == 0) return -1;
+        StageEnv e;
+        u32 * d = (u32 *)e.dev((size_t)n * 4 + 64, data, (size_t)n * 4);
+        u32 * t = (u32 *)e.dev(64);
+        Arena a = e.ctx->arena_for(scan_temp_words(n) * 4 + (1u << 20));
+        exclusive_scan_u32(d, n, t, a, e.s);
+        e.down(data, d, (size_t)n * 4);
+        if (total) *total = e.word(t);
         return 0;
     });
 }

@@ -92,6 +92,52 @@ __global__ void k_add_last(const u32 * __restrict__ sums_excl, const u32 * __res
     *out = *sums_excl + *last_tile_total;
 }
 
+// Mid-sized tables in ONE launch (round 5): a workgroup of 1024, every thread a contiguous chunk of the table (16-byte accesses; a thread's lines are
+// reused from L1 / L2 across its iterations), one workgroup scan over the chunk sums.  Up to 256 Ki words -- the count table of a radix pass of up to
+// 1024 tiles (4 Mi keys) -- this replaces reduce + apply(1 tile) + apply: three launches of ~10 us with their gaps, of which the sorter's ~40 mid-sized
+// passes per block paid ~1.5 ms (profiles/r05_call6_kernels_*: 123 k_scan_apply + 68 k_scan_reduce launches per 256 MiB block).
+constexpr int SC1_BLOCK = 1024;
+constexpr u64 SC1_MAX = 262144;
+__global__ void __launch_bounds__(SC1_BLOCK) k_scan_single(u32 * __restrict__ data, u64 n, u32 * __restrict__ total_out) {
+    __shared__ u32 lds[SC1_BLOCK / WAVE + 1];
+    const u64 quads = (n + 3) / 4;                                  // the table in groups of four words
+    const u64 per = (quads + SC1_BLOCK - 1) / SC1_BLOCK;            // groups per thread
+    const u64 q0 = (u64)threadIdx.x * per, q1 = q0 + per < quads ? q0 + per : quads;
+    const bool vec = (reinterpret_cast<uintptr_t>(data) & 15u) == 0;
+    auto load4 = [&](u64 q, u32 (&v)[4]) {
+        if (vec && 4 * q + 4 <= n) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(data + 4 * q);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = 4 * q + k < n ? data[4 * q + k] : 0u;
+        }
+    };
+    u32 acc = 0;
+    for (u64 q = q0; q < q1; q++) {
+        u32 v[4];
+        load4(q, v);
+        acc += v[0] + v[1] + v[2] + v[3];
+    }
+    u32 tot;
+    u32 run = block_excl_add<SC1_BLOCK>(acc, lds, tot);
+    for (u64 q = q0; q < q1; q++) {
+        u32 v[4];
+        load4(q, v);
+        u32 o[4];
+        o[0] = run; o[1] = o[0] + v[0]; o[2] = o[1] + v[1]; o[3] = o[2] + v[2];
+        run = o[3] + v[3];
+        if (vec && 4 * q + 4 <= n) {
+            *reinterpret_cast<uint4 *>(data + 4 * q) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (4 * q + k < n) data[4 * q + k] = o[k];
+        }
+    }
+    if (total_out && threadIdx.x == 0) *total_out = tot;
+}
+
 static void scan_rec(u32 * d, u64 n, u32 * d_total, Arena & tmp, hipStream_t s) {
     if (n == 0) {
         if (d_total) HIP_CHECK(hipMemsetAsync(d_total, 0, 4, s));
@@ -99,6 +145,11 @@ static void scan_rec(u32 * d, u64 n, u32 * d_total, Arena & tmp, hipStream_t s) 
     }
     if (n <= SC_TILE) {
         launch(k_scan_apply, dim3(1), dim3(SC_BLOCK), 0, s, d, n, (const u32 *)nullptr, d_total);
+        return;
+    }
+    static const bool no_single = getenv("BZ3_SCAN_NO_SINGLE") != nullptr;  // (experiments: the recursive scan for every size, as up to round 4; read once)
+    if (n <= SC1_MAX && !no_single) {
+        launch(k_scan_single, dim3(1), dim3(SC1_BLOCK), 0, s, d, n, d_total);
         return;
     }
     const u64 tiles = (n + SC_TILE - 1) / SC_TILE;

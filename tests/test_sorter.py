@@ -62,8 +62,33 @@ def test_sorter_across_the_raw_table_bound_on_the_emulator(emu):
         _check(emu, n, 8, 8, seed=n + 1, skew=True)
 
 
+SCAN_SIZES = [1, 2047, 2048, 2049, 5003, 65537, 262143, 262144, 262145, 300000]  # one tile | one launch (up to 262144 words) | the recursive scan
+
+
+def _check_scan(lib, n, seed):
+    rng = np.random.default_rng(seed)
+    d = rng.integers(0, 4000, n, dtype=np.uint64).astype(np.uint32)
+    want = np.concatenate([[0], np.cumsum(d.astype(np.uint64))[:-1]]).astype(np.uint32)
+    tot = C.c_uint32(0)
+    buf = d.copy()
+    assert lib.bz3_hip_debug_scan_u32(buf.ctypes.data_as(C.c_void_p), n, C.byref(tot)) == 0
+    assert np.array_equal(buf, want), n
+    assert tot.value == int(d.astype(np.uint64).sum()) & 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("n", SCAN_SIZES)
+def test_scan_on_the_emulator(emu, n):
+    _check_scan(emu, n, seed=n)
+
+
+@pytest.mark.gpu
+def test_scan_on_the_gpu(gpu_lib):
+    for n in SCAN_SIZES + [1 << 24, (1 << 24) + 7]:
+        _check_scan(gpu_lib, n, seed=n)
+
+
 @pytest.mark.gpu
 def test_sorter_on_the_gpu(gpu_lib):
-    for n, kb, db in CASES + [(RAW_KEYS - 5, 18, 9), (RAW_KEYS, 18, 8), (RAW_KEYS + 4096 + 17, 18, 9), (5_000_003, 18, 9), (5_000_003, 32, 8), (40_000_000, 18, 9)]:
+    for n, kb, db in CASES + [(RAW_KEYS - 5, 18, 9), (RAW_KEYS, 18, 8), (RAW_KEYS + 4096 + 17, 18, 9), (1024 * 4096, 8, 8), (1024 * 4096 + 4096, 8, 8), (5_000_003, 18, 9), (5_000_003, 32, 8), (40_000_000, 18, 9)]:
         _check(gpu_lib, n, kb, db, seed=n + db)
     _check(gpu_lib, 3_000_000, 18, 9, seed=7, skew=True)
