@@ -500,6 +500,13 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
         const u32 abort_limit = gap == CM_NO_GAP ? 0xFFFFFFFFu : (gap > 4096u ? (u32)(((u64)(gap - 2048u) * 32u) / 33u) : 0u);
         u32 hrow1 = 0, hrow2 = 0;  // slots of bytes -1 and -2 (byte value 0 before the block starts: slot 0)
         if (R) cm_rows_init<R>(rc);
+        // The chunk's bytes are loaded ONE CHUNK AHEAD (round 5).  The wave used to load them where it needs them: an HBM round trip (1-2 us) in
+        // front of every 32 bytes, on a wave whose own work per chunk is ~55 % of what the coder takes for it -- so the launch time moved with the
+        // memory latency of the day (65.0 s on five boxes, 71.3 and 74.6 s on two: calls 7 / 8 of round 5, the decoder's launch identical on all).
+        // (In-place coding: the sink only assumes that the bytes below the current chunk's end are in registers; loading further ahead is safe.)
+        // (Unconditional loads at clamped addresses, masked where they are USED: behind a branch the compiler completes the load -- s_waitcnt -- inside it.)
+        const u8 * __restrict__ in_pf = n ? in : reinterpret_cast<const u8 *>(jobs);  // (an empty block: the clamped address must still be memory of ours)
+        u32 raw_next = in_pf[(u32)lane < n ? (u32)lane : (n ? n - 1u : 0u)];
         for (u32 base = 0; base < n; base += CM_CHUNK) {
             const u32 cnt = (n - base < CM_CHUNK) ? n - base : CM_CHUNK;
             while (debug != 2 && base + cnt - cons_seen > CM_RING) {  // ring full: wait for the coder
@@ -507,7 +514,11 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
                 if (base + cnt - cons_seen > CM_RING) BZ3_SPIN_PAUSE();
             }
             // lane r holds byte r of the chunk together with its 4 predecessors
-            const u32 mine = ((u32)lane < cnt) ? in[base + lane] : 0u;
+            const u32 mine = ((u32)lane < cnt) ? raw_next : 0u;
+            {
+                const u64 nx = (u64)base + CM_CHUNK + (u32)lane;  // (u64: base + 32 + lane passes 2^32 only beyond the format's block limit, but be exact)
+                raw_next = in_pf[nx < (u64)n ? nx : (u64)n - 1u];
+            }
             u32 rowv = 0;
             if (R) {
                 rowv = cm_rows_chunk<R, 4>(m, rc, rs, spill, mine, cnt, hrow1, hrow2, (u32)lane);  // (the wave moves whole rows: four cells per lane)
@@ -717,11 +728,17 @@ __device__ __forceinline__ u64 cm_clock() {
 
 
 // The coded bytes are read 64 at a time (one byte per lane) and handed out by v_readlane.  Bytes past the end read as -1 (:345).
+// The NEXT 64 bytes are already on their way when a window runs out (round 5: the load used to be issued where its bytes were needed, an HBM round
+// trip on the walker's path every 64 coded bytes).
 #define CM_NEXT_BYTE(dst)                                                              \
     do {                                                                               \
         if (ip - ibase >= 64u) {                                                       \
             ibase += 64u;                                                              \
-            window = (ibase + lane < in_size) ? in[ibase + lane] : 0xFFFFFFFFu;        \
+            window = (ibase + lane < in_size) ? window_raw : 0xFFFFFFFFu;              \
+            {                                                                          \
+                const u64 nx_ = (u64)ibase + 64u + (u32)lane;                          \
+                window_raw = in_pf[nx_ < (u64)in_size ? nx_ : (in_size ? (u64)in_size - 1u : 0u)]; \
+            }                                                                          \
         }                                                                              \
         dst = cm_readlane(window, (int)(ip - ibase));                                  \
         ip++;                                                                          \
@@ -1028,6 +1045,9 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
     u32 low_u = 0, range_u = 0xFFFFFFFFu, code = 0, c1 = 0;
     u32 ip = 0, ibase = 0;
     u32 window = (ibase + lane < in_size) ? in[ibase + lane] : 0xFFFFFFFFu;
+    // (loaded unconditionally at a clamped address and masked when it becomes the window: see the encoder's model wave)
+    const u8 * __restrict__ in_pf = in_size ? in : reinterpret_cast<const u8 *>(jobs);  // (no coded bytes at all: the clamped address must still be memory of ours)
+    u32 window_raw = in_pf[64u + (u32)lane < in_size ? 64u + (u32)lane : (in_size ? in_size - 1u : 0u)];
     for (int j = 0; j < 4; j++) {  // :438-441; bytes past the end read as -1 (:345)
         u32 b;
         CM_NEXT_BYTE(b);

@@ -222,13 +222,15 @@ def test_batch_api_host_buffers(gpu_lib, oracle, text):
         gpu_lib.bz3_free(s)
 
 
-@pytest.mark.parametrize("pipe", [None, "1,4", "5,3", "6,2"], ids=["auto", "w1s4", "w5s3", "w6s2"])
+@pytest.mark.parametrize("pipe", [None, "1,4", "5,3", "6,2", "3,8"], ids=["auto", "w1s4", "w5s3", "w6s2", "w3s8"])
 def test_front_end_and_tail_rings_on_gpu(gpu_lib, oracle, text, pipe, monkeypatch):
     """The encoder's front end and the decoder's tail run their serial LZP kernels on side streams over a ring of context slots
     (api.hip encode_group / decode_group).  Under the CPU emulator kernels run at launch, so only here do the side streams really
     overlap the group's stream: 40 blocks (LZP applied, declined, stored) through forced ring shapes -- windows of one block
-    through four slots, a ragged last window through three, round 2's two slots of six -- and the automatic one, classic and lean
-    states: the oracle's bytes both ways."""
+    through four slots, a ragged last window through three, round 2's two slots of six, eight slots (all eight side streams; the shape a
+    GPU-filling batch's tail takes by default since round 5, there with windows of 8) -- and the automatic one, classic and lean states: the
+    oracle's bytes both ways.  With more than one block the tail runs on the CU partition (side streams on reserved CUs, whole-GPU kernels on
+    the rest) wherever the runtime grants the masked streams."""
     for var in ("BZ3_HIP_LZP_PIPE", "BZ3_HIP_TAIL_PIPE"):
         if pipe:
             monkeypatch.setenv(var, pipe)
