@@ -114,7 +114,9 @@ struct DeviceCtx {
                 std::vector<uint32_t> side, mainm;
                 cu_masks(real_cus, want, side, mainm);
                 bool ok = hipExtStreamCreateWithCUMask(&rs, (uint32_t)mainm.size(), mainm.data()) == hipSuccess;
-                for (int k = 0; ok && k < AUX; k++) ok = hipExtStreamCreateWithCUMask(&sm[k], (uint32_t)side.size(), side.data()) == hipSuccess;
+                // (RING_SLOTS of them: every masked stream is a hardware queue of its own, and call 8 -- eight of them, a tail ring of 8 x 8 -- ran every
+                // phase of the tail slower than call 6's four; a ring with more slots than that runs unpartitioned on the plain streams)
+                for (int k = 0; ok && k < RING_SLOTS; k++) ok = hipExtStreamCreateWithCUMask(&sm[k], (uint32_t)side.size(), side.data()) == hipSuccess;
                 if (!ok) {  // the runtime refuses: plain streams only
                     (void)hipGetLastError();
                     if (rs) (void)hipStreamDestroy(rs);
@@ -1151,16 +1153,9 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     s32 tail_window = tail_slots == 4 ? 16 : 32;
     lead->ctx->ensure_aux();
     // With the CU partition the whole-GPU kernels run at their stand-alone pace and the LZP decoders become what the ring has to hide: ~1.0 s per launch
-    // at 256 MiB beside the streaming kernels (0.55 s alone: their 1 MiB tables do not stay in L2), whatever the window -- calls 6 / 7: 16 x 4 waited
-    // 3.7 s of the tail for them, 12 x 4 7.1 s.  (slots - 1) x window blocks of whole-GPU work (~21 ms each) must outlast that: eight slots of 8, the same 64
-    // blocks in flight, hide 1.18 s.  (Round 4 and call 1 had measured 8 x 8 as a loss -- while the stragglers, not the decoders, set the pace.)
-    if (lead->ctx->rest && tail_slots == 4) {
-        static const bool wide_ring = [] { const char * e = getenv("BZ3_HIP_TAIL_WIDE"); return !e || atoi(e) != 0; }();  // (experiments, read once: 0 = 16 x 4 as before)
-        if (wide_ring) {
-            tail_slots = 8;
-            tail_window = 8;
-        }
-    }
+    // at 256 MiB beside the streaming kernels (0.55 s alone: their 1 MiB tables do not stay in L2), whatever the window.  Measured at full size on 48
+    // reserved CUs (profiles/r05_call{6,7,8}_*): 16 x 4 waits 3.7 s of a 21.9 s tail for them, 12 x 4 7.1 s of 22.8, 8 x 8 (eight masked streams) 7.0 s of
+    // 29.5 with every other phase slower too.  Four slots of 16 stay.
     if (const char * e = getenv("BZ3_HIP_TAIL_PIPE")) {  // "window,slots": tests / experiments
         int w = 0, q = 0;
         if (sscanf(e, "%d,%d", &w, &q) == 2 && w >= 1 && q >= 2 && q <= DeviceCtx::AUX) {
@@ -1251,7 +1246,7 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     // The tail's whole-GPU kernels keep off the CUs the side streams' LZP decoders sit on (DeviceCtx::rest), when the device is partitioned
     hipStream_t s_cm = s;
     hipStream_t * side_streams = lead->ctx->aux;
-    if (lead->ctx->rest && (size_t)n > 1) {
+    if (lead->ctx->rest && (size_t)n > 1 && tail_slots <= DeviceCtx::RING_SLOTS) {
         side_streams = lead->ctx->aux_m;
         HIP_CHECK(hipStreamSynchronize(s));  // headers, stored blocks' CRCs and the CM launches ran on the group's stream
         s = lead->ctx->rest;
