@@ -905,6 +905,14 @@ def main():
         RESULT["line"] = out
         if a.leg == "cfg5":
             out["config"]["legs"]["cfg5_round_trip_MiBps"] = out["value"]
+        elif not a.emu:
+            # the cfg5 leg is a run of its own (a 511 MiB block's CM launches last ~2.5 + ~5.3 minutes): its last RECORDED value rides along, marked as such
+            try:
+                with open(os.path.join(ROOT, "profiles", "r05_bench_cfg5_256x511MiB.json")) as fh:
+                    out["config"]["legs"]["cfg5_round_trip_MiBps_recorded"] = json.load(fh)["value"]
+                    out["config"]["legs"]["cfg5_note"] = "recorded by `bench.py --leg cfg5 --blocks 256` (profiles/r05_bench_cfg5_256x511MiB.json), not measured in this run"
+            except Exception:
+                pass
 
     # ---- extra legs (rank 0 at N=1; the watchdog prints the line without them if they overrun) ----------------------------
     def left_s():

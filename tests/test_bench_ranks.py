@@ -34,7 +34,7 @@ def _check(d, world):
     # what the driver's record keeps of the legs and of the sharding model lives under `config`
     sm = d["config"]["sharding_model"]
     assert sm["cfg4_linux_tarball_5_blocks_8_gpus"] == 0.625 and sm["cfg5_8GiB_17_blocks_8_gpus"] == round(17 / 24, 4)
-    assert d["config"]["legs"] == {} and str(world) in sm["this_run"]
+    assert set(d["config"]["legs"]) <= {"cfg5_round_trip_MiBps_recorded", "cfg5_note"} and str(world) in sm["this_run"]
 
 
 def test_bench_spawns_its_own_ranks_and_rank_0_reports_the_aggregate():

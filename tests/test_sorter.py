@@ -68,7 +68,9 @@ SCAN_SIZES = [1, 2047, 2048, 2049, 5003, 65537, 262143, 262144, 262145, 300000] 
 def _check_scan(lib, n, seed):
     rng = np.random.default_rng(seed)
     d = rng.integers(0, 4000, n, dtype=np.uint64).astype(np.uint32)
-    want = np.concatenate([[0], np.cumsum(d.astype(np.uint64))[:-1]]).astype(np.uint32)
+    want = np.zeros(n, dtype=np.uint64)  # (uint64 throughout: [0] + uint64 would promote to float64)
+    want[1:] = np.cumsum(d.astype(np.uint64))[:-1]
+    want = (want & np.uint64(0xFFFFFFFF)).astype(np.uint32)  # the device sums wrap modulo 2^32
     tot = C.c_uint32(0)
     buf = d.copy()
     assert lib.bz3_hip_debug_scan_u32(buf.ctypes.data_as(C.c_void_p), n, C.byref(tot)) == 0
