@@ -348,7 +348,7 @@ int cm_variant_for(const DeviceCtx * ctx, size_t njobs, bool encode) {
     return CM_VARIANT_FULL;
 }
 
-size_t cm_scratch_bytes(size_t njobs) { return njobs * (CM_SPILL_BYTES + 256) + 4096; }
+size_t cm_scratch_bytes(size_t njobs) { return njobs * (CM_SPILL_BYTES + 256) + 4096 + CM_CLAIM_WORDS * 4 + 256; }
 
 // Runs the CM kernel over `jobs` (host copies; d_jobs has room for all of them) and returns the kernel time in ms.
 // Row-cache variants: blocks the kernel gave up are coded again by the full-model kernel in a second launch.
@@ -381,6 +381,15 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
     }
     const int variant = cm_variant_for(ctx, jobs.size(), std::is_same<Job, CmEncodeJob>::value);
     const size_t mk = arena.mark();
+    if constexpr (std::is_same<Job, CmEncodeJob>::value) {  // a word per CU for the coder waves' SIMD claims (cm.hip)
+        static const bool no_claim = getenv("BZ3_CM_NO_CLAIM") != nullptr;  // (experiments, read once: the block index decides, as up to round 4)
+        if (!no_claim) {
+            u32 * claim = arena.take<u32>(CM_CLAIM_WORDS);
+            HIP_CHECK(hipMemsetAsync(claim, 0, CM_CLAIM_WORDS * sizeof(u32), s));
+            for (auto & j : jobs) j.claim = dev_addr(claim);
+            for (auto & j : direct) j.claim = dev_addr(claim);
+        }
+    }
     u32 * d_status = nullptr;
     if (cm_variant_has_rows(variant)) {
         u8 * spill = arena.take<u8>(jobs.size() * CM_SPILL_BYTES);
@@ -2330,9 +2339,12 @@ BZIP3_API float bz3_hip_stage_cm_encode_many(const uint8_t * in, int32_t n, uint
         u8 * spill = cm_variant_has_rows(variant) ? e.dev(CM_SPILL_BYTES * (size_t)copies) : nullptr;
         u32 * status = (u32 *)e.dev(4 * (size_t)copies + 64);
         HIP_CHECK(hipMemsetAsync(status, 0, 4 * (size_t)copies, e.s));
+        u32 * claim = getenv("BZ3_CM_NO_CLAIM") ? nullptr : (u32 *)e.dev(CM_CLAIM_WORDS * 4);  // (BZ3_CM_NO_CLAIM: the block index decides which wave codes, as up to round 4)
+        if (claim) HIP_CHECK(hipMemsetAsync(claim, 0, CM_CLAIM_WORDS * 4, e.s));
         std::vector<CmEncodeJob> jobs;
         for (int32_t k = 0; k < copies; k++) {
             CmEncodeJob j{dev_addr(d), dev_addr(o + stride * (size_t)k), dev_addr(w + 4 * (size_t)k), (u32)n, debug};
+            j.claim = claim ? dev_addr(claim) : 0;
             if (spill) {
                 j.spill = dev_addr(spill + CM_SPILL_BYTES * (size_t)k);
                 j.status = dev_addr(status + k);

@@ -372,6 +372,23 @@ __device__ __forceinline__ void cm_code_bits_raw(const CmByteEvents & ev, u32 & 
         rmin = r < rmin ? r : rmin;
     }
 }
+// The same, remembering the range after every bit (rr) and the bit's contribution to low (md): what the slow path's search for the FIRST due
+// renormalisation reads (round 5).  On the fast path they are the values the recurrence computes anyway; nothing is added there.
+template <int K0, int CNT>
+__device__ __forceinline__ void cm_code_bits_raw_keep(const CmByteEvents & ev, u32 & r, u32 & l, u32 & rmin, u32 (&rr)[8], u32 (&md)[8]) {
+#pragma unroll
+    for (int kk = K0; kk < K0 + CNT; kk++) {
+        const uint2 ek = ev.k[kk];
+        const u64 prod = (u64)r * ev.m[kk] + (((u64)ek.y << 32) | ek.x);
+        const u32 r2 = (u32)(prod >> 18);
+        const u32 d = (r - r2) & ek.x;
+        l += d;
+        md[kk] = d;
+        rr[kk] = r2;
+        r = r2;
+        rmin = r < rmin ? r : rmin;
+    }
+}
 // Where the coded bytes go.  Normally `out`, a buffer of its own.  In-place coding (gap != CM_NO_GAP): `out` lies
 // `gap` bytes BELOW the input inside the same buffer, so a byte may only be stored below the input bytes that every
 // model wave has already loaded: while byte i is being coded these are the chunks up to and including the one that
@@ -415,6 +432,37 @@ __device__ __forceinline__ void cm_code_bits_checked(const CmByteEvents & ev, u3
             }
         }
     }
+}
+
+// Slow path of a byte whose 8 untested bits ended inside one 2^24 bucket (or whose range reached zero on the way): a renormalisation was due after
+// one of them.  Up to the FIRST such bit the untested values are the reference's own (nothing had been renormalised yet, :390), so the state after bit
+// K is (low + md[0..K], rr[K]): find the first K whose interval lies in a bucket, renormalise there (:390-394) and code only the bits behind it with
+// the test after every bit.  (Rounds 1-4 coded the byte again in halves: raw 4 bits, test, then bit by bit -- ~78 instructions per firing against
+// ~66 here; a quarter of the bytes fire.)
+template <int K>
+__device__ __forceinline__ void cm_code_from_first_due(const CmByteEvents & ev, const u32 (&rr)[8], const u32 (&md)[8], u32 lk, u32 & range, u32 & low, CmSink & sink, u32 i) {
+    {
+        // (opaque to the optimiser: left to itself it recognises these partial sums as the fast path's own low + md[0] + .. and keeps THOSE alive
+        // instead -- eight single adds on every byte where the fast path had four v_add3)
+        u32 m = md[K];
+#ifndef BZ3_EMU
+        asm volatile("" : "+v"(m));
+#endif
+        lk += m;
+    }
+    const u32 rk = rr[K];
+    if (__ballot((lk ^ (lk + rk)) < (1u << 24)) != 0ull || K == 7) {  // (K == 7: the caller's test has fired, so some bit is due; the last one if no earlier)
+        low = lk;
+        range = rk;
+        while (__ballot((low ^ (low + range)) < (1u << 24)) != 0ull) {  // :390-394
+            sink.put(low >> 24, i);
+            low <<= 8;
+            range = (range << 8) | 0xFFu;
+        }
+        cm_code_bits_checked<(K < 7 ? K + 1 : 7), 7 - K>(ev, range, low, sink, i);
+        return;
+    }
+    if constexpr (K < 7) cm_code_from_first_due<K + 1>(ev, rr, md, lk, range, low, sink, i);
 }
 
 // Brings the rows of a chunk's bytes into the cache (R > 0).  mine = this lane's byte (lanes < cnt), hrow1 / hrow2 =
@@ -470,14 +518,42 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
             ring.k[t] = make_uint2(0u, 0u);
             ring.m[t] = 1u << 17;
         }
-    cm_model_init(m);
     const int lane = lane_id();
     // Which of the two waves codes.  The hardware deals the waves of the workgroups of a CU round the four SIMDs in turn, so with two
-    // waves per workgroup the first and the third workgroup of a CU land on the same pair of SIMDs; a launch of three blocks per CU puts
-    // blocks k, k + 256 and k + 512 on one CU (tools/cm_wave_placement.py shows both for the decoder).  The third one swaps its roles,
-    // so that no two coder waves -- the critical path of their blocks -- share a SIMD.  (The emulator swaps every other block instead:
-    // its batches are small.)
-    const u32 role = cm_uniform((u32)wave_id()) ^ ((blockIdx.x >> CM_ENC_SWAP_SHIFT) & 1u);
+    // waves per workgroup the first and the third workgroup of a CU land on the same pair of SIMDs, and two coder waves -- the critical
+    // path of their blocks -- on one SIMD cost both a quarter of their pace.  Rounds 3-4 let the block index decide (blocks k, k + 256,
+    // k + 512 share a CU when the dispatch is undisturbed: the third swaps its roles).  It mostly is at 256 MiB blocks (65.0 s per launch,
+    // but 71.3 and 74.6 s in two of round 5's runs) and mostly is NOT for smaller ones: the encode launch of 768 x 32 MiB blocks took 10.76 s
+    // in seven of eight launches and 8.25 s in the eighth (profiles/r05_cm_encoder_placement.txt).  Round 5: the workgroups of a CU CLAIM
+    // the SIMD of their coder in a word per CU (HW_ID / XCC_ID name the CU and the SIMD a wave runs on): wave 0's SIMD if it is free, else
+    // wave 1's.  (No claim word -- the emulator, old callers --: the block index decides as before; the emulator swaps every other block.)
+    __shared__ u32 s_simd[2], s_coder;
+    u32 claim_key = 0;
+#ifndef BZ3_EMU
+    {
+        const u32 hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        claim_key = ((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+        if (lane == 0) s_simd[wave_id() & 1] = (hw >> 4) & 3u;
+    }
+#endif
+    cm_model_init(m);  // (ends with a barrier: both SIMD numbers are there)
+    if (threadIdx.x == 0) {
+        u32 coder = (blockIdx.x >> CM_ENC_SWAP_SHIFT) & 1u;
+#ifndef BZ3_EMU
+        if (jobs[blockIdx.x].claim) {
+            u32 * __restrict__ claim = global_ptr<u32>(jobs[blockIdx.x].claim) + claim_key;
+            const u32 b0 = 1u << s_simd[0], b1 = 1u << s_simd[1];
+            if (!(atomicOr(claim, b0) & b0)) coder = 0;
+            else {
+                (void)atomicOr(claim, b1);
+                coder = 1;
+            }
+        }
+#endif
+        s_coder = coder;
+    }
+    __syncthreads();
+    const u32 role = cm_uniform((u32)wave_id()) ^ cm_uniform(s_coder);
     if (role != 0) {
         if (debug == 1) return;
         // ---- model wave ------------------------------------------------------------------------------
@@ -606,13 +682,13 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     auto bucket_or_zero = [](u32 l, u32 r, u32 rmin) __attribute__((always_inline)) -> bool { return (l ^ (l + r)) < (1u << 24) || rmin == 0u; };
     auto code_byte = [&](const CmByteEvents & ev, CmByteEvents & next, const u32 i) __attribute__((always_inline)) {
         u32 r = range, l = low, rmin = 0xFFFFFFFFu;
-        cm_code_bits_raw<0, 4>(ev, r, l, rmin);
+        u32 rr[8], md[8];  // range after every bit, every bit's contribution to low: read by the slow path only
+        cm_code_bits_raw_keep<0, 4>(ev, r, l, rmin, rr, md);
         cm_sched_fence();
         koff = (koff + 64u) & (CM_RING * 64u - 1u);
         fetch(next);           // unconditional (a branch here would let the compiler move the fetch to the top of the byte): if byte i+1 is not
         cm_sched_fence();      // there yet the slot still holds an older byte and the caller fetches again after waiting
-        const u32 r4 = r, l4 = l, rmin4 = rmin;
-        cm_code_bits_raw<4, 4>(ev, r, l, rmin);
+        cm_code_bits_raw_keep<4, 4>(ev, r, l, rmin, rr, md);
         const bool bad = bucket_or_zero(l, r, rmin);
         const u32 range_old = range, low_old = low;
         range = r;  // committed before the test: an `if` with one arm (cf. the decoder's walker)
@@ -620,20 +696,7 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
         if (__builtin_expect(__ballot(bad) != 0ull, 0)) {
             range = range_old;
             low = low_old;
-            if (__ballot(bucket_or_zero(l4, r4, rmin4)) == 0ull) {  // (the half's own bucket test is implied by the final one; its range-reached-zero guard is not)
-                range = r4;
-                low = l4;
-            } else {
-                cm_code_bits_checked<0, 4>(ev, range, low, sink, i);
-            }
-            r = range, l = low, rmin = 0xFFFFFFFFu;
-            cm_code_bits_raw<4, 4>(ev, r, l, rmin);
-            if (__ballot(bucket_or_zero(l, r, rmin)) == 0ull) {
-                range = r;
-                low = l;
-            } else {
-                cm_code_bits_checked<4, 4>(ev, range, low, sink, i);
-            }
+            cm_code_from_first_due<0>(ev, rr, md, low_old, range, low, sink, i);
         }
     };
     // Waits until the model waves have published byte i (false: they gave the block up).
@@ -646,11 +709,20 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
         lds_acquire();
         return true;
     };
+    // the SIMD claimed for this coder is free again when the block is done (a launch with more workgroups than fit at once hands it to a later one)
+    auto release_claim = [&]() __attribute__((always_inline)) {
+#ifndef BZ3_EMU
+        if (jobs[blockIdx.x].claim) (void)atomicAnd(global_ptr<u32>(jobs[blockIdx.x].claim) + claim_key, ~(1u << s_simd[s_coder & 1u]));
+#endif
+    };
     CmByteEvents eva, evb;
     for (u32 i = 0; i < n;) {
         // the bytes below lim are published (whole chunks of 32, the block's last one apart): coded in pairs, the two register sets
         // alternating.  koff points at byte i; the fetch inside code_byte moves it on.
-        if (!wait_for(i)) return;
+        if (!wait_for(i)) {
+            release_claim();
+            return;
+        }
         fetch(eva);  // (again, if the fetch behind the previous pair came too early)
         const u32 lim = prod_seen < n ? prod_seen : n;
         while (i + 2u <= lim) {
@@ -670,6 +742,7 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     }
     out_size[0] = sink.failed ? 0xFFFFFFFFu : sink.op;
     out_size[1] = sink.sw;
+    release_claim();
 }
 
 constexpr int CM_ROWS_ENC = 96;   // 48 KiB of C1 rows: 76,008 B of LDS per workgroup, two workgroups per CU

@@ -114,7 +114,11 @@ struct CmEncodeJob {  // device addresses as integers: see prims.hpp global_ptr(
     // out_size[0] = 0xFFFFFFFF when `side` overflowed.
     u32 gap = CM_NO_GAP, side_cap = 0;
     u64 side = 0;
+    // u32[CM_CLAIM_WORDS] *, zeroed before the launch (0: none): one word per CU in which the workgroups of that CU claim the SIMD their coder wave sits on
+    // (cm.hip, "which of the two waves codes")
+    u64 claim = 0;
 };
+constexpr u32 CM_CLAIM_WORDS = 4096;  // XCC (4 bits) | SE (3) | SH (1) | CU (4)
 struct CmDecodeJob {
     u64 in;        // coded bytes; reads past in_size yield 0xFF.. like read_in (:345)
     u64 out;
