@@ -372,23 +372,6 @@ __device__ __forceinline__ void cm_code_bits_raw(const CmByteEvents & ev, u32 & 
         rmin = r < rmin ? r : rmin;
     }
 }
-// The same, remembering the range after every bit (rr) and the bit's contribution to low (md): what the slow path's search for the FIRST due
-// renormalisation reads (round 5).  On the fast path they are the values the recurrence computes anyway; nothing is added there.
-template <int K0, int CNT>
-__device__ __forceinline__ void cm_code_bits_raw_keep(const CmByteEvents & ev, u32 & r, u32 & l, u32 & rmin, u32 (&rr)[8], u32 (&md)[8]) {
-#pragma unroll
-    for (int kk = K0; kk < K0 + CNT; kk++) {
-        const uint2 ek = ev.k[kk];
-        const u64 prod = (u64)r * ev.m[kk] + (((u64)ek.y << 32) | ek.x);
-        const u32 r2 = (u32)(prod >> 18);
-        const u32 d = (r - r2) & ek.x;
-        l += d;
-        md[kk] = d;
-        rr[kk] = r2;
-        r = r2;
-        rmin = r < rmin ? r : rmin;
-    }
-}
 // Where the coded bytes go.  Normally `out`, a buffer of its own.  In-place coding (gap != CM_NO_GAP): `out` lies
 // `gap` bytes BELOW the input inside the same buffer, so a byte may only be stored below the input bytes that every
 // model wave has already loaded: while byte i is being coded these are the chunks up to and including the one that
@@ -432,37 +415,6 @@ __device__ __forceinline__ void cm_code_bits_checked(const CmByteEvents & ev, u3
             }
         }
     }
-}
-
-// Slow path of a byte whose 8 untested bits ended inside one 2^24 bucket (or whose range reached zero on the way): a renormalisation was due after
-// one of them.  Up to the FIRST such bit the untested values are the reference's own (nothing had been renormalised yet, :390), so the state after bit
-// K is (low + md[0..K], rr[K]): find the first K whose interval lies in a bucket, renormalise there (:390-394) and code only the bits behind it with
-// the test after every bit.  (Rounds 1-4 coded the byte again in halves: raw 4 bits, test, then bit by bit -- ~78 instructions per firing against
-// ~66 here; a quarter of the bytes fire.)
-template <int K>
-__device__ __forceinline__ void cm_code_from_first_due(const CmByteEvents & ev, const u32 (&rr)[8], const u32 (&md)[8], u32 lk, u32 & range, u32 & low, CmSink & sink, u32 i) {
-    {
-        // (opaque to the optimiser: left to itself it recognises these partial sums as the fast path's own low + md[0] + .. and keeps THOSE alive
-        // instead -- eight single adds on every byte where the fast path had four v_add3)
-        u32 m = md[K];
-#ifndef BZ3_EMU
-        asm volatile("" : "+v"(m));
-#endif
-        lk += m;
-    }
-    const u32 rk = rr[K];
-    if (__ballot((lk ^ (lk + rk)) < (1u << 24)) != 0ull || K == 7) {  // (K == 7: the caller's test has fired, so some bit is due; the last one if no earlier)
-        low = lk;
-        range = rk;
-        while (__ballot((low ^ (low + range)) < (1u << 24)) != 0ull) {  // :390-394
-            sink.put(low >> 24, i);
-            low <<= 8;
-            range = (range << 8) | 0xFFu;
-        }
-        cm_code_bits_checked<(K < 7 ? K + 1 : 7), 7 - K>(ev, range, low, sink, i);
-        return;
-    }
-    if constexpr (K < 7) cm_code_from_first_due<K + 1>(ev, rr, md, lk, range, low, sink, i);
 }
 
 // Brings the rows of a chunk's bytes into the cache (R > 0).  mine = this lane's byte (lanes < cnt), hrow1 / hrow2 =
@@ -646,6 +598,9 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     const u32 vzero = cm_opaque_zero();  // keeps the recurrence on the vector ALU
     u32 range = 0xFFFFFFFFu ^ vzero, low = vzero, prod_seen = debug == 1 ? 0xFFFFFFFFu : 0u;
     CmSink sink{out, global_ptr<u8>(jobs[blockIdx.x].side), jobs[blockIdx.x].gap, jobs[blockIdx.x].side_cap, n};
+    // (Round 5 tried the slow path as a search for the FIRST due renormalisation in the values the fast pass has computed anyway -- ~66 instructions per
+    // firing on paper against ~78 -- and measured it 6.3 % SLOWER on the launch, 8,641 against 8,130 ms at 768 x 32 MiB: tools/patches/cm_encoder_first_due_search.patch,
+    // profiles/r05_cm_encoder_placement.txt.)
     // Fast path: all 8 bits of the byte without a single test.  While nothing is renormalised the intervals are
     // nested, so "a renormalisation was due after some bit" is equivalent to "the final interval lies within one
     // 2^24 bucket" (:390): one test per byte (plus the guard against a range that reached zero on the way).  If it fires
@@ -682,13 +637,13 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
     auto bucket_or_zero = [](u32 l, u32 r, u32 rmin) __attribute__((always_inline)) -> bool { return (l ^ (l + r)) < (1u << 24) || rmin == 0u; };
     auto code_byte = [&](const CmByteEvents & ev, CmByteEvents & next, const u32 i) __attribute__((always_inline)) {
         u32 r = range, l = low, rmin = 0xFFFFFFFFu;
-        u32 rr[8], md[8];  // range after every bit, every bit's contribution to low: read by the slow path only
-        cm_code_bits_raw_keep<0, 4>(ev, r, l, rmin, rr, md);
+        cm_code_bits_raw<0, 4>(ev, r, l, rmin);
         cm_sched_fence();
         koff = (koff + 64u) & (CM_RING * 64u - 1u);
         fetch(next);           // unconditional (a branch here would let the compiler move the fetch to the top of the byte): if byte i+1 is not
         cm_sched_fence();      // there yet the slot still holds an older byte and the caller fetches again after waiting
-        cm_code_bits_raw_keep<4, 4>(ev, r, l, rmin, rr, md);
+        const u32 r4 = r, l4 = l, rmin4 = rmin;
+        cm_code_bits_raw<4, 4>(ev, r, l, rmin);
         const bool bad = bucket_or_zero(l, r, rmin);
         const u32 range_old = range, low_old = low;
         range = r;  // committed before the test: an `if` with one arm (cf. the decoder's walker)
@@ -696,7 +651,20 @@ __device__ __forceinline__ void cm_encode_block(const CmEncodeJob * __restrict__
         if (__builtin_expect(__ballot(bad) != 0ull, 0)) {
             range = range_old;
             low = low_old;
-            cm_code_from_first_due<0>(ev, rr, md, low_old, range, low, sink, i);
+            if (__ballot(bucket_or_zero(l4, r4, rmin4)) == 0ull) {  // (the half's own bucket test is implied by the final one; its range-reached-zero guard is not)
+                range = r4;
+                low = l4;
+            } else {
+                cm_code_bits_checked<0, 4>(ev, range, low, sink, i);
+            }
+            r = range, l = low, rmin = 0xFFFFFFFFu;
+            cm_code_bits_raw<4, 4>(ev, r, l, rmin);
+            if (__ballot(bucket_or_zero(l, r, rmin)) == 0ull) {
+                range = r;
+                low = l;
+            } else {
+                cm_code_bits_checked<4, 4>(ev, range, low, sink, i);
+            }
         }
     };
     // Waits until the model waves have published byte i (false: they gave the block up).
