@@ -991,14 +991,19 @@ def main():
                 random_host = SharedBlocks("bz3_bench_random", [rb] * n_ref)
                 for j in range(n_ref):
                     random_host.put_tensor(torch, j, bufs[rsel[j]])
+            gu0, rf0 = int(lib.bz3_hip_cm_blocks_given_up()), int(lib.bz3_hip_cm_blocks_routed_full())
             te, td, coded = round_trip(rsel, [rb] * nr)
+            gu1, rf1 = int(lib.bz3_hip_cm_blocks_given_up()), int(lib.bz3_hip_cm_blocks_routed_full())
             assert all(fingerprint(torch, bufs[k][:rb]) == f for k, f in zip(rsel, fpr)), "random: round trip changed the data"
             RESULT["line"]["configs"]["random"] = {
                 "workload": f"{nr} x {a.random_block_mib:g} MiB uniformly random blocks on one GPU (states of {a.block_mib:g} MiB)",
                 "value": round(nr * rb / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
                 "compressed_ratio": round(nr * rb / sum(coded), 4),
-                "cm_blocks_given_up": "all (256 live order-1 rows: the row-cache kernels hand every block to the whole-model kernels, up to one per CU at a time)"}
+                # 256 live order-1 rows fit no row cache: since round 5 such blocks go STRAIGHT to the whole-model kernels (encode: by the BWT's histogram,
+                # decode: by a payload that did not shrink), one per CU at a time, instead of being given up by the row-cache kernels first
+                "cm_blocks_given_up": gu1 - gu0, "cm_blocks_routed_to_whole_model": rf1 - rf0}
             leg("random_MiBps", RESULT["line"]["configs"]["random"]["value"])
+            leg("random_cm_blocks_given_up", gu1 - gu0)
             leg("random_block_MiB", a.random_block_mib)
             progress(f"random: {RESULT['line']['configs']['random']['value']} MiB/s")
 
