@@ -18,6 +18,26 @@ for d in cases:
     idx, u = o.bwt(d)
     assert g.unbwt(u, idx) == (0, d), len(d)
 print("stages ok", flush=True)
+# round 5: the sorter's hooks (raw-count scatter / scanned offsets, 8- and 9-bit digits), the one-launch scan at ragged sizes, the LZP link build through
+# position bins on a block of several tiles with a ragged last one
+import numpy as np
+rng = np.random.default_rng(5)
+for n, kb, db in ((4097, 18, 9), (70001, 18, 9), (70001, 16, 8), (128 * 4096 + 4096 + 3, 9, 9)):
+    keys = rng.integers(0, 1 << kb, n, dtype=np.uint64).astype(np.uint32)
+    sk = np.empty(n, dtype=np.uint32); si = np.empty(n, dtype=np.uint32)
+    assert lib.bz3_hip_debug_sort_u32(keys.ctypes.data_as(C.c_void_p), n, kb, db, sk.ctypes.data_as(C.c_void_p), si.ctypes.data_as(C.c_void_p)) == -(-kb // db)
+    assert np.array_equal(si, np.argsort(keys, kind="stable").astype(np.uint32)), (n, kb, db)
+for n in (2049, 5003, 65537, 262144, 262147):
+    d = rng.integers(0, 1000, n, dtype=np.uint64).astype(np.uint32)
+    want = np.zeros(n, dtype=np.uint64); want[1:] = np.cumsum(d.astype(np.uint64))[:-1]
+    buf = d.copy(); tot = C.c_uint32(0)
+    assert lib.bz3_hip_debug_scan_u32(buf.ctypes.data_as(C.c_void_p), n, C.byref(tot)) == 0 and np.array_equal(buf, want.astype(np.uint32)), n
+for d in (t[3000:3000 + 4096 * 9 + 5] + t[3100:3100 + 20000], (t[200:1500] * 30)[:4096 * 6 - 1]):
+    assert g.lzp_encode(d) == o.lzp_encode(d), len(d)
+    m, lz = o.lzp_encode(d)
+    if m > 0:
+        assert g.lzp_decode(lz, len(d) + 64) == (len(d), d)
+print("sorter / scan / binned links ok", flush=True)
 for rounds in (0, 8):  # big groups straight to rank doubling / through several more windows first (test hook of the suffix sorter)
     lib.bz3_hip_debug_bwt_big_rounds(rounds)
     for d in cases + [t[777:777 + n] for n in (511, 512, 513, 1025, 2049, 4097)] + [b"a" * 2049]:
