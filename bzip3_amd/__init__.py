@@ -74,6 +74,7 @@ def _declare(L, strict=True):
         "bz3_hip_stage_last_ms": (C.c_float, []),
         "bz3_hip_debug_sort_u32": (i32, [vp, u32, C.c_int, C.c_int, vp, vp]),
         "bz3_hip_debug_scan_u32": (i32, [vp, u32, vp]),
+        "bz3_hip_debug_cu_masks": (i32, [C.c_int, C.c_int, vp, vp]),
         "bz3_hip_set_collect_window_us": (None, [C.c_int]),
         "bz3_hip_debug_collected_batches": (C.c_uint, [C.c_int, C.POINTER(C.c_uint)]),
         "bz3_hip_stage_cm_encode": (i32, [vp, i32, vp]),

@@ -2157,6 +2157,18 @@ BZIP3_API int32_t bz3_hip_stage_unbwt(const uint8_t * in, uint8_t * out, int32_t
     });
 }
 
+// Tests only: the CU masks of the partition (DeviceCtx::cu_masks) for a device of `cus` CUs and `reserve` reserved ones: words = (cus + 31) / 32 each.
+BZIP3_API int32_t bz3_hip_debug_cu_masks(int cus, int reserve, uint32_t * side, uint32_t * rest) {
+    if (cus < 32 || cus > 1024 || reserve < 8 || !side || !rest) return -1;
+    std::vector<uint32_t> a, b;
+    DeviceCtx::cu_masks(cus, reserve, a, b);
+    for (size_t k = 0; k < a.size(); k++) {
+        side[k] = a[k];
+        rest[k] = b[k];
+    }
+    return (int32_t)a.size();
+}
+
 // Tests only: sort.hip's device-wide exclusive scan on a host buffer (in place); returns the grand total through *total.
 BZIP3_API int32_t bz3_hip_debug_scan_u32(uint32_t * data, uint32_t n, uint32_t * total) {
     return stage_guard([&]() -> s32 {

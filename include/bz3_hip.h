@@ -117,6 +117,8 @@ BZIP3_API int32_t bz3_hip_stage_lzp_encode(const uint8_t * in, int32_t n, uint8_
 BZIP3_API int32_t bz3_hip_stage_lzp_decode(const uint8_t * in, int32_t n, uint8_t * out, int32_t max); /* lzp_decompress */
 BZIP3_API int32_t bz3_hip_stage_bwt(const uint8_t * in, uint8_t * out, int32_t n);                  /* libsais_bwt     */
 BZIP3_API int32_t bz3_hip_stage_unbwt(const uint8_t * in, uint8_t * out, int32_t n, int32_t idx);   /* libsais_unbwt   */
+/* tests only: the two CU masks of the decoder's partition (side streams / everything else) for `cus` CUs of which `reserve` are set aside; returns the words per mask */
+BZIP3_API int32_t bz3_hip_debug_cu_masks(int cus, int reserve, uint32_t * side, uint32_t * rest);
 /* tests only: sort.hip's device-wide exclusive prefix sum, in place on a host buffer */
 BZIP3_API int32_t bz3_hip_debug_scan_u32(uint32_t * data, uint32_t n, uint32_t * total);
 /* tests only: sort.hip's stable LSD radix sort of (keys[i], i) over key bits [0, key_bits), digits of 8 or 9 bits; returns the passes run */

@@ -121,3 +121,24 @@ def test_prototypes_equal_the_reference_header_when_it_is_here():
                   "BZ3_ERR_INIT", "BZ3_ERR_DATA_SIZE_TOO_SMALL"):
         val = lambda p: re.search(r"#define\s+%s\s+(-?\d+)" % macro, open(p).read()).group(1)
         assert val(os.path.join(ROOT, "include", "libbz3.h")) == val(ref_path), macro
+
+
+def test_cu_partition_masks_are_disjoint_and_balanced(lib):
+    """The decoder's CU partition (api.hip DeviceCtx::cu_masks): the reserved CUs and the rest are disjoint, cover the device, and the reserved ones are
+    spread evenly whichever way the driver deals mask bits to the eight XCDs -- in blocks of 32 bits or round robin (bit i -> XCD i mod 8)."""
+    import ctypes as C
+
+    for cus, reserve in ((256, 48), (256, 32), (256, 64), (256, 16), (128, 32)):
+        words = (cus + 31) // 32
+        side = (C.c_uint32 * words)()
+        rest = (C.c_uint32 * words)()
+        assert lib.bz3_hip_debug_cu_masks(cus, reserve, side, rest) == words
+        s_bits = {32 * w + b for w in range(words) for b in range(32) if (side[w] >> b) & 1}
+        r_bits = {32 * w + b for w in range(words) for b in range(32) if (rest[w] >> b) & 1}
+        blocks = min(8, cus // 32)
+        per = min(8, max(1, reserve // 8))
+        assert not (s_bits & r_bits) and (s_bits | r_bits) == set(range(cus))
+        assert len(s_bits) == per * blocks
+        assert all(sum(1 for i in s_bits if i // 32 == a) == per for a in range(blocks))          # dealt in blocks of 32
+        if blocks == 8:
+            assert all(sum(1 for i in s_bits if i % 8 == x) == per for x in range(8))              # dealt round robin
