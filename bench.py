@@ -82,6 +82,10 @@ CM_MODES = {"auto": -1, "full": 0, "rows": 1, "rows3": 2}
 # explains; it sets the same default when it initialises the runtime itself -- here torch does, so it has to be in the environment before that).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
+# runs of their own whose last record rides along under config.recorded (never under config.legs)
+RECORDED_RUNS = {"cfg5_256x511MiB_round_trip": "r06_bench_cfg5_256x511MiB.json", "random_256x256MiB_round_trip": "r06_bench_random_256x256MiB.json"}
+PHASE = {"name": "start-up", "fatal": True}  # where an exception would come from; fatal: the headline is not valid without this phase
+
 T_START = time.perf_counter()
 RANK = int(os.environ.get("RANK", "0"))
 WORLD = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,6 +156,15 @@ def plan_steps(left_s, t_first_s, req_steps, req_warmup):
         more = max(1, min(req_steps, afford - (warmup - 1)))
         return warmup, more
     return 0, max(0, min(req_steps - 1, afford))
+
+
+def inject(point):
+    """TESTS ONLY (tests/test_bench_ranks.py): BZ3_BENCH_INJECT_FAIL=<point>[:assert] raises at the named point, to exercise the exit paths."""
+    want = os.environ.get("BZ3_BENCH_INJECT_FAIL", "")
+    if want.split(":")[0] == point:
+        if want.endswith(":assert"):
+            raise AssertionError(f"injected assertion at {point}")
+        raise RuntimeError(f"injected failure at {point}")
 
 
 def progress(msg):
@@ -559,6 +572,33 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
     start_watchdog(a.deadline_s)
+    try:
+        run(a)
+    except SystemExit:
+        raise
+    except BaseException as e:  # every exit path prints the JSON line (round 5's run died with a traceback and no line)
+        import traceback
+
+        traceback.print_exc()
+        sys.stderr.flush()
+        msg = f"{type(e).__name__}: {str(e)[:400]}"
+        if RANK == 0:
+            if RESULT["line"] is None:  # nothing timed yet: a line that says so
+                RESULT["line"] = {"metric": "MiB/s encode+decode round-trip, 256 MiB blocks", "value": None, "unit": "MiB/s", "n_gpus": WORLD, "steps": 0, "warmup": 0,
+                                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic", "config": {"workload": "failed before the first timed step completed"}}
+            RESULT["line"]["error"] = msg
+            RESULT["line"]["failed_phase"] = PHASE["name"]
+            emit_line(final=False)
+        # a failure in or before the timed steps or their verification invalidates the headline: non-zero exit, with the line printed
+        # (an AssertionError is a correctness check that did not hold -- a block that failed to code, a round trip that changed the data: always fatal; anything
+        # else after the first step has been timed AND verified leaves a valid headline: exit 0 with the error in the line)
+        fatal = PHASE["fatal"] or isinstance(e, AssertionError) or RESULT["line"] is None or RESULT["line"].get("value") is None
+        os._exit(1 if fatal else 0)
+    if RANK == 0 and RESULT["line"] is not None and RESULT["line"].get("parity_failed"):
+        os._exit(1)
+
+
+def run(a):
     import torch  # first: the HIP runtime of the process must be torch's (see bzip3_amd._share_hip_runtime_with_torch)
     import torch.distributed as dist
 
@@ -709,6 +749,35 @@ def main():
         per_thread = 7.5 * cpu_block + (64 << 20)  # reference state (~5.1 x block) + buffer + the shared copies
         cpu_n = int(max(1, min(os.cpu_count() or 1, a.cpu_threads, nblk, host_mem_available() * 0.8 // per_thread)))
     coded_kept = []
+    parity_sample = {}  # "coded": SharedBlocks with the GPU's coded bytes of blocks 0..cpu_n-1, "how": where they were copied
+
+    def keep_coded_sample(sizes):
+        """The GPU's coded bytes of the parity sample, set aside before the in-place decode overwrites them.  Device-to-device copies into the
+        headroom the library leaves (bz3_hip_set_workspace_headroom); if the device has no room for them after all (round 5: the kept workspace had
+        taken every byte and the FIRST of these 48 MiB clones killed the run), straight to host shared memory instead -- slower, inside the timed
+        step, and reported; if even that fails the sample is skipped and the run goes on without the byte comparison."""
+        t_ = time.perf_counter()
+        try:
+            for i in range(cpu_n):
+                coded_kept.append(bufs[i][: sizes[i]].clone())
+            dev_sync()
+            parity_sample["how"] = f"device-to-device copies inside the first timed step ({(time.perf_counter() - t_) * 1e3:.0f} ms)"
+            return
+        except RuntimeError as e:  # torch.OutOfMemoryError is one
+            coded_kept.clear()
+            if cuda:
+                torch.cuda.empty_cache()
+            progress(f"parity sample: no room on the device for the copies ({str(e)[:80]}...); copying to host memory instead")
+        try:
+            sh = SharedBlocks("bz3_bench_coded", [int(sizes[i]) for i in range(cpu_n)])
+            for i in range(cpu_n):
+                sh.put_tensor(torch, i, bufs[i])
+            parity_sample["coded"] = sh
+            parity_sample["how"] = f"device-to-host copies inside the first timed step ({time.perf_counter() - t_:.2f} s: the device had no room for device-side copies)"
+        except Exception as e:
+            parity_sample["coded"] = None
+            parity_sample["how"] = f"skipped: {type(e).__name__}: {str(e)[:120]}"
+            progress("parity sample " + parity_sample["how"])
 
     def one_step(record=False):
         sizes = (C.c_int32 * nblk)(*[block_size] * nblk)
@@ -728,9 +797,8 @@ def main():
             stage["bwt"] = {"rounds": r.value, "radix_passes": p.value, "sorted_elements": e.value}
             ring = lib.bz3_hip_debug_front_end_ring()  # the encoder's front-end pipeline: context slots x blocks per window
             stage["front_end_ring"] = {"slots": (ring >> 16) & 0xFF, "window": ring & 0xFFFF, "workspace_handed_back": bool(ring >> 30)}
-            if cpu_block == block_size and not coded_kept and not step_s and want_cpu:  # a few ms of device-to-device copies inside the timed region, first step only
-                for i in range(cpu_n):
-                    coded_kept.append(bufs[i][: sizes[i]].clone())
+            if cpu_block == block_size and not coded_kept and not step_s and want_cpu and "coded" not in parity_sample:
+                keep_coded_sample(sizes)  # a few ms of device-to-device copies inside the timed region, first step only (the in-place decode destroys the coded bytes)
         t2 = time.perf_counter()
         lib.bz3_hip_decode_blocks_device(states, ptrs, bsz, sizes, orig, nblk)
         t3 = time.perf_counter()
@@ -752,8 +820,144 @@ def main():
     # the workspace survives between the calls of the timed steps (a caller that runs GPU-filling lean batches back to back would ask for the same:
     # include/bz3_hip.h); it is handed back before the extra legs
     keep_ws = not a.emu and os.environ.get("BZ3_BENCH_KEEP_WS", "1") != "0"
+    # what the library must leave free on the device when a call returns (include/bz3_hip.h: the headroom rule): room for the parity sample's
+    # copies of the coded blocks (~a fifth of a block each) and the fingerprints' temporaries
+    headroom = (4 << 30) + (int(cpu_n * block_size * 0.3) if want_cpu and cpu_block == block_size else 0)
+    headroom = min(headroom, 8 << 30)
+    if not a.emu and hasattr(lib, "bz3_hip_set_workspace_headroom"):
+        lib.bz3_hip_set_workspace_headroom(headroom)
+
+    def build_line():
+        """The JSON line from what has been timed so far (rank 0 keeps it in RESULT; every exit path prints it)."""
+        steps_run, timed, warmup_run = len(step_s), sum(step_s), 0
+        total_bytes = world * nblk * block_size
+        value = total_bytes * steps_run / 2 ** 20 / timed
+        if rank == 0:
+            comp_total = sum(comp_sizes)
+            n_dec = block_size  # n' ~ n for text
+            cm_dec_ms, cm_enc_ms = stage["dec"]["cm"], stage["enc"]["cm"]
+            bwt_ms = stage["enc"]["bwt"]
+            # Dominant kernel = the CM launch that takes longer.  Algorithmic bytes of a CM launch: every block's n' bytes on one
+            # side and its coded bytes on the other (SURVEY.md 8d: CM 1R + cW / cR + 1W); launch time from HIP events on the
+            # launching stream (api.hip run_cm_jobs).
+            dec_dominant = cm_dec_ms >= cm_enc_ms
+            dom_ms = max(cm_dec_ms if dec_dominant else cm_enc_ms, 1e-6)
+            enc_names = {0: "k_cm_encode", 1: "k_cm_encode_rows", 2: "k_cm_encode_rows3"}
+            dec_names = {0: "k_cm_decode_sync", 1: "k_cm_decode_sync2", 2: "k_cm_decode_sync3"}
+            kern = (dec_names if dec_dominant else enc_names).get(lib.bz3_hip_cm_variant_for(local_dev, nblk, 0 if dec_dominant else 1), "k_cm_decode_sync")
+            cm_bytes = n_dec * nblk + comp_total
+            # HBM traffic of the dominant kernel from the PMC pass (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs,
+            # corrected as MI355X_MICROARCH.md prescribes), recorded per byte and scaled to this launch.
+            traffic = None
+            try:
+                with open(PMC_TRAFFIC_FILE) as fh:
+                    pm = json.load(fh).get(kern)
+                if pm and dec_dominant:
+                    traffic = int(pm["fetch_bytes_per_coded_byte"] * comp_total + pm["write_bytes_per_decoded_byte"] * n_dec * nblk)
+                elif pm:
+                    traffic = int(pm["fetch_bytes_per_input_byte"] * n_dec * nblk + pm["write_bytes_per_coded_byte"] * comp_total)
+            except Exception:
+                pass
+            what = {"": f"synthetic enwik-style {a.kind}", "cfg5": "16-symbol order-1 Markov (BASELINE.json configs[4] stand-in)"}[a.leg]
+            if a.emu:
+                what = "16-symbol order-1 Markov (--emu: CPU emulation of the kernels, control-flow test only)"
+            out = {
+                "metric": "MiB/s encode+decode round-trip, 256 MiB blocks" if not a.leg else f"MiB/s encode+decode round-trip, {block_size >> 20} MiB blocks (leg {a.leg})",
+                "value": round(value, 3),
+                "unit": "MiB/s",
+                "n_gpus": world,
+                "steps": steps_run,
+                "warmup": warmup_run,
+                "ms_per_step": round(timed / steps_run * 1e3, 1),
+                "step_s": [round(x, 2) for x in step_s],
+                "step_spread": round((max(step_s) - min(step_s)) / (timed / steps_run), 4),
+                "higher_is_better": True,
+                "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": "u8",
+                "data": "synthetic",
+                "requested": {"steps": a.steps, "warmup": a.warmup, "budget_s": a.budget_s,
+                              "note": "steps/warmup clamped to the wall budget: one step codes and decodes a GPU-filling batch of 256 MiB blocks; both steps are timed, "
+                                      "the first one includes the first-call effects (workspace allocation); nothing else runs on the host or the GPU during the timed steps"},
+                "config": {
+                    "workload": f"{nblk} x {block_size / 2 ** 20:g} MiB {what} blocks per GPU"
+                                + (f" (word-bigram Markov over shakespeare.txt tokens, {noise * 100:g} % noise tokens = enwik8's 4.41 : 1 at -b 16; {nbase} independent texts, "
+                                   f"block k = text k mod {nbase} with its 64 KiB pieces in a block-specific order)" if a.kind == "text" and not a.leg and not a.emu else "")
+                                + ", resident in HBM, bz3_hip_encode_blocks_device + bz3_hip_decode_blocks_device",
+                    "block_bytes": block_size,
+                    "blocks_per_gpu": nblk,
+                    "parallelism": f"blocks sharded over {world} GPU(s), no collective",
+                    "sharding_model": sharding_model(world),
+                    "legs": {},  # the scalars of the extra legs (filled as they finish; the driver's record keeps `config`, not `configs`)
+                    "compressed_ratio": round((nblk * block_size) / max(1, comp_total), 3),
+                    "cm_mode": a.cm_mode,
+                    "lean_states": bool(lean),
+                    "keep_workspace": bool(keep_ws),
+                    "workspace_headroom_bytes": int(headroom),
+                    "parity_sample": parity_sample.get("how"),
+                    "cm_blocks_given_up": int(lib.bz3_hip_cm_blocks_given_up()),
+                    "bwt_output_repeat_rate_16MiB_sample": None,
+                    "round_trip_check": f"position-weighted 64-bit fingerprint of every block + byte-for-byte comparison of {n_keep} blocks",
+                },
+                # dominant kernel by time: a CM launch (one workgroup per block; a serial integer recurrence,
+                # latency-bound by construction -- SURVEY.md 7/H1), priced against the HBM roofline as the contract asks
+                "roofline": {
+                    "kernel": kern,
+                    "bound": "hbm",
+                    "achieved": round(cm_bytes / (dom_ms * 1e-3) / 1e9, 6),
+                    "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s",
+                    "frac": round(cm_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 9),
+                    "traffic": traffic,
+                    "launch_ms": dom_ms,
+                    "algorithmic_bytes_per_launch": int(cm_bytes),
+                },
+                "path_roofline": {
+                    "achieved": round(ALG_BYTES_ROUND_TRIP * total_bytes * steps_run / timed / 1e9, 4),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "bytes_per_input_byte": ALG_BYTES_ROUND_TRIP,
+                },
+                "bwt_roofline": {
+                    "stage": "bwt_forward (one 56-bit code-window radix sort + in-LDS group resolution), one block",
+                    "achieved": round(ALG_BYTES_BWT * block_size / (max(bwt_ms, 1e-6) * 1e-3) / 1e9, 3),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(ALG_BYTES_BWT * block_size / (max(bwt_ms, 1e-6) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
+                    "ms": bwt_ms, **stage.get("bwt", {}),
+                },
+                "stages": json.loads(json.dumps(stage)),
+                "gen_s": round(t_gen, 1),
+                "configs": {},
+                "cpu_baseline": {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": "not run (budget, --no-cpu-baseline, --leg or N > 1)"},
+            }
+            prev = RESULT["line"]
+            if prev is not None:  # a line built after an earlier step: what has been measured beside the steps since then stays
+                out["configs"] = prev["configs"]
+                out["cpu_baseline"] = prev["cpu_baseline"]
+                out["config"]["legs"] = prev["config"]["legs"]
+                for k_ in ("bwt_output_repeat_rate_16MiB_sample",):
+                    if prev["config"].get(k_) is not None:
+                        out["config"][k_] = prev["config"][k_]
+            RESULT["line"] = out
+            if a.leg == "cfg5":
+                out["config"]["legs"]["cfg5_round_trip_MiBps"] = out["value"]
+            elif not a.emu:
+                # the cfg5 leg is a run of its own (a 511 MiB block's CM launches last ~2.5 + ~5.3 minutes): its last RECORDED value rides along, marked as such
+                # (under a key of its own: config.legs holds only what THIS run measured -- ADVICE r05)
+                rec_ = {}
+                for key_, file_ in RECORDED_RUNS.items():
+                    try:
+                        with open(os.path.join(ROOT, "profiles", file_)) as fh:
+                            j_ = json.load(fh)
+                        rec_[key_] = {"value": j_["value"], "unit": j_.get("unit", "MiB/s"), "vs_cpu": (j_.get("cpu_baseline") or {}).get("gpu_over_cpu"), "file": "profiles/" + file_}
+                    except Exception:
+                        pass
+                if rec_:
+                    out["config"]["recorded"] = {"note": "runs of their own (`bench.py --leg cfg5`, `bench.py --kind random`): NOT measured in this run, copied from the files named", **rec_}
+
+
     if keep_ws:
         lib.bz3_hip_set_keep_workspace(1)
+    PHASE["name"] = "first timed step"
+    inject("step1")
     barrier()
     t0 = time.perf_counter()
     one_step(record=True)
@@ -767,63 +971,49 @@ def main():
         for k in range(n_keep):
             assert torch.equal(bufs[k][:block_size], kept[k]), f"block {k}: round trip changed the data"
 
+    build_line()  # from here on every exit path prints a line (the watchdog, SIGTERM, an exception)
+    PHASE["name"] = "verification of the first step's round trip"
+    inject("verify1")
     verify_round_trip()
     # the GPU's coded bytes of the parity sample go to shared memory NOW (outside the timed steps): 64 x ~50 MB of HBM that the second
     # step's ring of LZP contexts can use
-    shared_coded = None
+    shared_coded = parity_sample.get("coded")
     if want_cpu and coded_kept:
-        shared_coded = SharedBlocks("bz3_bench_coded", [int(c.numel()) for c in coded_kept])
-        for i, c in enumerate(coded_kept):
-            shared_coded.put_tensor(torch, i, c)
+        try:
+            shared_coded = SharedBlocks("bz3_bench_coded", [int(c.numel()) for c in coded_kept])
+            for i, c in enumerate(coded_kept):
+                shared_coded.put_tensor(torch, i, c)
+        except Exception as e:
+            shared_coded = None
+            parity_sample["how"] = f"skipped: {type(e).__name__}: {str(e)[:120]}"
         coded_kept.clear()
         if cuda:
             torch.cuda.empty_cache()
+    PHASE["fatal"] = False  # one step timed and verified: the headline stands whatever happens next (but see main(): assertions stay fatal)
     left = agree(a.budget_s - elapsed()) - reserve
     second = (a.steps >= 2 or a.warmup > 0) and left > step_s[0] * 1.03
     if second:
+        PHASE["name"] = "second timed step"
+        inject("step2")
         barrier()
         t0 = time.perf_counter()
         one_step(record=True)
         barrier()
         step_s.append(max_over_ranks(time.perf_counter() - t0))
+        build_line()
+        PHASE["name"] = "verification of the second step's round trip"
         verify_round_trip()
     if keep_ws:
         lib.bz3_hip_set_keep_workspace(-1)
         lib.bz3_hip_release_cached_memory()
-    steps_run, timed, warmup_run = len(step_s), sum(step_s), 0
+    build_line()
+    steps_run = len(step_s)
     progress(f"timed {steps_run} step(s): {[round(x, 1) for x in step_s]} s (requested {a.steps} / {a.warmup}; budget {a.budget_s:.0f}s)")
-
-    total_bytes = world * nblk * block_size
-    value = total_bytes * steps_run / 2 ** 20 / timed
-    if rank == 0:
-        comp_total = sum(comp_sizes)
-        n_dec = block_size  # n' ~ n for text
-        cm_dec_ms, cm_enc_ms = stage["dec"]["cm"], stage["enc"]["cm"]
-        bwt_ms = stage["enc"]["bwt"]
-        # Dominant kernel = the CM launch that takes longer.  Algorithmic bytes of a CM launch: every block's n' bytes on one
-        # side and its coded bytes on the other (CM 1R + cW / cR + 1W); launch time from HIP events on the
-        # launching stream (api.hip run_cm_jobs).
-        dec_dominant = cm_dec_ms >= cm_enc_ms
-        dom_ms = max(cm_dec_ms if dec_dominant else cm_enc_ms, 1e-6)
-        enc_names = {0: "k_cm_encode", 1: "k_cm_encode_rows", 2: "k_cm_encode_rows3"}
-        dec_names = {0: "k_cm_decode_sync", 1: "k_cm_decode_sync2", 2: "k_cm_decode_sync3"}
-        kern = (dec_names if dec_dominant else enc_names).get(lib.bz3_hip_cm_variant_for(local_dev, nblk, 0 if dec_dominant else 1), "k_cm_decode_sync")
-        cm_bytes = n_dec * nblk + comp_total
-        # HBM traffic of the dominant kernel from the PMC pass (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs,
-        # corrected as MI355X_MICROARCH.md prescribes), recorded per byte and scaled to this launch.
-        traffic = None
-        try:
-            with open(PMC_TRAFFIC_FILE) as fh:
-                pm = json.load(fh).get(kern)
-            if pm and dec_dominant:
-                traffic = int(pm["fetch_bytes_per_coded_byte"] * comp_total + pm["write_bytes_per_decoded_byte"] * n_dec * nblk)
-            elif pm:
-                traffic = int(pm["fetch_bytes_per_input_byte"] * n_dec * nblk + pm["write_bytes_per_coded_byte"] * comp_total)
-        except Exception:
-            pass
+    PHASE["name"] = "extra legs"
+    inject("legs")
+    if rank == 0 and not a.emu:
         # what the CM stage sees, on a 16 MiB sample of block 0 through the stage hooks (outside the timed region): how often a byte of
         # the BWT output repeats its predecessor decides how often the decoder's guess-ahead is right
-        repeat_rate = None
         try:
             import numpy as np
 
@@ -831,92 +1021,41 @@ def main():
             smp = bufs[0][: min(block_size, 16 << 20)].cpu().numpy().tobytes()
             nl_, lz_ = g_.lzp_encode(smp)
             u_ = np.frombuffer(g_.bwt(lz_ if nl_ > 0 else smp)[1], dtype=np.uint8)
-            repeat_rate = round(float((u_[1:] == u_[:-1]).mean()), 4)
+            RESULT["line"]["config"]["bwt_output_repeat_rate_16MiB_sample"] = round(float((u_[1:] == u_[:-1]).mean()), 4)
         except Exception as e:
             progress(f"repeat-rate sample failed: {e}")
-        what = {"": f"synthetic enwik-style {a.kind}", "cfg5": "16-symbol order-1 Markov (BASELINE.json configs[4] stand-in)"}[a.leg]
-        if a.emu:
-            what = "16-symbol order-1 Markov (--emu: CPU emulation of the kernels, control-flow test only)"
-        out = {
-            "metric": "MiB/s encode+decode round-trip, 256 MiB blocks" if not a.leg else f"MiB/s encode+decode round-trip, {block_size >> 20} MiB blocks (leg {a.leg})",
-            "value": round(value, 3),
-            "unit": "MiB/s",
-            "n_gpus": world,
-            "steps": steps_run,
-            "warmup": warmup_run,
-            "ms_per_step": round(timed / steps_run * 1e3, 1),
-            "step_s": [round(x, 2) for x in step_s],
-            "step_spread": round((max(step_s) - min(step_s)) / (timed / steps_run), 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "requested": {"steps": a.steps, "warmup": a.warmup, "budget_s": a.budget_s,
-                          "note": "steps/warmup clamped to the wall budget: one step codes and decodes a GPU-filling batch of 256 MiB blocks; both steps are timed, "
-                                  "the first one includes the first-call effects (workspace allocation); nothing else runs on the host or the GPU during the timed steps"},
-            "config": {
-                "workload": f"{nblk} x {block_size / 2 ** 20:g} MiB {what} blocks per GPU"
-                            + (f" (word-bigram Markov over shakespeare.txt tokens, {noise * 100:g} % noise tokens = enwik8's 4.41 : 1 at -b 16; {nbase} independent texts, "
-                               f"block k = text k mod {nbase} with its 64 KiB pieces in a block-specific order)" if a.kind == "text" and not a.leg and not a.emu else "")
-                            + ", resident in HBM, bz3_hip_encode_blocks_device + bz3_hip_decode_blocks_device",
-                "block_bytes": block_size,
-                "blocks_per_gpu": nblk,
-                "parallelism": f"blocks sharded over {world} GPU(s), no collective",
-                "sharding_model": sharding_model(world),
-                "legs": {},  # the scalars of the extra legs (filled as they finish; the driver's record keeps `config`, not `configs`)
-                "compressed_ratio": round((nblk * block_size) / max(1, comp_total), 3),
-                "cm_mode": a.cm_mode,
-                "lean_states": bool(lean),
-                "keep_workspace": bool(keep_ws),
-                "cm_blocks_given_up": int(lib.bz3_hip_cm_blocks_given_up()),
-                "bwt_output_repeat_rate_16MiB_sample": repeat_rate,
-                "round_trip_check": f"position-weighted 64-bit fingerprint of every block + byte-for-byte comparison of {n_keep} blocks",
-            },
-            # dominant kernel by time: a CM launch (one workgroup per block; a serial integer recurrence,
-            # latency-bound by construction -- SURVEY.md 7/H1), priced against the HBM roofline as the contract asks
-            "roofline": {
-                "kernel": kern,
-                "bound": "hbm",
-                "achieved": round(cm_bytes / (dom_ms * 1e-3) / 1e9, 6),
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": round(cm_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 9),
-                "traffic": traffic,
-                "launch_ms": dom_ms,
-                "algorithmic_bytes_per_launch": int(cm_bytes),
-            },
-            "path_roofline": {
-                "achieved": round(ALG_BYTES_ROUND_TRIP * total_bytes * steps_run / timed / 1e9, 4),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "bytes_per_input_byte": ALG_BYTES_ROUND_TRIP,
-            },
-            "bwt_roofline": {
-                "stage": "bwt_forward (one 56-bit code-window radix sort + in-LDS group resolution), one block",
-                "achieved": round(ALG_BYTES_BWT * block_size / (max(bwt_ms, 1e-6) * 1e-3) / 1e9, 3),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ALG_BYTES_BWT * block_size / (max(bwt_ms, 1e-6) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
-                "ms": bwt_ms, **stage.get("bwt", {}),
-            },
-            "stages": stage,
-            "gen_s": round(t_gen, 1),
-            "configs": {},
-            "cpu_baseline": {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": "not run (budget, --no-cpu-baseline, --leg or N > 1)"},
-        }
-        RESULT["line"] = out
-        if a.leg == "cfg5":
-            out["config"]["legs"]["cfg5_round_trip_MiBps"] = out["value"]
-        elif not a.emu:
-            # the cfg5 leg is a run of its own (a 511 MiB block's CM launches last ~2.5 + ~5.3 minutes): its last RECORDED value rides along, marked as such
-            try:
-                with open(os.path.join(ROOT, "profiles", "r05_bench_cfg5_256x511MiB.json")) as fh:
-                    out["config"]["legs"]["cfg5_round_trip_MiBps_recorded"] = json.load(fh)["value"]
-                    out["config"]["legs"]["cfg5_note"] = "recorded by `bench.py --leg cfg5 --blocks 256` (profiles/r05_bench_cfg5_256x511MiB.json), not measured in this run"
-            except Exception:
-                pass
-
     # ---- extra legs (rank 0 at N=1; the watchdog prints the line without them if they overrun) ----------------------------
     def left_s():
         return a.budget_s - elapsed()
+
+    class guard:
+        """An extra leg may fail (out of memory beside the batch, a reference process that dies ...) without taking the run's line with it: the
+        failure is recorded under configs[name] and the next leg runs."""
+
+        def __init__(self, name):
+            self.name = name
+
+        def __enter__(self):
+            PHASE.update(name=f"leg {self.name}", fatal=False)
+
+        def __exit__(self, et, ev, tb):
+            if et is None or not issubclass(et, Exception):
+                return False
+            import traceback
+
+            progress(f"leg {self.name} FAILED: {et.__name__}: {str(ev)[:300]}")
+            traceback.print_tb(tb, file=sys.stderr)
+            if RESULT["line"] is not None:
+                slot = RESULT["line"]["configs"].setdefault(self.name, {})
+                if isinstance(slot, dict):
+                    slot["failed"] = f"{et.__name__}: {str(ev)[:300]}"
+                RESULT["line"].setdefault("failed_legs", []).append(self.name)
+            try:
+                if cuda:
+                    torch.cuda.empty_cache()
+            except Exception:
+                pass
+            return True
 
     def leg(name, v):
         """a leg's scalar where the driver's record keeps it (config.legs)"""
@@ -947,16 +1086,17 @@ def main():
     ref_choice = {"label": "gcc -O2", "path": None}
     shared_plain = None
     cpu_worker_proc = None
-    if want_cpu and a.deadline_s - 30.0 - elapsed() > cpu_need:
-        # plaintext of blocks 0..cpu_n-1 (verified above) and the GPU's coded bytes of the same blocks, in shared memory for the reference process
-        bs_cpu = min(cpu_block, block_size)
-        shared_plain = SharedBlocks("bz3_bench_plain", [bs_cpu] * cpu_n)
-        for i in range(cpu_n):
-            shared_plain.put_tensor(torch, i, bufs[i if cpu_block == block_size else 0])
-        progress(f"cpu_baseline: {cpu_n} threads x {bs_cpu >> 20} MiB blocks in a process of its own (estimated {cpu_need:.0f}s); GPU-only legs meanwhile")
-        cpu_worker_proc = RefWorker(shared_plain.meta(), max(bs_cpu, 65 * 1024), coded=shared_coded.meta() if shared_coded else None, probe=True)
-    elif want_cpu:
-        RESULT["line"]["cpu_baseline"]["sample"] = f"not run: needs ~{cpu_need:.0f}s, {a.deadline_s - elapsed():.0f}s to the deadline"
+    with guard("cpu_baseline_start"):
+        if want_cpu and a.deadline_s - 30.0 - elapsed() > cpu_need:
+            # plaintext of blocks 0..cpu_n-1 (verified above) and the GPU's coded bytes of the same blocks, in shared memory for the reference process
+            bs_cpu = min(cpu_block, block_size)
+            shared_plain = SharedBlocks("bz3_bench_plain", [bs_cpu] * cpu_n)
+            for i in range(cpu_n):
+                shared_plain.put_tensor(torch, i, bufs[i if cpu_block == block_size else 0])
+            progress(f"cpu_baseline: {cpu_n} threads x {bs_cpu >> 20} MiB blocks in a process of its own (estimated {cpu_need:.0f}s); GPU-only legs meanwhile")
+            cpu_worker_proc = RefWorker(shared_plain.meta(), max(bs_cpu, 65 * 1024), coded=shared_coded.meta() if shared_coded else None, probe=True)
+        elif want_cpu:
+            RESULT["line"]["cpu_baseline"]["sample"] = f"not run: needs ~{cpu_need:.0f}s, {a.deadline_s - elapsed():.0f}s to the deadline"
 
     def free_most_of_the_batch():
         """room for the legs below: most of the batch's buffers and the big workspace are not needed any more"""
@@ -972,127 +1112,135 @@ def main():
     live_states = nblk
     random_host = None
     mixed_host = None
-    if extras_wanted and a.kind == "text" and left_s() > 200.0:
-        # ---- random: incompressible blocks, as many as the timed batch had (LZP and RLE decline, model 0, ~1.004 bytes per byte) ----
-        rb = int(a.random_block_mib * (1 << 20))
-        nr = a.random_blocks if a.random_blocks > 0 else nblk
-        nr = max(1, min(nr, nblk))
-        if rb <= block_size:
-            progress(f"random: {nr} x {a.random_block_mib:g} MiB")
+    with guard("random"):
+        if extras_wanted and a.kind == "text" and left_s() > 200.0:
+            # ---- random: incompressible blocks, as many as the timed batch had (LZP and RLE decline, model 0, ~1.004 bytes per byte) ----
+            rb = int(a.random_block_mib * (1 << 20))
+            nr = a.random_blocks if a.random_blocks > 0 else nblk
+            nr = max(1, min(nr, nblk))
+            if rb <= block_size:
+                progress(f"random: {nr} x {a.random_block_mib:g} MiB")
+                g = torch.Generator(device=device)
+                g.manual_seed(2)
+                fpr = []
+                rsel = list(range(nblk - nr, nblk))  # (their text is not needed any more, except blocks 0..cpu_n-1's: those are in shared memory already)
+                for k in rsel:
+                    bufs[k][:rb] = torch.randint(0, 256, (rb,), dtype=torch.uint8, generator=g, device=device)
+                    fpr.append(fingerprint(torch, bufs[k][:rb]))
+                n_ref = min(nr, a.cpu_threads, os.cpu_count() or 1)
+                if want_cpu:
+                    random_host = SharedBlocks("bz3_bench_random", [rb] * n_ref)
+                    for j in range(n_ref):
+                        random_host.put_tensor(torch, j, bufs[rsel[j]])
+                gu0, rf0 = int(lib.bz3_hip_cm_blocks_given_up()), int(lib.bz3_hip_cm_blocks_routed_full())
+                te, td, coded = round_trip(rsel, [rb] * nr)
+                gu1, rf1 = int(lib.bz3_hip_cm_blocks_given_up()), int(lib.bz3_hip_cm_blocks_routed_full())
+                assert all(fingerprint(torch, bufs[k][:rb]) == f for k, f in zip(rsel, fpr)), "random: round trip changed the data"
+                RESULT["line"]["configs"]["random"] = {
+                    "workload": f"{nr} x {a.random_block_mib:g} MiB uniformly random blocks on one GPU (states of {a.block_mib:g} MiB)",
+                    "value": round(nr * rb / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
+                    "compressed_ratio": round(nr * rb / sum(coded), 4),
+                    # 256 live order-1 rows fit no row cache: since round 5 such blocks go STRAIGHT to the whole-model kernels (encode: by the BWT's histogram,
+                    # decode: by a payload that did not shrink), one per CU at a time, instead of being given up by the row-cache kernels first
+                    "cm_blocks_given_up": gu1 - gu0, "cm_blocks_routed_to_whole_model": rf1 - rf0}
+                leg("random_MiBps", RESULT["line"]["configs"]["random"]["value"])
+                leg("random_cm_blocks_given_up", gu1 - gu0)
+                leg("random_block_MiB", a.random_block_mib)
+                progress(f"random: {RESULT['line']['configs']['random']['value']} MiB/s")
+
+    with guard("free_most_of_the_batch"):
+        if extras_wanted and a.kind == "text" and nblk > 160 and left_s() > 60.0:
+            live_states = free_most_of_the_batch()
+
+    with guard("mixed"):
+        if extras_wanted and a.kind == "text" and live_states >= 96 and block_size >= (32 << 20) and left_s() > 200.0:
+            # mixed batch: text, binary and incompressible blocks through ONE pair of batch calls
+            mb = 32 << 20
+            per = 32
             g = torch.Generator(device=device)
-            g.manual_seed(2)
-            fpr = []
-            rsel = list(range(nblk - nr, nblk))  # (their text is not needed any more, except blocks 0..cpu_n-1's: those are in shared memory already)
-            for k in rsel:
-                bufs[k][:rb] = torch.randint(0, 256, (rb,), dtype=torch.uint8, generator=g, device=device)
-                fpr.append(fingerprint(torch, bufs[k][:rb]))
-            n_ref = min(nr, a.cpu_threads, os.cpu_count() or 1)
-            if want_cpu:
-                random_host = SharedBlocks("bz3_bench_random", [rb] * n_ref)
-                for j in range(n_ref):
-                    random_host.put_tensor(torch, j, bufs[rsel[j]])
-            gu0, rf0 = int(lib.bz3_hip_cm_blocks_given_up()), int(lib.bz3_hip_cm_blocks_routed_full())
-            te, td, coded = round_trip(rsel, [rb] * nr)
-            gu1, rf1 = int(lib.bz3_hip_cm_blocks_given_up()), int(lib.bz3_hip_cm_blocks_routed_full())
-            assert all(fingerprint(torch, bufs[k][:rb]) == f for k, f in zip(rsel, fpr)), "random: round trip changed the data"
-            RESULT["line"]["configs"]["random"] = {
-                "workload": f"{nr} x {a.random_block_mib:g} MiB uniformly random blocks on one GPU (states of {a.block_mib:g} MiB)",
-                "value": round(nr * rb / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
-                "compressed_ratio": round(nr * rb / sum(coded), 4),
-                # 256 live order-1 rows fit no row cache: since round 5 such blocks go STRAIGHT to the whole-model kernels (encode: by the BWT's histogram,
-                # decode: by a payload that did not shrink), one per CU at a time, instead of being given up by the row-cache kernels first
-                "cm_blocks_given_up": gu1 - gu0, "cm_blocks_routed_to_whole_model": rf1 - rf0}
-            leg("random_MiBps", RESULT["line"]["configs"]["random"]["value"])
-            leg("random_cm_blocks_given_up", gu1 - gu0)
-            leg("random_block_MiB", a.random_block_mib)
-            progress(f"random: {RESULT['line']['configs']['random']['value']} MiB/s")
-
-    if extras_wanted and a.kind == "text" and nblk > 160 and left_s() > 60.0:
-        live_states = free_most_of_the_batch()
-
-    if extras_wanted and a.kind == "text" and live_states >= 96 and block_size >= (32 << 20) and left_s() > 200.0:
-        # mixed batch: text, binary and incompressible blocks through ONE pair of batch calls
-        mb = 32 << 20
-        per = 32
-        g = torch.Generator(device=device)
-        g.manual_seed(7)
-        sel = list(range(64, 64 + 3 * per))  # (blocks 0..63 keep their text for the legs below)
-        for j in range(per):  # the first 32 keep their text; then binary (little-endian words of a random walk); then random
-            k = sel[per + j]
-            walk = torch.cumsum(torch.randint(-3, 4, (mb // 4,), generator=g, device=device, dtype=torch.int32), 0).to(torch.int32)
-            bufs[k][:mb] = walk.view(torch.uint8)
-            bufs[sel[2 * per + j]][:mb] = torch.randint(0, 256, (mb,), dtype=torch.uint8, generator=g, device=device)
-        fpm = [fingerprint(torch, bufs[k][:mb]) for k in sel]
-        if want_cpu and host_mem_available() > 3 * len(sel) * mb:  # the same 96 blocks for the reference (run later, when the host is free again)
-            mixed_host = SharedBlocks("bz3_bench_mixed", [mb] * len(sel))
-            for j, k in enumerate(sel):
-                mixed_host.put_tensor(torch, j, bufs[k])
-        before = int(lib.bz3_hip_cm_blocks_given_up())
-        te, td, coded = round_trip(sel, [mb] * len(sel))
-        assert all(fingerprint(torch, bufs[k][:mb]) == f for k, f in zip(sel, fpm)), "mixed: round trip changed the data"
-        RESULT["line"]["configs"]["mixed"] = {
-            "workload": f"{3 * per} x 32 MiB blocks in one batch on one GPU: {per} text, {per} binary (32-bit words of a random walk), {per} uniformly random",
-            "value": round(len(sel) * mb / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
-            "compressed_ratio": {"text": round(per * mb / sum(coded[:per]), 3), "binary": round(per * mb / sum(coded[per : 2 * per]), 3),
-                                 "random": round(per * mb / sum(coded[2 * per :]), 4)},
-            "cm_blocks_given_up": int(lib.bz3_hip_cm_blocks_given_up()) - before}
-        leg("mixed_MiBps", RESULT["line"]["configs"]["mixed"]["value"])
-        progress(f"mixed: {RESULT['line']['configs']['mixed']['value']} MiB/s, {RESULT['line']['configs']['mixed']['cm_blocks_given_up']} blocks given up by the row-cache kernels")
+            g.manual_seed(7)
+            sel = list(range(64, 64 + 3 * per))  # (blocks 0..63 keep their text for the legs below)
+            for j in range(per):  # the first 32 keep their text; then binary (little-endian words of a random walk); then random
+                k = sel[per + j]
+                walk = torch.cumsum(torch.randint(-3, 4, (mb // 4,), generator=g, device=device, dtype=torch.int32), 0).to(torch.int32)
+                bufs[k][:mb] = walk.view(torch.uint8)
+                bufs[sel[2 * per + j]][:mb] = torch.randint(0, 256, (mb,), dtype=torch.uint8, generator=g, device=device)
+            fpm = [fingerprint(torch, bufs[k][:mb]) for k in sel]
+            if want_cpu and host_mem_available() > 3 * len(sel) * mb:  # the same 96 blocks for the reference (run later, when the host is free again)
+                mixed_host = SharedBlocks("bz3_bench_mixed", [mb] * len(sel))
+                for j, k in enumerate(sel):
+                    mixed_host.put_tensor(torch, j, bufs[k])
+            before = int(lib.bz3_hip_cm_blocks_given_up())
+            te, td, coded = round_trip(sel, [mb] * len(sel))
+            assert all(fingerprint(torch, bufs[k][:mb]) == f for k, f in zip(sel, fpm)), "mixed: round trip changed the data"
+            RESULT["line"]["configs"]["mixed"] = {
+                "workload": f"{3 * per} x 32 MiB blocks in one batch on one GPU: {per} text, {per} binary (32-bit words of a random walk), {per} uniformly random",
+                "value": round(len(sel) * mb / 2 ** 20 / (te + td), 3), "unit": "MiB/s", "t_enc_s": round(te, 2), "t_dec_s": round(td, 2),
+                "compressed_ratio": {"text": round(per * mb / sum(coded[:per]), 3), "binary": round(per * mb / sum(coded[per : 2 * per]), 3),
+                                     "random": round(per * mb / sum(coded[2 * per :]), 4)},
+                "cm_blocks_given_up": int(lib.bz3_hip_cm_blocks_given_up()) - before}
+            leg("mixed_MiBps", RESULT["line"]["configs"]["mixed"]["value"])
+            progress(f"mixed: {RESULT['line']['configs']['mixed']['value']} MiB/s, {RESULT['line']['configs']['mixed']['cm_blocks_given_up']} blocks given up by the row-cache kernels")
 
     # ---- cpu_baseline: started after the timed steps, collected here (the legs above used the GPU only) ----------------
-    if cpu_worker_proc is not None:
-        res = cpu_worker_proc.result()
-        if "rec" in res:
-            rec = res["rec"]
-            ref_choice.update(label=res.get("ref_label") or "gcc -O2", path=res.get("ref_path"))
-            rec["build_probe_1_thread_8MiB_MiBps"] = res.get("probe", {})
-            rec["threads_note"] = ("threads = 64: the reference's CLI caps -j at 64 (src/main.c:213); one thread per block as in bz3_encode_blocks (src/libbz3.c:845-856).  "
-                                   "cores = effective_cpus = min(threads, cpu_quota_cpus): what the container may run at once (cgroup) -- on the round-4 GPU boxes 16 of the 256 "
-                                   "logical CPUs, where 64, 32 and 16 threads give the same rate within 8 % (profiles/r04_cpu_threads_probe.json).  gpu_over_cpu compares with those "
-                                   "effective CPUs, not with an unthrottled -j 64; gpu_equivalent_cpus = GPU MiB/s / (reference MiB/s per effective CPU)")
-            rec["process"] = f"a process of its own (no torch, no HIP runtime), pinned to {res.get('pinned_to_cpus', 0)} cores; started after the timed steps, while the GPU ran legs that use no host cores"
-            rec["gpu_over_cpu"] = round(RESULT["line"]["value"] / rec["value"], 3) if rec.get("value") else None
-            # one MI355X with a GPU-filling batch in flight = this many of the host's CPUs running the reference
-            rec["gpu_equivalent_cpus"] = round(RESULT["line"]["value"] / rec["MiBps_per_cpu"], 1) if rec.get("MiBps_per_cpu") else None
-            leg("gpu_over_cpu_threads", rec["gpu_over_cpu"])
-            leg("gpu_equivalent_cpus", rec["gpu_equivalent_cpus"])
-            if "parity_same" in res:
-                rec["parity"] = f"{res['parity_same']} of {res['parity_of']} blocks of {cpu_block >> 20} MiB: the GPU's coded bytes are identical to the reference's"
-            RESULT["line"]["cpu_baseline"] = rec
-            progress(f"cpu_baseline: {rec['value']} MiB/s on {rec['threads']} threads = {rec['effective_cpus']} effective CPUs ({ref_choice['label']}); {rec.get('parity', '')}")
-            assert res.get("parity_same") == res.get("parity_of"), "GPU output differs from the reference: " + rec.get("parity", "")
-        else:
-            RESULT["line"]["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": "not run: " + res.get("err", "?")}
+    with guard("cpu_baseline"):
+        if cpu_worker_proc is not None:
+            res = cpu_worker_proc.result()
+            if "rec" in res:
+                rec = res["rec"]
+                ref_choice.update(label=res.get("ref_label") or "gcc -O2", path=res.get("ref_path"))
+                rec["build_probe_1_thread_8MiB_MiBps"] = res.get("probe", {})
+                rec["threads_note"] = ("threads = 64: the reference's CLI caps -j at 64 (src/main.c:213); one thread per block as in bz3_encode_blocks (src/libbz3.c:845-856).  "
+                                       "cores = effective_cpus = min(threads, cpu_quota_cpus): what the container may run at once (cgroup) -- on the round-4 GPU boxes 16 of the 256 "
+                                       "logical CPUs, where 64, 32 and 16 threads give the same rate within 8 % (profiles/r04_cpu_threads_probe.json).  gpu_over_cpu compares with those "
+                                       "effective CPUs, not with an unthrottled -j 64; gpu_equivalent_cpus = GPU MiB/s / (reference MiB/s per effective CPU)")
+                rec["process"] = f"a process of its own (no torch, no HIP runtime), pinned to {res.get('pinned_to_cpus', 0)} cores; started after the timed steps, while the GPU ran legs that use no host cores"
+                rec["gpu_over_cpu"] = round(RESULT["line"]["value"] / rec["value"], 3) if rec.get("value") else None
+                # one MI355X with a GPU-filling batch in flight = this many of the host's CPUs running the reference
+                rec["gpu_equivalent_cpus"] = round(RESULT["line"]["value"] / rec["MiBps_per_cpu"], 1) if rec.get("MiBps_per_cpu") else None
+                leg("gpu_over_cpu_threads", rec["gpu_over_cpu"])
+                leg("gpu_equivalent_cpus", rec["gpu_equivalent_cpus"])
+                if "parity_same" in res:
+                    rec["parity"] = f"{res['parity_same']} of {res['parity_of']} blocks of {cpu_block >> 20} MiB: the GPU's coded bytes are identical to the reference's"
+                RESULT["line"]["cpu_baseline"] = rec
+                progress(f"cpu_baseline: {rec['value']} MiB/s on {rec['threads']} threads = {rec['effective_cpus']} effective CPUs ({ref_choice['label']}); {rec.get('parity', '')}")
+                if res.get("parity_same") != res.get("parity_of"):  # NOT swallowed by the guard: the run fails, with the line printed
+                    RESULT["line"]["parity_failed"] = "GPU output differs from the reference: " + rec.get("parity", "")
+                    progress(RESULT["line"]["parity_failed"])
+            else:
+                RESULT["line"]["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": "not run: " + res.get("err", "?")}
 
     def ref_beside(meta, bs):
         """the reference's -j N on the same blocks, in a process of its own while the GPU codes them"""
         return RefWorker(meta, max(bs, 65 * 1024), ref_path=ref_choice["path"], ref_label=ref_choice["label"])
 
-    if random_host is not None and "random" in RESULT["line"]["configs"] and left_s() > 60.0:
-        res = ref_beside(random_host.meta(), int(a.random_block_mib * (1 << 20))).result()
-        rec = RESULT["line"]["configs"]["random"]
-        if "rec" in res:
-            rec["cpu"] = res["rec"]
-            rec["vs_cpu"] = round(rec["value"] / res["rec"]["value"], 3)
-            leg("random_vs_cpu", rec["vs_cpu"])
-            progress(f"random: reference on {res['rec']['threads']} threads: {res['rec']['value']} MiB/s")
-        else:
-            rec["cpu"] = {"value": None, "sample": "failed: " + res.get("err", "?")}
-        random_host.close()
+    with guard("random_cpu"):
+        if random_host is not None and "random" in RESULT["line"]["configs"] and left_s() > 60.0:
+            res = ref_beside(random_host.meta(), int(a.random_block_mib * (1 << 20))).result()
+            rec = RESULT["line"]["configs"]["random"]
+            if "rec" in res:
+                rec["cpu"] = res["rec"]
+                rec["vs_cpu"] = round(rec["value"] / res["rec"]["value"], 3)
+                leg("random_vs_cpu", rec["vs_cpu"])
+                progress(f"random: reference on {res['rec']['threads']} threads: {res['rec']['value']} MiB/s")
+            else:
+                rec["cpu"] = {"value": None, "sample": "failed: " + res.get("err", "?")}
+            random_host.close()
 
-    if mixed_host is not None and "mixed" in RESULT["line"]["configs"] and left_s() > 150.0:
-        res = ref_beside(mixed_host.meta(), 32 << 20).result()
-        rec = RESULT["line"]["configs"]["mixed"]
-        if "rec" in res:
-            rec["cpu"] = res["rec"]
-            rec["vs_cpu"] = round(rec["value"] / res["rec"]["value"], 3)
-            leg("mixed_vs_cpu", rec["vs_cpu"])
-            progress(f"mixed: reference on {res['rec']['threads']} threads: {res['rec']['value']} MiB/s")
-        else:
-            rec["cpu"] = {"value": None, "sample": "failed: " + res.get("err", "?")}
-    if mixed_host is not None:
-        mixed_host.close()
-        mixed_host = None
+    with guard("mixed_cpu"):
+        if mixed_host is not None and "mixed" in RESULT["line"]["configs"] and left_s() > 150.0:
+            res = ref_beside(mixed_host.meta(), 32 << 20).result()
+            rec = RESULT["line"]["configs"]["mixed"]
+            if "rec" in res:
+                rec["cpu"] = res["rec"]
+                rec["vs_cpu"] = round(rec["value"] / res["rec"]["value"], 3)
+                leg("mixed_vs_cpu", rec["vs_cpu"])
+                progress(f"mixed: reference on {res['rec']['threads']} threads: {res['rec']['value']} MiB/s")
+            else:
+                rec["cpu"] = {"value": None, "sample": "failed: " + res.get("err", "?")}
+        if mixed_host is not None:
+            mixed_host.close()
+            mixed_host = None
 
     if extras_wanted and a.kind == "text" and left_s() > 200.0:
         # (after the reference process has finished: the stage hooks wait for the stream between launches, and a host whose CPU quota 64
@@ -1155,55 +1303,59 @@ def main():
                 rec[f"cpu_j{nb}"] = {"value": None, "sample": "failed: " + res.get("err", "?")}
 
     n3 = (a.cfg3_bytes + block_size - 1) // block_size  # blocks of the cfg3 leg: full blocks + one partial
-    if extras_wanted and a.kind == "text" and nblk >= n3:
-        # cfg3 (BASELINE.json configs[2]): 1,000,000,000 B at -b 256 = 3 full blocks + 194,693,632 B, on one GPU
-        cm_s = (stage["enc"]["cm"] + stage["dec"]["cm"]) * 1e-3
-        est = cm_s * (1.0 if per_cu == 1 else 0.7) + 15.0
-        if left_s() > est:
-            progress(f"cfg3: {n3} blocks (estimated {est:.0f}s)")
-            is_cfg3 = a.cfg3_bytes == CFG3_BYTES and block_size == 256 << 20
-            small_config("cfg3", a.cfg3_bytes, block_size, "BASELINE.json configs[2] stand-in" if is_cfg3 else "(not BASELINE's size)")
-        else:
-            RESULT["line"]["configs"]["cfg3"] = {"skipped": f"needs ~{est:.0f}s, {left_s():.0f}s of the budget left"}
-    if extras_wanted and a.kind == "text" and block_size >= (32 << 20) and nblk >= 3:
-        # cfg2 (BASELINE.json configs[1]): 100,000,000 B at -b 32 = 2 full blocks + 32,891,136 B
-        if left_s() > 60.0:
-            small_config("cfg2", 100_000_000, 32 << 20, "BASELINE.json configs[1] stand-in")
-        else:
-            RESULT["line"]["configs"]["cfg2"] = {"skipped": f"{left_s():.0f}s of the budget left"}
+    with guard("cfg3"):
+        if extras_wanted and a.kind == "text" and nblk >= n3:
+            # cfg3 (BASELINE.json configs[2]): 1,000,000,000 B at -b 256 = 3 full blocks + 194,693,632 B, on one GPU
+            cm_s = (stage["enc"]["cm"] + stage["dec"]["cm"]) * 1e-3
+            est = cm_s * (1.0 if per_cu == 1 else 0.7) + 15.0
+            if left_s() > est:
+                progress(f"cfg3: {n3} blocks (estimated {est:.0f}s)")
+                is_cfg3 = a.cfg3_bytes == CFG3_BYTES and block_size == 256 << 20
+                small_config("cfg3", a.cfg3_bytes, block_size, "BASELINE.json configs[2] stand-in" if is_cfg3 else "(not BASELINE's size)")
+            else:
+                RESULT["line"]["configs"]["cfg3"] = {"skipped": f"needs ~{est:.0f}s, {left_s():.0f}s of the budget left"}
+
+    with guard("cfg2"):
+        if extras_wanted and a.kind == "text" and block_size >= (32 << 20) and nblk >= 3:
+            # cfg2 (BASELINE.json configs[1]): 100,000,000 B at -b 32 = 2 full blocks + 32,891,136 B
+            if left_s() > 60.0:
+                small_config("cfg2", 100_000_000, 32 << 20, "BASELINE.json configs[1] stand-in")
+            else:
+                RESULT["line"]["configs"]["cfg2"] = {"skipped": f"{left_s():.0f}s of the budget left"}
 
     hb = int(a.host_api_block_mib * (1 << 20))
-    if extras_wanted and a.kind == "text" and hb > 0 and hb <= block_size and live_states >= 8:
-        # ---- host_api: SURVEY.md 8d's timing boundary -- bz3_encode_blocks / bz3_decode_blocks on malloc'ed HOST buffers (H2D / D2H inside the
-        # timed calls) against the same batch device-resident.  Blocks of hb bytes, one per state still alive.
-        nh = live_states
-        est = 2.2 * (stage["enc"]["cm"] + stage["dec"]["cm"]) * 1e-3 * hb / block_size * (1.0 if nh > 2 * cus else 0.8) + 30.0
-        if left_s() > est and host_mem_available() > nh * (hb + hb // 40 + 8192) * 1.3:
-            progress(f"host_api: {nh} x {a.host_api_block_mib:g} MiB through host buffers (estimated {est:.0f}s)")
-            sel = list(range(nh))
-            hcap = lib.bz3_bound(hb) + 64
-            fph = [fingerprint(torch, bufs[k][:hb]) for k in sel]
-            te_d, td_d, coded_d = round_trip(sel, [hb] * nh)
-            host = [(C.c_uint8 * hcap)() for _ in sel]
-            for k in sel:
-                torch.frombuffer(host[k], dtype=torch.uint8, count=hb).copy_(bufs[k][:hb])
-            cap_saved = cap
-            cap = hcap  # (round_trip passes `cap` as the buffer size of the decode call)
-            te_h, td_h, coded_h = round_trip(sel, [hb] * nh, host=host)
-            cap = cap_saved
-            ok = coded_h == coded_d and all(fingerprint(torch, torch.frombuffer(host[k], dtype=torch.uint8, count=hb).to(device)) == fph[k] for k in sel[:8])
-            assert ok, "host_api: the host-buffer round trip differs from the device-resident one"
-            RESULT["line"]["configs"]["host_api"] = {
-                "workload": f"{nh} x {a.host_api_block_mib:g} MiB text blocks through bz3_encode_blocks + bz3_decode_blocks on malloc'ed host buffers (H2D / D2H inside the timed calls: "
-                            f"SURVEY.md 8d's boundary, include/libbz3.h:206-213), and the same batch device-resident",
-                "value": round(nh * hb / 2 ** 20 / (te_h + td_h), 3), "unit": "MiB/s", "t_enc_s": round(te_h, 2), "t_dec_s": round(td_h, 2),
-                "device_resident": {"value": round(nh * hb / 2 ** 20 / (te_d + td_d), 3), "t_enc_s": round(te_d, 2), "t_dec_s": round(td_d, 2)},
-                "pcie_inclusive_over_device_resident": round((te_d + td_d) / (te_h + td_h), 4)}
-            leg("host_api_ratio", RESULT["line"]["configs"]["host_api"]["pcie_inclusive_over_device_resident"])
-            progress(f"host_api: {RESULT['line']['configs']['host_api']['value']} MiB/s through host buffers, x{RESULT['line']['configs']['host_api']['pcie_inclusive_over_device_resident']} of device-resident")
-            del host
-        else:
-            RESULT["line"]["configs"]["host_api"] = {"skipped": f"needs ~{est:.0f}s, {left_s():.0f}s of the budget left"}
+    with guard("host_api"):
+        if extras_wanted and a.kind == "text" and hb > 0 and hb <= block_size and live_states >= 8:
+            # ---- host_api: SURVEY.md 8d's timing boundary -- bz3_encode_blocks / bz3_decode_blocks on malloc'ed HOST buffers (H2D / D2H inside the
+            # timed calls) against the same batch device-resident.  Blocks of hb bytes, one per state still alive.
+            nh = live_states
+            est = 2.2 * (stage["enc"]["cm"] + stage["dec"]["cm"]) * 1e-3 * hb / block_size * (1.0 if nh > 2 * cus else 0.8) + 30.0
+            if left_s() > est and host_mem_available() > nh * (hb + hb // 40 + 8192) * 1.3:
+                progress(f"host_api: {nh} x {a.host_api_block_mib:g} MiB through host buffers (estimated {est:.0f}s)")
+                sel = list(range(nh))
+                hcap = lib.bz3_bound(hb) + 64
+                fph = [fingerprint(torch, bufs[k][:hb]) for k in sel]
+                te_d, td_d, coded_d = round_trip(sel, [hb] * nh)
+                host = [(C.c_uint8 * hcap)() for _ in sel]
+                for k in sel:
+                    torch.frombuffer(host[k], dtype=torch.uint8, count=hb).copy_(bufs[k][:hb])
+                cap_saved = cap
+                cap = hcap  # (round_trip passes `cap` as the buffer size of the decode call)
+                te_h, td_h, coded_h = round_trip(sel, [hb] * nh, host=host)
+                cap = cap_saved
+                ok = coded_h == coded_d and all(fingerprint(torch, torch.frombuffer(host[k], dtype=torch.uint8, count=hb).to(device)) == fph[k] for k in sel[:8])
+                assert ok, "host_api: the host-buffer round trip differs from the device-resident one"
+                RESULT["line"]["configs"]["host_api"] = {
+                    "workload": f"{nh} x {a.host_api_block_mib:g} MiB text blocks through bz3_encode_blocks + bz3_decode_blocks on malloc'ed host buffers (H2D / D2H inside the timed calls: "
+                                f"SURVEY.md 8d's boundary, include/libbz3.h:206-213), and the same batch device-resident",
+                    "value": round(nh * hb / 2 ** 20 / (te_h + td_h), 3), "unit": "MiB/s", "t_enc_s": round(te_h, 2), "t_dec_s": round(td_h, 2),
+                    "device_resident": {"value": round(nh * hb / 2 ** 20 / (te_d + td_d), 3), "t_enc_s": round(te_d, 2), "t_dec_s": round(td_d, 2)},
+                    "pcie_inclusive_over_device_resident": round((te_d + td_d) / (te_h + td_h), 4)}
+                leg("host_api_ratio", RESULT["line"]["configs"]["host_api"]["pcie_inclusive_over_device_resident"])
+                progress(f"host_api: {RESULT['line']['configs']['host_api']['value']} MiB/s through host buffers, x{RESULT['line']['configs']['host_api']['pcie_inclusive_over_device_resident']} of device-resident")
+                del host
+            else:
+                RESULT["line"]["configs"]["host_api"] = {"skipped": f"needs ~{est:.0f}s, {left_s():.0f}s of the budget left"}
 
     if rank == 0:
         emit_line(final=True)

@@ -58,6 +58,14 @@ def _declare(L, strict=True):
         "bz3_hip_set_lean_states": (C.c_int, [C.c_int]),
         "bz3_hip_release_cached_memory": (None, []),
         "bz3_hip_set_keep_workspace": (C.c_int, [C.c_int]),
+        "bz3_hip_set_workspace_headroom": (None, [C.c_longlong]),
+        "bz3_hip_workspace_headroom": (sz, []),
+        "bz3_hip_debug_headroom_events": (C.c_uint, [C.c_int, C.POINTER(C.c_uint)]),
+        "bz3_hip_debug_ring_contexts": (sz, [sz, sz, sz, sz, sz, sz, C.c_int, sz]),
+        "bz3_hip_debug_arena_slack": (sz, [sz]),
+        "bz3_hip_debug_cm_launches": (C.c_uint, [C.c_int]),
+        "bz3_hip_debug_workspace_bytes": (sz, [sz, C.c_int]),
+        "bz3_hip_debug_cached_bytes": (sz, [C.c_int]),
         "bz3_hip_encode_block_device": (i32, [vp, vp, i32]),
         "bz3_hip_decode_block_device": (i32, [vp, vp, sz, i32, i32]),
         "bz3_hip_encode_blocks_device": (None, [vp, vp, vp, i32]),

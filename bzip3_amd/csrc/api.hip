@@ -210,12 +210,18 @@ struct DeviceCtx {
         return b;
     }
 
+    // What arena_for allocates beyond the request (alignment losses of the takes, a somewhat larger next call): a sixteenth, but never more than
+    // 512 MiB -- round 5's unbounded sixteenth was 5 GB of an 80 GB ring that nobody used and the host program could not have.
+    static size_t arena_slack(size_t bytes) {
+        const size_t s16 = bytes >> 4, cap = (size_t)512 << 20;
+        return (s16 < cap ? s16 : cap) + ((size_t)1 << 20);
+    }
     Arena arena_for(size_t bytes) {  // caller holds mu
         if (bytes > ws_cap) {
             if (ws) HIP_CHECK(hipFree(ws));
             ws = nullptr;
             ws_cap = 0;
-            size_t want = bytes + (bytes >> 4) + (1u << 20);
+            size_t want = bytes + arena_slack(bytes);
             HIP_CHECK(hipMalloc((void **)&ws, want));
             ws_cap = want;
         }
@@ -236,19 +242,25 @@ std::atomic<int> g_lean{-1};  // -1 = not read from the environment yet; see bz3
 std::atomic<int> g_front_end_ring{0};  // window | slots << 16 of the last encode_group (bz3_hip_debug_front_end_ring)
 std::atomic<int> g_arena_swaps{0};  // swap buffers served from the arena (bz3_hip_debug_arena_swap_buffers)
 std::atomic<unsigned> g_cm_given_up{0};  // blocks the row-cache CM kernels handed back to the full-model kernels (statistics)
+std::atomic<unsigned> g_cm_launches{0};  // CM kernel launches (statistics, bz3_hip_debug_cm_launches)
 std::atomic<unsigned> g_cm_routed_full{0};  // blocks sent straight to the full-model kernels by their histogram / payload size (statistics)
+
+#ifndef BZ3_EMU
+// The rings run a group's whole-GPU kernels on one stream and the serial one-workgroup-per-block kernels (LZP drivers / decoders) of up to four windows on
+// side streams.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue do not
+// overlap: with five streams on four queues the tail of 256 x 64 MiB blocks measured 3.23 s, with more queues 3.08 s (profiles/r05_tail_hw_queues.txt).
+// The library asks for 8 ONCE, when it is loaded (before any thread of the host program can be reading the environment through it), never overrides the
+// user's setting, and BZ3_HIP_SET_HW_QUEUES=0 turns even that off.  It only has an effect if the runtime is not up yet: a host program that initialises HIP
+// first (bench.py through torch) sets the variable itself -- INTEGRATION.md lists it as a requirement on the host.
+__attribute__((constructor)) static void bz3_hip_on_load() {
+    const char * e = getenv("BZ3_HIP_SET_HW_QUEUES");
+    if (!e || atoi(e) != 0) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+#endif
 
 int device_count() {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_device_count < 0) {
-#ifndef BZ3_EMU
-        // The rings run a group's whole-GPU kernels on one stream and the serial one-workgroup-per-block kernels (LZP drivers / decoders) of up to
-        // four windows on side streams.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and
-        // streams that share a queue do not overlap: with five streams on four queues the tail of 256 x 64 MiB blocks measured 3.23 s, with 16
-        // queues 3.08 s (profiles/r05_tail_hw_queues.txt).  Only effective if the runtime has not been initialised yet (a host program that
-        // initialises HIP first -- bench.py through torch -- sets the variable itself); never overrides the user's setting.
-        (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
-#endif
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
         g_device_count = n;
@@ -360,7 +372,9 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
                   const std::vector<char> * to_full = nullptr) {
     if (jobs.empty()) return 0.f;
     std::vector<Job> direct;  // straight to the whole-model kernel
-    if (to_full && cm_mode() < 0) {
+    // Routing only pays when the WHOLE batch would take a row-cache variant: a batch that fits one block per CU is whole-model work anyway, and splitting it
+    // would run two serial launches, each as long as its slowest block, where one does.
+    if (to_full && cm_mode() < 0 && cm_variant_has_rows(cm_variant_for(ctx, jobs.size(), std::is_same<Job, CmEncodeJob>::value))) {
         std::vector<Job> keep;
         for (size_t i = 0; i < jobs.size(); i++) ((*to_full)[i] ? direct : keep).push_back(jobs[i]);
         if (!direct.empty()) {
@@ -372,6 +386,7 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
         float ms0 = 0.f;
         HIP_CHECK(hipMemcpyAsync(d_jobs, direct.data(), sizeof(Job) * direct.size(), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipEventRecord(ev0, s));
+        g_cm_launches.fetch_add(1);
         go(d_jobs, (u32)direct.size(), s, (int)CM_VARIANT_FULL);
         HIP_CHECK(hipEventRecord(ev1, s));
         HIP_CHECK(hipStreamSynchronize(s));
@@ -405,6 +420,7 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
     float ms = 0.f, ms2 = 0.f;
     HIP_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipEventRecord(ev0, s));
+    g_cm_launches.fetch_add(1);
     go(d_jobs, (u32)jobs.size(), s, variant);
     HIP_CHECK(hipEventRecord(ev1, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -422,6 +438,7 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
         if (!again.empty()) {
             HIP_CHECK(hipMemcpyAsync(d_jobs, again.data(), sizeof(Job) * again.size(), hipMemcpyHostToDevice, s));
             HIP_CHECK(hipEventRecord(ev0, s));
+            g_cm_launches.fetch_add(1);
             go(d_jobs, (u32)again.size(), s, (int)CM_VARIANT_FULL);  // whole model in LDS: nothing to give up
             HIP_CHECK(hipEventRecord(ev1, s));
             HIP_CHECK(hipStreamSynchronize(s));
@@ -431,6 +448,7 @@ float run_cm_jobs(const DeviceCtx * ctx, Arena & arena, std::vector<Job> & jobs,
     if (!direct.empty()) {  // (the variant had no row cache: nothing was handed back, the routed blocks still wait)
         HIP_CHECK(hipMemcpyAsync(d_jobs, direct.data(), sizeof(Job) * direct.size(), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipEventRecord(ev0, s));
+        g_cm_launches.fetch_add(1);
         go(d_jobs, (u32)direct.size(), s, (int)CM_VARIANT_FULL);
         HIP_CHECK(hipEventRecord(ev1, s));
         HIP_CHECK(hipStreamSynchronize(s));
@@ -560,6 +578,41 @@ inline bool sizes_fit(size_t buffer_size, s32 lzp_size, s32 rle_size, s32 orig_s
     const size_t a = lzp_size < 0 ? 0 : (size_t)lzp_size, b = rle_size < 0 ? 0 : (size_t)rle_size, c = orig_size < 0 ? 0 : (size_t)orig_size;
     return a <= buffer_size && b <= buffer_size && c <= buffer_size;
 }
+
+// ---- headroom: the device memory the library leaves to the host program -------------------------------------------------------------------------
+// The library keeps memory between calls (the workspace arena, idle pooled swap buffers; with keep-workspace a GPU-filling batch's whole ring).  The caller
+// owns its memory, so there is a rule about how much the library may sit on: when a batch call returns, at least `headroom` bytes of the
+// device are free (hipMemGetInfo), or the library holds nothing cached at all.  Two halves: (1) the rings are SIZED for it -- the encoder's ring of LZP
+// contexts takes the free memory minus headroom minus what the arena adds on top (ring_contexts_for); (2) it is ENFORCED when a group returns
+// (enforce_headroom): idle pooled swap buffers go back to the driver first, the workspace second.  bz3_hip_set_workspace_headroom / environment
+// BZ3_HIP_WS_HEADROOM_MB; default 4 GiB.  Round 5 had a fixed 6 GiB margin that the arena's own slack consumed: bench.py's next 48 MiB allocation failed.
+std::atomic<long long> g_ws_headroom{-1};  // bytes; -1 = the environment decides
+inline size_t ws_headroom() {
+    static const long long env = [] {
+        const char * e = getenv("BZ3_HIP_WS_HEADROOM_MB");
+        return e && *e ? (long long)strtoull(e, nullptr, 10) << 20 : (long long)4 << 30;
+    }();
+    const long long v = g_ws_headroom.load();
+    return (size_t)(v < 0 ? env : v);
+}
+// LZP contexts the encoder's ring may hold.  free_b: free device memory now; have: the arena the context already owns (reused); need: per-block scratch of the
+// stages; fixed: the batch's job arrays, side buffers and CM scratch in the arena; ctx_bytes: one LZP context; cap: one borrowed swap buffer (lean states: a block
+// in the ring holds exactly one context and one swap buffer; others own their swap buffers, and 7/10 of what is free is the estimate of rounds 1-4).
+inline size_t ring_contexts_for(size_t free_b, size_t have, size_t need, size_t fixed, size_t ctx_bytes, size_t cap, bool lean, size_t headroom) {
+    const size_t total = free_b + have;
+    const size_t base = need + fixed;
+    if (total <= base || !ctx_bytes) return 0;
+    size_t by_share = (total - base) / 10 * 7 / ctx_bytes;
+    // what is left once the headroom, the arena's slack and the takes' alignment are set aside
+    const size_t aside = headroom + ((size_t)513 << 20) + ((size_t)64 << 20);
+    const size_t room = total > base + aside ? total - base - aside : 0;
+    if (!lean) {
+        const size_t by_room = room / ctx_bytes;
+        return by_share < by_room ? by_share : by_room;
+    }
+    return room / (ctx_bytes + cap);
+}
+void enforce_headroom(DeviceCtx * ctx, hipStream_t s);
 
 // Lean states own no swap buffer: they borrow one from the device's pool while a stage sequence needs it.
 // BZ3_HIP_KEEP_WS=1 (experiment, round 5's first measurement): a lean batch's workspace survives the call -- the decode call that follows reuses the
@@ -734,6 +787,27 @@ void encode_finish(bz3_state * st, float cm_ms) {
     st->result = total;
 }
 
+std::atomic<unsigned> g_headroom_trims{0}, g_headroom_releases{0};  // statistics (bz3_hip_debug_headroom_events)
+// Second half of the headroom rule (see ws_headroom): called with the context's mutex held when a group's call ends.
+void enforce_headroom(DeviceCtx * ctx, hipStream_t s) {
+    const size_t h = ws_headroom();
+    size_t free_b = 0, total_b = 0;
+    if (!h || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b >= h) return;
+    if (ctx->temp_idle_bytes() > 0) {
+        ctx->temp_trim();
+        g_headroom_trims.fetch_add(1);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b >= h) return;
+    }
+    if (ctx->ws) {
+        (void)hipStreamSynchronize(s);
+        (void)hipDeviceSynchronize();  // side streams included
+        (void)hipFree(ctx->ws);
+        ctx->ws = nullptr;
+        ctx->ws_cap = 0;
+        g_headroom_releases.fetch_add(1);
+    }
+}
+
 // Shape of the encoder's front-end pipeline: `contexts` LZP contexts fit into the memory budget, the batch has n blocks.
 // ns context slots (2..DeviceCtx::RING_SLOTS; up to DeviceCtx::AUX when forced) of `window` blocks each.  A window's drivers hide behind the whole-GPU work of ns-1 other
 // windows, so the drivers' share of the pace is T_driver / ((ns-1) * window) per block: more slots of fewer blocks get more out
@@ -792,7 +866,9 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     // contexts = what fits into 7/10 of the memory that is free right now beside the sorter's workspace (the rest: the blocks' borrowed
     // swap buffers, allocator slack).  A workspace that grew far beyond the sorter's needs for this is handed back when the call
     // ends (below): the decode call that follows needs the room for staged payloads and the swap buffers of its tail windows.
-    size_t budget = (size_t)32 << 30;
+    const size_t headroom = ws_headroom();
+    const size_t fixed = (size_t)n * (sizeof(CmEncodeJob) + CM_SIDE_BYTES + 256) + cm_scratch_bytes((size_t)n) + 65536 + (size_t)DeviceCtx::AUX * 8 * (sizeof(LzpDriverJob) + 256);
+    size_t contexts = ((size_t)32 << 30) / ctx_bytes;
     {
         // Swap buffers the previous call left idle in the pool (a decode call's tail ring holds up to 4 x 16 of them, 17 GB at 256 MiB)
         // are memory this call's ring of LZP contexts cannot use: round 4's full-size run had a ring of 4 x 4 contexts and an encode
@@ -800,27 +876,15 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         // Round 5: only when that memory is MISSING -- an ordinary lean batch whose ring gets its full shape beside the pool keeps the
         // buffers it is about to borrow again (a free + malloc cycle per buffer and call otherwise, 30-45 ms per GiB).
         size_t free_b = 0, total_b = 0;
+        const s32 full = DeviceCtx::RING_SLOTS * 8;  // 4 slots x 8 blocks: what pipeline_shape grants at most
         if (lead->lean && lead->ctx->temp_idle_bytes() > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t full_ring = (size_t)DeviceCtx::RING_SLOTS * 8u * (ctx_bytes + lead->cap);  // 4 slots x 8 blocks: what pipeline_shape grants at most
-            const size_t wanted = (size_t)(n < DeviceCtx::RING_SLOTS * 8 ? n : DeviceCtx::RING_SLOTS * 8) * (ctx_bytes + lead->cap);
-            const size_t have0 = lead->ctx->ws_cap;
-            if (free_b + have0 < need + ((size_t)6 << 30) + (wanted < full_ring ? wanted : full_ring)) lead->ctx->temp_trim();
+            if (ring_contexts_for(free_b, lead->ctx->ws_cap, need, fixed, ctx_bytes, lead->cap, true, headroom) < (size_t)(n < full ? n : full)) lead->ctx->temp_trim();
         }
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t have = lead->ctx->ws_cap;  // the arena already holds this much
-            budget = (free_b + have > need) ? (free_b + have - need) / 10 * 7 : 0;
-            if (lead->lean) {
-                // lean states: what a block in the ring holds is known exactly -- its LZP context and one borrowed swap buffer -- so the ring may take
-                // all but a fixed margin (round 4: 7/10 of the free memory gave 17 contexts, a ring of 4 x 4, where 21 fit: 4 x 5)
-                const size_t margin = (size_t)6 << 30;
-                const size_t avail = free_b + have > need + margin ? free_b + have - need - margin : 0;
-                const size_t exact = avail / (ctx_bytes + lead->cap) * ctx_bytes;
-                if (exact > budget) budget = exact;
-            }
-        }
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            contexts = ring_contexts_for(free_b, lead->ctx->ws_cap, need, fixed, ctx_bytes, lead->cap, lead->lean, headroom);
     }
     s32 window = 1, ns = 2;
-    pipeline_shape((s32)(budget / ctx_bytes < 1024 ? budget / ctx_bytes : 1024), n, window, ns);
+    pipeline_shape((s32)(contexts < 1024 ? contexts : 1024), n, window, ns);
     lead->ctx->ensure_aux();
     hipStream_t s = lead->stream;
     DrainOnUnwind drain{s, lead->ctx->aux, DeviceCtx::AUX};
@@ -953,6 +1017,7 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         lead->ctx->ws_cap = 0;
         g_front_end_ring.fetch_or(1 << 30);
     }
+    enforce_headroom(lead->ctx, lead->stream);
 }
 
 // ======================================================================================================
@@ -1138,7 +1203,8 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
         size_t free_b = 0, total_b = 0;
         if (any_lean && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t have = lead->ctx->ws_cap;
-            const size_t room = free_b + have > need ? free_b + have - need : 0;
+            const size_t aside = need + ws_headroom() + ((size_t)577 << 20);  // (+ the arena's slack: see ring_contexts_for)
+            const size_t room = free_b + have > aside ? free_b + have - aside : 0;
             stage_budget = room - room / 4;  // leave a quarter for the swap buffers of the tail windows
         }
     }
@@ -1255,7 +1321,10 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     // The tail's whole-GPU kernels keep off the CUs the side streams' LZP decoders sit on (DeviceCtx::rest), when the device is partitioned
     hipStream_t s_cm = s;
     hipStream_t * side_streams = lead->ctx->aux;
-    if (lead->ctx->rest && (size_t)n > 1 && tail_slots <= DeviceCtx::RING_SLOTS) {
+    // Only in the regime it was measured in (profiles/r05_call{6,7,8}_*: 256-768 blocks): a small batch has at most 32 short LZP decoders, and its inverse
+    // BWT, mRLE and CRC kernels would give up 19 % of the device and gain a synchronisation for them.  BZ3_HIP_CU_PARTITION_MIN_BLOCKS (read once; tests: 2).
+    static const s32 part_min = [] { const char * e = getenv("BZ3_HIP_CU_PARTITION_MIN_BLOCKS"); return e && atoi(e) > 0 ? (s32)atoi(e) : (s32)128; }();
+    if (lead->ctx->rest && n >= part_min && tail_slots <= DeviceCtx::RING_SLOTS) {
         side_streams = lead->ctx->aux_m;
         HIP_CHECK(hipStreamSynchronize(s));  // headers, stored blocks' CRCs and the CM launches ran on the group's stream
         s = lead->ctx->rest;
@@ -1354,6 +1423,8 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
         fprintf(stderr, "[bz3 rings] decode tail: %d blocks, %d windows of %d x %d slots: %.1f ms = inverse BWTs + LZP launches %.1f + waiting for a window's LZP decoders %.1f + mRLE / CRC / hand-back %.1f\n",
                 (int)n, (int)nwin, (int)tail_window, (int)tail_slots, now_ms() - tr_t0, tr_unbwt, tr_wait, tr_finish - tr_wait);
     for (s32 i = 0; i < n; i++) sts[i]->pending = bz3_state::NONE;
+    if (s != s_cm) (void)hipStreamSynchronize(s);  // (the tail ran on the masked stream; decode_finish has waited for every block already)
+    enforce_headroom(lead->ctx, s_cm);
 }
 
 void on_failure(bz3_state * st) {
@@ -1720,6 +1791,32 @@ void collect(int kind, SingleReq & r) {
 }  // namespace
 
 BZIP3_API unsigned bz3_hip_cm_blocks_routed_full(void) { return g_cm_routed_full.load(); }
+BZIP3_API void bz3_hip_set_workspace_headroom(long long bytes) { g_ws_headroom.store(bytes < 0 ? -1 : bytes); }
+BZIP3_API size_t bz3_hip_workspace_headroom(void) { return ws_headroom(); }
+BZIP3_API unsigned bz3_hip_debug_headroom_events(int reset, unsigned * releases) {
+    const unsigned t = reset ? g_headroom_trims.exchange(0) : g_headroom_trims.load();
+    const unsigned r = reset ? g_headroom_releases.exchange(0) : g_headroom_releases.load();
+    if (releases) *releases = r;
+    return t;
+}
+BZIP3_API size_t bz3_hip_debug_ring_contexts(size_t free_b, size_t have, size_t need, size_t fixed, size_t ctx_bytes, size_t cap, int lean, size_t headroom) {
+    return ring_contexts_for(free_b, have, need, fixed, ctx_bytes, cap, lean != 0, headroom);
+}
+BZIP3_API size_t bz3_hip_debug_workspace_bytes(size_t block_bytes, int which) {  // 0: per-block scratch of the stages, 1: one LZP context of the encoder's ring
+    return which == 0 ? workspace_bytes_for((u64)block_bytes + 64) : lzp_encode_ctx_bytes((u64)block_bytes + 64) + 65536;
+}
+BZIP3_API unsigned bz3_hip_debug_cm_launches(int reset) { return reset ? g_cm_launches.exchange(0) : g_cm_launches.load(); }
+BZIP3_API size_t bz3_hip_debug_arena_slack(size_t bytes) { return DeviceCtx::arena_slack(bytes); }
+BZIP3_API size_t bz3_hip_debug_cached_bytes(int device) {  // workspace + idle pooled swap buffers the library holds on `device` right now
+    DeviceCtx * c = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (device >= 0 && (size_t)device < g_ctx.size()) c = g_ctx[(size_t)device];
+    }
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return c->ws_cap + c->temp_idle_bytes();
+}
 BZIP3_API int bz3_hip_set_keep_workspace(int on) {
     g_keep_ws.store(on < 0 ? -1 : (on ? 1 : 0));
     return 0;

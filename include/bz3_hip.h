@@ -42,8 +42,10 @@ BZIP3_API int bz3_hip_set_cm_mode(int mode);
  * takes them (0 = none: straight to the deep path; k < 0 = the default, 1).  Output bytes do not depend on it. */
 BZIP3_API void bz3_hip_debug_bwt_big_rounds(int k);
 /* Number of blocks the row-cache kernels have handed back to the full-model kernels so far (statistics). */
-BZIP3_API unsigned bz3_hip_cm_blocks_routed_full(void); /* statistics: blocks of GPU-filling batches sent straight to the whole-model CM kernels (many live byte values / a payload that hardly shrank) */
 BZIP3_API unsigned bz3_hip_cm_blocks_given_up(void);
+/* Number of blocks sent STRAIGHT to the whole-model CM kernels so far (statistics): blocks of batches that take a row-cache variant (more blocks than
+ * CUs) with many live byte values (encode) or a payload that hardly shrank (decode).  A batch of at most one block per CU is never split. */
+BZIP3_API unsigned bz3_hip_cm_blocks_routed_full(void);
 
 /* The CM kernel variant (0..8, 12 as above) a batch of `blocks` blocks on `device` is coded (encode != 0) or decoded with under the
  * current mode; -1 for an invalid device. */
@@ -60,8 +62,24 @@ BZIP3_API int bz3_hip_debug_front_end_ring(void);
 /* Keep-workspace mode for lean states (same as BZ3_HIP_KEEP_WS=1 in the environment, but switchable: 1 on, 0 off, -1 back to the environment):
  * a GPU-filling lean batch's workspace survives the call, the decode call that follows reuses it and carves the swap buffers of its tail windows
  * from it -- instead of a hipFree and two multi-GB hipMallocs per round trip (30-45 ms per GiB).  The memory stays with the library until
- * bz3_hip_release_cached_memory().  bench.py turns it on for its timed steps. */
+ * bz3_hip_release_cached_memory(), within the headroom rule below.  bench.py turns it on for its timed steps. */
 BZIP3_API int bz3_hip_set_keep_workspace(int on);
+/* Headroom: the device memory the library leaves to the host program (the caller owns its memory; the library's workspace, its pool of swap buffers and --
+ * with keep-workspace -- a GPU-filling batch's whole ring are caches).  Rule: when a batch call returns, at least `bytes` of the device are free
+ * (hipMemGetInfo), or the library holds nothing cached on that device.  The rings are sized for it and the rule is enforced when a call ends (idle pooled swap
+ * buffers go back to the driver first, the workspace second).  Default 4 GiB; environment BZ3_HIP_WS_HEADROOM_MB; bytes < 0 = back to the environment;
+ * 0 = no rule (the library may keep whatever it grew to). */
+BZIP3_API void bz3_hip_set_workspace_headroom(long long bytes);
+BZIP3_API size_t bz3_hip_workspace_headroom(void);
+/* Statistics: how often the rule had to be enforced since the last reset -- returns the pool trims, *releases receives the workspace releases. */
+BZIP3_API unsigned bz3_hip_debug_headroom_events(int reset, unsigned * releases);
+/* tests only: LZP contexts the encoder's front-end ring may hold (api.hip ring_contexts_for), the arena's slack beyond a request, and the bytes the
+ * library holds cached on `device` right now (workspace + idle pooled swap buffers). */
+BZIP3_API size_t bz3_hip_debug_ring_contexts(size_t free_bytes, size_t have, size_t need, size_t fixed, size_t ctx_bytes, size_t cap, int lean, size_t headroom);
+BZIP3_API size_t bz3_hip_debug_arena_slack(size_t bytes);
+BZIP3_API unsigned bz3_hip_debug_cm_launches(int reset); /* statistics: CM kernel launches of the batch paths since the last reset */
+BZIP3_API size_t bz3_hip_debug_workspace_bytes(size_t block_bytes, int which); /* 0: per-block scratch of the stages, 1: one LZP context of the encoder's ring */
+BZIP3_API size_t bz3_hip_debug_cached_bytes(int device);
 /* Statistics of the keep-workspace experiment (environment BZ3_HIP_KEEP_WS=1: a lean batch's workspace survives the call and the decoder's tail carves
  * its swap buffers from it): swap buffers served from the arena instead of the pool since the last reset. */
 BZIP3_API int bz3_hip_debug_arena_swap_buffers(int reset);

@@ -142,3 +142,40 @@ def test_cu_partition_masks_are_disjoint_and_balanced(lib):
         assert all(sum(1 for i in s_bits if i // 32 == a) == per for a in range(blocks))          # dealt in blocks of 32
         if blocks == 8:
             assert all(sum(1 for i in s_bits if i % 8 == x) == per for x in range(8))              # dealt round robin
+
+
+def test_headroom_rule_sizing_arithmetic(lib):
+    """VERDICT r05 item 2: the headroom rule (include/bz3_hip.h bz3_hip_set_workspace_headroom; api.hip ring_contexts_for / DeviceCtx::arena_slack).  The ring of
+    LZP contexts is sized so that the arena it lives in -- request + slack -- and the swap buffers its blocks borrow leave `headroom` bytes of the device free;
+    round 5 had a fixed 6 GiB margin that an unbounded 1/16 slack (5 GB of an 80 GB arena) consumed."""
+    GiB = 1 << 30
+    assert lib.bz3_hip_workspace_headroom() == 4 * GiB  # the default
+    lib.bz3_hip_set_workspace_headroom(3 * GiB)
+    assert lib.bz3_hip_workspace_headroom() == 3 * GiB
+    lib.bz3_hip_set_workspace_headroom(-1)
+    assert lib.bz3_hip_workspace_headroom() == 4 * GiB
+    # the slack is a sixteenth, capped at 512 MiB (+ 1 MiB)
+    assert lib.bz3_hip_debug_arena_slack(16 << 20) == (1 << 20) + (1 << 20)
+    assert lib.bz3_hip_debug_arena_slack(80 * GiB) == (512 << 20) + (1 << 20)
+    # the bench's regime: 768 lean states of 256 MiB, 91 GiB of the device free when the encode call starts
+    n = 256 << 20
+    need, ctx, cap = lib.bz3_hip_debug_workspace_bytes(n, 0), lib.bz3_hip_debug_workspace_bytes(n, 1), lib.bz3_bound(n)
+    assert 14 * GiB < need < 17 * GiB and 2 * GiB < ctx < 2.5 * GiB
+    fixed = 768 * (64 + 65536 + 256 + 131072 + 512) + (1 << 20)
+    for headroom in (0, 4 * GiB, 6 * GiB, 8 * GiB, 40 * GiB):
+        for free in (91 * GiB, 60 * GiB, 30 * GiB, 18 * GiB):
+            for have in (0, 20 * GiB):
+                c = lib.bz3_hip_debug_ring_contexts(free, have, need, fixed, ctx, cap, 1, headroom)
+                arena = need + fixed + c * (ctx + 1024)
+                held = arena + lib.bz3_hip_debug_arena_slack(arena) + c * cap  # the arena as arena_for allocates it + one borrowed swap buffer per context
+                if c > 0:
+                    assert free + have - held >= headroom, (headroom, free, have, c)  # the rule holds by construction ...
+                    c1 = c + 1
+                    arena1 = need + fixed + c1 * (ctx + 1024)
+                    assert free + have - (arena1 + lib.bz3_hip_debug_arena_slack(arena1) + c1 * cap) < headroom + (128 << 20)  # ... and nothing much is left unused
+    # 91 GiB free, the bench's headroom: a ring of 4 x 7 as in rounds 4-5 (pipeline_shape: window = contexts / 4)
+    assert lib.bz3_hip_debug_ring_contexts(91 * GiB, 0, need, fixed, ctx, cap, 1, 8 * GiB) // 4 == 7
+    # classic states own their swap buffers: 7/10 of what is free, but never into the headroom
+    assert lib.bz3_hip_debug_ring_contexts(10 * GiB, 0, 1 * GiB, 0, 1 * GiB, 0, 0, 0) == 6
+    assert lib.bz3_hip_debug_ring_contexts(10 * GiB, 0, 1 * GiB, 0, 1 * GiB, 0, 0, 4 * GiB) == 4
+    assert lib.bz3_hip_debug_ring_contexts(1 * GiB, 0, 2 * GiB, 0, 1 * GiB, 0, 1, 0) == 0

@@ -472,6 +472,56 @@ print("ok")
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-300:], r.stderr[-1200:])
 
 
+def test_a_small_mixed_batch_is_never_split(oracle):
+    """routing by histogram / payload size only pays when the WHOLE batch would take a row-cache variant.  A batch of at most one block
+    per CU is whole-model work anyway: a text block beside a random one is ONE CM launch per direction, nothing routed, nothing given up (round 5's decoder
+    split such a batch into two serial launches, each as long as its slowest block)."""
+    import subprocess
+
+    code = r'''
+import sys, ctypes as C
+sys.path[:0] = [%r, %r, %r]
+import bzip3_amd, datagen
+from build_emu import build
+from oracle_lib import Oracle
+lib = bzip3_amd._declare(C.CDLL(build()))
+o = Oracle()
+bs = 65 * 1024
+t = datagen.shakespeare()
+for lean in (0, 1):
+    lib.bz3_hip_set_lean_states(lean)
+    n = 2
+    assert lib.bz3_hip_cm_variant_for(0, n, 0) == 0
+    blocks = [t[5000:5900], datagen.random_bytes(6000, seed=77)]
+    states = (C.c_void_p * n)(*[lib.bz3_new(bs) for _ in range(n)])
+    cap = lib.bz3_bound(bs) + 64
+    bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+    for b, d in zip(bufs, blocks):
+        C.memmove(b, d, len(d))
+    ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+    g0, r0 = lib.bz3_hip_cm_blocks_given_up(), lib.bz3_hip_cm_blocks_routed_full()
+    lib.bz3_hip_debug_cm_launches(1)
+    lib.bz3_encode_blocks(states, ptrs, sizes, n)
+    assert lib.bz3_hip_debug_cm_launches(1) == 1, lean
+    for i, d in enumerate(blocks):
+        assert bytes(bufs[i][: sizes[i]]) == o.encode_block(d, bs)[2], (lean, i)
+    assert sizes[1] * 10 >= 6000 * 9  # the random block's payload did not shrink: round 5's decoder routed it
+    bsz = (C.c_size_t * n)(*[cap] * n)
+    orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+    lib.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+    assert lib.bz3_hip_debug_cm_launches(1) == 1, lean
+    for i, d in enumerate(blocks):
+        assert lib.bz3_last_error(states[i]) == 0 and bytes(bufs[i][: len(d)]) == d, (lean, i)
+    assert (lib.bz3_hip_cm_blocks_given_up() - g0, lib.bz3_hip_cm_blocks_routed_full() - r0) == (0, 0), lean
+    for s in states:
+        lib.bz3_free(s)
+print("ok")
+''' % (os.path.dirname(HERE), HERE, os.path.join(HERE, "emu"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BZ3_HIP_CUS="2"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-300:], r.stderr[-1200:])
+
+
 # ---- SURVEY.md 8f/N1: streaming file driver (stream.hip) ------------------------------------------------------------------
 def _bz3_file(oracle, data, bs):
     """The reference CLI's file for `data` at block size bs (-j 1 layout: doc/bzip3_format.md, src/main.c:173-180, :243-256)."""

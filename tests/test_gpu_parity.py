@@ -227,10 +227,10 @@ def test_front_end_and_tail_rings_on_gpu(gpu_lib, oracle, text, pipe, monkeypatc
     """The encoder's front end and the decoder's tail run their serial LZP kernels on side streams over a ring of context slots
     (api.hip encode_group / decode_group).  Under the CPU emulator kernels run at launch, so only here do the side streams really
     overlap the group's stream: 40 blocks (LZP applied, declined, stored) through forced ring shapes -- windows of one block
-    through four slots, a ragged last window through three, round 2's two slots of six, eight slots (all eight side streams; the shape a
-    GPU-filling batch's tail takes by default since round 5, there with windows of 8) -- and the automatic one, classic and lean states: the
-    oracle's bytes both ways.  With more than one block the tail runs on the CU partition (side streams on reserved CUs, whole-GPU kernels on
-    the rest) wherever the runtime grants the masked streams."""
+    through four slots, a ragged last window through three, round 2's two slots of six, eight slots (all eight side streams: an experiment's
+    shape; a GPU-filling batch's tail takes four slots of 16 blocks by default) -- and the automatic one, classic and lean states: the
+    oracle's bytes both ways.  The CU partition (side streams on reserved CUs, whole-GPU kernels on the rest) is taken from 128 blocks on
+    (round 6): test_large_lean_batch_default_rings_and_kept_workspace_on_gpu covers it."""
     for var in ("BZ3_HIP_LZP_PIPE", "BZ3_HIP_TAIL_PIPE"):
         if pipe:
             monkeypatch.setenv(var, pipe)
@@ -719,3 +719,89 @@ def test_zz_calibrated_text_stays_on_the_three_per_cu_kernels(gpu_lib, oracle):
             gpu_lib.bz3_free(s)
     finally:
         gpu_lib.bz3_hip_set_cm_mode(-1)
+
+
+def test_kept_workspace_leaves_the_headroom_to_the_host_program(gpu_lib, text):
+    """the headroom rule (include/bz3_hip.h bz3_hip_set_workspace_headroom).  The device is filled with ballast until only a few GiB are
+    free -- less than a full ring of LZP contexts would take --, then a lean batch goes through encode and decode with the workspace KEPT.  After each call
+    at least `headroom` bytes are free and a torch allocation of that size succeeds (round 5: the kept workspace took every byte and the host program's next
+    48 MiB allocation failed); the ring shrank to make that true; the round trip is the identity and the coded bytes equal a run without memory pressure."""
+    import torch
+
+    GiB = 1 << 30
+    dev = torch.device("cuda", 0)
+    bs = 16 << 20
+    n = 40
+    base = (text * 4)[:bs]
+    cap = gpu_lib.bz3_bound(bs) + 64
+    headroom = 2 * GiB
+    gpu_lib.bz3_hip_bind_device(0)
+    gpu_lib.bz3_hip_release_cached_memory()
+    src = torch.frombuffer(bytearray(base), dtype=torch.uint8).to(dev)
+    bufs = []
+    for k in range(n):
+        b = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        b[:bs] = torch.roll(src, 4099 * k)
+        bufs.append(b)
+    plain = [b[:bs].clone() for b in bufs[:3]]
+    need, ctx = gpu_lib.bz3_hip_debug_workspace_bytes(bs, 0), gpu_lib.bz3_hip_debug_workspace_bytes(bs, 1)
+    ballast = None
+    try:
+        assert gpu_lib.bz3_hip_set_lean_states(1) == 0 and gpu_lib.bz3_hip_set_keep_workspace(1) == 0
+        gpu_lib.bz3_hip_set_workspace_headroom(headroom)
+        states = (C.c_void_p * n)(*[gpu_lib.bz3_new(bs) for _ in range(n)])
+        assert all(states)
+        ptrs = (C.c_void_p * n)(*[b.data_ptr() for b in bufs])
+
+        def round_trip():
+            sizes = (C.c_int32 * n)(*[bs] * n)
+            gpu_lib.bz3_hip_encode_blocks_device(states, ptrs, sizes, n)
+            assert all(sizes[i] > 0 and gpu_lib.bz3_last_error(states[i]) == 0 for i in range(n))
+            free_enc = torch.cuda.mem_get_info(dev)[0]
+            ring = gpu_lib.bz3_hip_debug_front_end_ring()
+            coded = [bytes(bufs[i][: sizes[i]].cpu().numpy()) for i in (0, 1, n - 1)]
+            bsz = (C.c_size_t * n)(*[cap] * n)
+            orig = (C.c_int32 * n)(*[bs] * n)
+            gpu_lib.bz3_hip_decode_blocks_device(states, ptrs, bsz, sizes, orig, n)
+            assert all(gpu_lib.bz3_last_error(states[i]) == 0 for i in range(n))
+            free_dec = torch.cuda.mem_get_info(dev)[0]
+            for i in range(3):
+                assert torch.equal(bufs[i][:bs], plain[i]), i
+            return free_enc, free_dec, (ring & 0xFFFF, (ring >> 16) & 0xFF), coded
+
+        _, _, shape0, coded0 = round_trip()  # plenty of memory: the ring takes its full shape, 4 slots of 8
+        assert shape0 == (8, 4), shape0
+        gpu_lib.bz3_hip_release_cached_memory()
+        torch.cuda.empty_cache()
+        # ballast: leave the stages' scratch + 12 contexts (with a swap buffer each) + the headroom free -- a full ring would be 32 contexts
+        leave = need + 12 * (ctx + cap) + headroom + (1 * GiB)
+        free0 = torch.cuda.mem_get_info(dev)[0]
+        assert free0 > leave + GiB
+        ballast = torch.empty(free0 - leave, dtype=torch.uint8, device=dev)
+        gpu_lib.bz3_hip_debug_headroom_events(1, None)
+        free_enc, free_dec, shape1, coded1 = round_trip()
+        assert coded1 == coded0  # the bytes do not depend on the ring's shape
+        assert shape1[0] * shape1[1] < 32 and shape1[0] * shape1[1] >= 8, shape1  # the ring shrank instead of eating the headroom
+        assert free_enc >= headroom and free_dec >= headroom, (free_enc, free_dec)
+        assert gpu_lib.bz3_hip_debug_cached_bytes(0) > need  # ... and the workspace is still kept
+        x = torch.empty(headroom - (64 << 20), dtype=torch.uint8, device=dev)  # what the host program was promised is really there
+        x.fill_(1)
+        torch.cuda.synchronize()
+        del x
+        rel = C.c_uint(0)
+        trims = gpu_lib.bz3_hip_debug_headroom_events(0, C.byref(rel))
+        assert rel.value == 0, (trims, rel.value)  # sized right: the rule did not have to throw the workspace away
+        # a headroom nobody can honour beside the ballast: the library then holds NOTHING when the call returns
+        gpu_lib.bz3_hip_set_workspace_headroom(leave + 8 * GiB)
+        round_trip()
+        assert gpu_lib.bz3_hip_debug_cached_bytes(0) == 0
+        for s_ in states:
+            gpu_lib.bz3_free(s_)
+    finally:
+        del ballast
+        gpu_lib.bz3_hip_set_workspace_headroom(-1)
+        gpu_lib.bz3_hip_set_keep_workspace(-1)
+        gpu_lib.bz3_hip_set_lean_states(0)
+        gpu_lib.bz3_hip_release_cached_memory()
+        gpu_lib.bz3_hip_bind_device(-1)
+        torch.cuda.empty_cache()
