@@ -742,8 +742,8 @@ def run(a):
     comp_sizes = [0] * nblk
     stage = {}
     # CPU parity / baseline sample: coded bytes of the first blocks, copied aside (device to device) before the in-place decode
-    want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline and not a.emu and not a.leg
-    cpu_block = int((a.cpu_block_mib or a.block_mib) * (1 << 20))
+    want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline and not a.emu  # (also for `--leg cfg5`, round 6: the reference beside the 511 MiB blocks)
+    cpu_block = int(a.cpu_block_mib * (1 << 20)) if a.cpu_block_mib else block_size
     cpu_n = 0
     if want_cpu:
         per_thread = 7.5 * cpu_block + (64 << 20)  # reference state (~5.1 x block) + buffer + the shared copies
@@ -822,8 +822,8 @@ def run(a):
     keep_ws = not a.emu and os.environ.get("BZ3_BENCH_KEEP_WS", "1") != "0"
     # what the library must leave free on the device when a call returns (include/bz3_hip.h: the headroom rule): room for the parity sample's
     # copies of the coded blocks (~a fifth of a block each) and the fingerprints' temporaries
-    headroom = (4 << 30) + (int(cpu_n * block_size * 0.3) if want_cpu and cpu_block == block_size else 0)
-    headroom = min(headroom, 8 << 30)
+    headroom = (3 << 29) + (int(cpu_n * block_size / 4.5) if want_cpu and cpu_block == block_size and a.kind == "text" and not a.leg else (3 << 29) if not want_cpu else cpu_n * (block_size + (8 << 20)))
+    headroom = max(3 << 30, min(headroom, 6 << 30 if a.kind == "text" and not a.leg else 40 << 30))
     if not a.emu and hasattr(lib, "bz3_hip_set_workspace_headroom"):
         lib.bz3_hip_set_workspace_headroom(headroom)
 

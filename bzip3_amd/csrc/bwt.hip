@@ -1723,6 +1723,7 @@ s32 bwt_forward(const u8 * d_in, u32 n, u8 * d_out, Arena & tmp, hipStream_t s, 
             if (m_next == 0) break;
             m = m_next;
             st.rounds++;
+            if (bwt_switches().trace) fprintf(stderr, "[bwt] n %u doubling round at depth %u: %u active suffixes\n", n, h, m);
             // the active suffixes are in vact, their slots in slot[scur], their ranks in grp
             launch(k_bwt_doubling_keys_grp, grid(m), dim3(BW_BLOCK), 0, s, (const u32 *)vact, (const u32 *)grp, (const u32 *)isa, m, n, h, key[0]);
             u32 * pv[2] = {vact, vfree};
