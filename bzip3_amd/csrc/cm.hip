@@ -295,6 +295,16 @@ __device__ __forceinline__ void cm_pair_store(__attribute__((address_space(3))) 
     }
 }
 #endif
+// Round-6 decoder experiments (compile-time, tools/build_variant.py; profiles/r06_cm_decoder_experiments.txt has what they measured):
+//   CM_EXP_EARLY_ROW   the model waves read C1[m][node] of the byte value m that the current run interrupted (the likeliest byte after a wrong guess: a third
+//                      of them) BEFORE barrier 1, so that a wrong guess that turns out to be m does not wait for that LDS round trip in the repair
+//   CM_EXP_PREFETCH    the walker asks for the speculative table of byte i+1 in the middle of the walk of byte i, behind ready flags of the four model waves
+#ifndef CM_EXP_EARLY_ROW
+#define CM_EXP_EARLY_ROW 0
+#endif
+#ifndef CM_EXP_PREFETCH
+#define CM_EXP_PREFETCH 0
+#endif
 constexpr bool CM_ENC_PAIR_HALVES = false;  // (measured in round 4: the encoder gains nothing from the halves -- its eight chain lanes pay two instructions more per bit instead)
 constexpr bool CM_DEC_PAIR_HALVES = true;   // the decoder's model waves: 767.7 -> 618.3 ns per byte and block at three blocks per CU together with the subtree form (profiles/r04_cm_decoder_experiments.txt)
 
@@ -957,6 +967,7 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
         // the directory byte value -> slot also lives in a register (lane k: entries 4k .. 4k+3): the lookup on a wrong guess is a
         // v_readlane instead of an LDS round trip on the path the walker waits for
         u32 rowreg = R ? reinterpret_cast<const u32 *>(rc.row_of)[lane] : 0u;
+        u32 mru = 0x100u;  // CM_EXP_EARLY_ROW: the byte value the current run interrupted (never k1); 0x100 = none yet
         u64 mprof_spec = 0, mprof_wait = 0, mprof_redo = 0;  // PROF
         __syncthreads();  // barrier 0: table 0 is there
         // One byte: `prev` = what the evaluation of byte i-1 left, `cur` receives that of byte i.  Two bytes per loop trip with the two
@@ -984,6 +995,14 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
             run_prev++;
             if (__builtin_expect(run_prev == 3u, 0)) c2row = c2row1;
             cur = evaluate(pt, prev.a1, cell, cm_mad24(cell, 9u, cm_mad24(c0, 7u, 0u)), c2row);
+            u32 early = 0;       // CM_EXP_EARLY_ROW: C1[mru][node], asked for while the walker still walks
+            bool early_ok = false;
+            if (CM_EXP_EARLY_ROW && mru < 0x100u) {
+                u32 row_m = mru;
+                if (R) row_m = (cm_readlane(rowreg, (int)(mru >> 2)) >> (8u * (mru & 3u))) & 0xFFu;
+                early_ok = !R || row_m < CM_ROW_SPILLED;  // (wave-uniform; a row that is not resident is fetched the ordinary way should it be needed)
+                if (early_ok) early = *(c1col + row_m * 256u);  // nobody writes that row before the repair reads it: the updates of byte i-1 go to the row of byte i-2 = k1 != mru
+            }
             if (PROF) m1 = cm_clock();
             __syncthreads();  // barrier 1: the walker has decoded byte i-1
             const u32 c = cm_uniform(LDS_PEEK(s_done[BUF ^ 1u]));
@@ -1019,7 +1038,10 @@ __device__ __forceinline__ void cm_decode_block_sync(const CmDecodeJob * __restr
                     }
                 }
                 CM_LDS u16 * const a1 = c1col + row * 256u;
-                const u32 p1 = *a1;
+                u32 p1;
+                if (CM_EXP_EARLY_ROW && early_ok && c == mru) p1 = early;  // (wave-uniform branch)
+                else p1 = *a1;
+                if (CM_EXP_EARLY_ROW) mru = g;  // the run of g's ends here: g is what a later wrong guess most likely returns to
                 u32 cell2 = prev.p1;
                 if (on_g) {
                     c0 = c0_old;

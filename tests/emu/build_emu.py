@@ -14,6 +14,11 @@ SOURCES = ["sort.hip", "crc32c.hip", "mrle.hip", "lzp.hip", "bwt.hip", "unbwt.hi
 
 
 def build():
+    """BZ3_EMU_DEFS="-DX=1 ...": a variant build (round 6's compile-time kernel experiments under the fuzzers), in a library and object directory of its own."""
+    global OUT
+    defs = os.environ.get("BZ3_EMU_DEFS", "").split()
+    tag = ("_" + hashlib.sha256(" ".join(defs).encode()).hexdigest()[:8]) if defs else ""
+    OUT = os.path.join(HERE, f"libbz3_emu{tag}_TESTONLY.so")
     srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "hip_emu.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(HERE, "hip_emu.hpp")]
     deps += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
@@ -26,11 +31,11 @@ def build():
         return OUT
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    os.makedirs(os.path.join(HERE, "build" + tag), exist_ok=True)
     for s in srcs:
-        o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
+        o = os.path.join(HERE, "build" + tag, os.path.basename(s) + ".o")
         objs.append(o)
-        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DBZ3_EMU", *(["-DBZ3_EMU_WATCH"] if os.environ.get("BZ3_EMU_WATCH") else []), "-I", HERE, "-I", CSRC, "-x", "c++", "-c", s, "-o", o,
+        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DBZ3_EMU", *defs, *(["-DBZ3_EMU_WATCH"] if os.environ.get("BZ3_EMU_WATCH") else []), "-I", HERE, "-I", CSRC, "-x", "c++", "-c", s, "-o", o,
                "-Wno-unknown-pragmas", "-Wno-attributes"]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for s, p in procs:
