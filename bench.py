@@ -122,6 +122,7 @@ def parse():
     ap.add_argument("--host-api-block-mib", type=float, default=32.0, help="block size of the host_api leg (0 = skip the leg)")
     ap.add_argument("--noise", type=float, default=-1.0, help="fraction of noise tokens in the text (-1 = tests/datagen.py ENWIK_NOISE, the enwik8 calibration)")
     ap.add_argument("--text-bases", type=int, default=8, help="independent texts the blocks are drawn from")
+    ap.add_argument("--legs", default="", help="comma-separated subset of the extra legs to run (random, mixed, cfg5_unbwt, cfg3, cfg2, host_api; default: all)")
     ap.add_argument("--leg", default="", choices=["", "cfg5"], help="run ONE optional leg instead of the default workload (cfg5: a GPU-filling batch of 511 MiB blocks)")
     ap.add_argument("--leg-block-mib", type=float, default=511.0, help="block size of --leg cfg5 (511 = BASELINE's; smaller values are for tests)")
     ap.add_argument("--emu", action="store_true", help="TESTS ONLY: the CPU emulator build of the kernels (tests/emu) and gloo instead of a GPU and RCCL; checks the control flow, measures nothing")
@@ -365,44 +366,57 @@ def host_mem_available():
     return 8 << 30
 
 
-REF_VARIANTS = (("gcc -O2", "libbz3ref.so"), ("gcc -O2 -march=x86-64-v3", "libbz3ref_v3.so"), ("clang -O3 -march=x86-64-v3", "libbz3ref_clang.so"))
+REF_VARIANTS = (("gcc -O2", "libbz3ref.so"), ("gcc -O2 -march=x86-64-v3", "libbz3ref_v3.so"), ("clang -O3 -march=x86-64-v3", "libbz3ref_clang.so"),
+                ("gcc -O2 -march=znver3", "libbz3ref_znver3.so"), ("clang -O3 -march=znver5", "libbz3ref_clang_znver5.so"))
+
+_PROBE_CODE = r"""
+import sys, time
+sys.path[:0] = [%r, %r]
+from oracle_lib import Bz3, RefLib
+r = RefLib(sys.argv[1])
+assert r.available
+b = Bz3(r.lib)
+sample = open(sys.argv[2], "rb").read()
+bs = max(len(sample), 65 * 1024)
+t0 = time.perf_counter()
+n_enc, err, blk = b.encode_block(sample, bs)
+k, err2, back = b.decode_block(blk, len(sample), bs)
+dt = time.perf_counter() - t0
+assert not err and not err2 and back == sample
+print(dt)
+"""
 
 
 def fastest_reference(sample):
     """(label, path, probe record) of the reference build that round-trips an 8 MiB sample fastest on ONE thread of this host.
     SURVEY.md 8d asks for gcc -O2 and clang -O3 with -march=native; the reference tree is not on the GPU box, so the variants are
-    compiled in the build container (oracle/Makefile) for x86-64-v3, the closest level both machines run."""
-    from oracle_lib import ORACLE_DIR, Bz3, RefLib
+    compiled in the build container (oracle/Makefile): plain, x86-64-v3, and -- round 6 -- what -march=native means on the GPU boxes'
+    host (gcc -march=znver3, the newest this gcc knows; AMD clang -march=znver5).  Every variant is probed in a PROCESS OF ITS OWN: a build
+    that uses an instruction this host lacks dies there (SIGILL) and is simply not a candidate."""
+    import tempfile
 
-    flags = ""
-    try:
-        with open("/proc/cpuinfo") as fh:
-            for ln in fh:
-                if ln.startswith("flags"):
-                    flags = ln
-                    break
-    except OSError:
-        pass
-    v3_ok = all(f" {x}" in flags for x in ("avx2", "bmi2", "fma"))
+    from oracle_lib import ORACLE_DIR
+
     probe, best = {}, None
-    for label, name in REF_VARIANTS:
-        path = os.path.join(ORACLE_DIR, "_ref", name)
-        if not os.path.exists(path) or ("v3" in label and not v3_ok):
-            continue
-        r = RefLib(path)
-        if not r.available:
-            continue
-        b = Bz3(r.lib)
-        bs = max(len(sample), 65 * 1024)
-        t0 = time.perf_counter()
-        n_enc, err, blk = b.encode_block(sample, bs)
-        k, err2, back = b.decode_block(blk, len(sample), bs)
-        dt = time.perf_counter() - t0
-        if err or err2 or back != sample:
-            continue
-        probe[label] = round(len(sample) / 2 ** 20 / dt, 3)
-        if best is None or dt < best[2]:
-            best = (label, path, dt)
+    with tempfile.NamedTemporaryFile(suffix=".bin", prefix="bz3_probe_") as f:
+        f.write(sample)
+        f.flush()
+        for label, name in REF_VARIANTS:
+            path = os.path.join(ORACLE_DIR, "_ref", name)
+            if not os.path.exists(path):
+                continue
+            try:
+                r = subprocess.run([sys.executable, "-c", _PROBE_CODE % (ROOT, os.path.join(ROOT, "tests")), path, f.name], capture_output=True, text=True, timeout=120)
+                if r.returncode != 0:
+                    probe[label] = f"does not run here (exit {r.returncode})"
+                    continue
+                dt = float(r.stdout.strip().splitlines()[-1])
+            except Exception as e:
+                probe[label] = f"probe failed: {type(e).__name__}"
+                continue
+            probe[label] = round(len(sample) / 2 ** 20 / dt, 3)
+            if best is None or dt < best[2]:
+                best = (label, path, dt)
     return (best[0], best[1], probe) if best else (None, None, probe)
 
 
@@ -858,7 +872,7 @@ def run(a):
                     traffic = int(pm["fetch_bytes_per_input_byte"] * n_dec * nblk + pm["write_bytes_per_coded_byte"] * comp_total)
             except Exception:
                 pass
-            what = {"": f"synthetic enwik-style {a.kind}", "cfg5": "16-symbol order-1 Markov (BASELINE.json configs[4] stand-in)"}[a.leg]
+            what = {"": "synthetic enwik-style text" if a.kind == "text" else "uniformly random", "cfg5": "16-symbol order-1 Markov (BASELINE.json configs[4] stand-in)"}[a.leg]
             if a.emu:
                 what = "16-symbol order-1 Markov (--emu: CPU emulation of the kernels, control-flow test only)"
             out = {
@@ -1028,6 +1042,12 @@ def run(a):
     def left_s():
         return a.budget_s - elapsed()
 
+    legs_sel = {x for x in a.legs.split(",") if x}
+
+    def leg_wanted(name):
+        """text batches only; `--legs a,b` picks some of the extra legs (default: all of them)"""
+        return extras_wanted and a.kind == "text" and (not legs_sel or name in legs_sel)
+
     class guard:
         """An extra leg may fail (out of memory beside the batch, a reference process that dies ...) without taking the run's line with it: the
         failure is recorded under configs[name] and the next leg runs."""
@@ -1113,7 +1133,7 @@ def run(a):
     random_host = None
     mixed_host = None
     with guard("random"):
-        if extras_wanted and a.kind == "text" and left_s() > 200.0:
+        if leg_wanted("random") and left_s() > 200.0:
             # ---- random: incompressible blocks, as many as the timed batch had (LZP and RLE decline, model 0, ~1.004 bytes per byte) ----
             rb = int(a.random_block_mib * (1 << 20))
             nr = a.random_blocks if a.random_blocks > 0 else nblk
@@ -1153,7 +1173,7 @@ def run(a):
             live_states = free_most_of_the_batch()
 
     with guard("mixed"):
-        if extras_wanted and a.kind == "text" and live_states >= 96 and block_size >= (32 << 20) and left_s() > 200.0:
+        if leg_wanted("mixed") and live_states >= 96 and block_size >= (32 << 20) and left_s() > 200.0:
             # mixed batch: text, binary and incompressible blocks through ONE pair of batch calls
             mb = 32 << 20
             per = 32
@@ -1242,7 +1262,7 @@ def run(a):
             mixed_host.close()
             mixed_host = None
 
-    if extras_wanted and a.kind == "text" and left_s() > 200.0:
+    if leg_wanted("cfg5_unbwt") and left_s() > 200.0:
         # (after the reference process has finished: the stage hooks wait for the stream between launches, and a host whose CPU quota 64
         # reference threads saturate stretches exactly those waits -- round 4's rehearsal measured this leg 3.4x slower beside them)
         # cfg5's stage (BASELINE.json configs[4]: "-b 511 max block ... decode-path unBWT throughput"): the inverse BWT of one block of the
@@ -1304,7 +1324,7 @@ def run(a):
 
     n3 = (a.cfg3_bytes + block_size - 1) // block_size  # blocks of the cfg3 leg: full blocks + one partial
     with guard("cfg3"):
-        if extras_wanted and a.kind == "text" and nblk >= n3:
+        if leg_wanted("cfg3") and nblk >= n3:
             # cfg3 (BASELINE.json configs[2]): 1,000,000,000 B at -b 256 = 3 full blocks + 194,693,632 B, on one GPU
             cm_s = (stage["enc"]["cm"] + stage["dec"]["cm"]) * 1e-3
             est = cm_s * (1.0 if per_cu == 1 else 0.7) + 15.0
@@ -1316,7 +1336,7 @@ def run(a):
                 RESULT["line"]["configs"]["cfg3"] = {"skipped": f"needs ~{est:.0f}s, {left_s():.0f}s of the budget left"}
 
     with guard("cfg2"):
-        if extras_wanted and a.kind == "text" and block_size >= (32 << 20) and nblk >= 3:
+        if leg_wanted("cfg2") and block_size >= (32 << 20) and nblk >= 3:
             # cfg2 (BASELINE.json configs[1]): 100,000,000 B at -b 32 = 2 full blocks + 32,891,136 B
             if left_s() > 60.0:
                 small_config("cfg2", 100_000_000, 32 << 20, "BASELINE.json configs[1] stand-in")
@@ -1325,7 +1345,7 @@ def run(a):
 
     hb = int(a.host_api_block_mib * (1 << 20))
     with guard("host_api"):
-        if extras_wanted and a.kind == "text" and hb > 0 and hb <= block_size and live_states >= 8:
+        if leg_wanted("host_api") and hb > 0 and hb <= block_size and live_states >= 8:
             # ---- host_api: SURVEY.md 8d's timing boundary -- bz3_encode_blocks / bz3_decode_blocks on malloc'ed HOST buffers (H2D / D2H inside the
             # timed calls) against the same batch device-resident.  Blocks of hb bytes, one per state still alive.
             nh = live_states
