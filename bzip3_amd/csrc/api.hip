@@ -71,10 +71,11 @@ struct DeviceCtx {
     hipStream_t aux_m[AUX] = {};  // the decoder's side streams, on the reserved CUs (the encoder's rings keep the plain ones: call 4 measured its
                                          // front end 6 % SLOWER with its LZP drivers confined to 32 CUs, profiles/r05_cu_partition_256x64MiB.txt)
     int reserved_cus = 0;
+    static int reserved_cus_wanted() { return cu_reserve_setting(); }
     static int cu_reserve_setting() {
         static const int v = [] {
             const char * e = getenv("BZ3_HIP_CU_RESERVE");
-            return e ? atoi(e) : 48;  // three windows of 16 LZP decoders in flight, a CU each (two on a CU halve each other's table-insert rate)
+            return e ? atoi(e) : 64;  // three windows of 20 LZP decoders in flight, a CU each (two on a CU halve each other's table-insert rate); rounds 5: 48 = 3 x 16
         }();
         return v;
     }
@@ -1226,6 +1227,19 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     // of 8 on a 128-block batch (profiles/r03_gaps_128x256MiB.txt): no gain there, where the pool's first allocations set the pace.
     s32 tail_slots = n >= 128 ? 4 : 2;
     s32 tail_window = tail_slots == 4 ? 16 : 32;
+    // Round 6: windows of 20 on 64 reserved CUs where 80 swap buffers can be had.  What the ring can hide is the whole-GPU work of the decoders in flight -- one per
+    // reserved CU: 48 x ~20 ms = 0.98 s at 256 MiB against launches of ~1.04 s, 3.9 s of waiting in a full-size tail; 60 in flight on 64 CUs: 2.2 s of waiting, the walks
+    // 3 % slower on 192 CUs, the tail 19.6 -> 18.3 s on the same box (profiles/r06_call4_full_*.progress.txt).  The buffers come out of the kept arena (below) or,
+    // without keep-workspace, out of the pool -- only when the device has the room beside the headroom (lean states; classic states own their swap buffers).
+    if (tail_slots == 4 && n >= 4 * 20 && lead->ctx->reserved_cus_wanted() >= 60) {
+        size_t cap_max = 0;
+        for (s32 i = 0; i < n; i++)
+            if (sts[i]->lean && sts[i]->cap > cap_max) cap_max = sts[i]->cap;
+        size_t free_b = 0, total_b = 0;
+        const size_t extra = (size_t)16 * cap_max;  // what four windows of 20 hold beyond four of 16
+        const bool from_arena = keep_workspace() && any_lean && lead->ctx->ws_cap >= need + need / 16 + (size_t)80 * ((cap_max + 255) & ~(size_t)255) + max_round / 64;
+        if (!any_lean || from_arena || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= (size_t)80 * cap_max + extra + ws_headroom() + ((size_t)2 << 30) + max_round)) tail_window = 20;
+    }
     lead->ctx->ensure_aux();
     // With the CU partition the whole-GPU kernels run at their stand-alone pace and the LZP decoders become what the ring has to hide: ~1.0 s per launch
     // at 256 MiB beside the streaming kernels (0.55 s alone: their 1 MiB tables do not stay in L2), whatever the window.  Measured at full size on 48
