@@ -75,7 +75,7 @@ struct DeviceCtx {
     static int cu_reserve_setting() {
         static const int v = [] {
             const char * e = getenv("BZ3_HIP_CU_RESERVE");
-            return e ? atoi(e) : 64;  // three windows of 20 LZP decoders in flight, a CU each (two on a CU halve each other's table-insert rate); rounds 5: 48 = 3 x 16
+            return e ? atoi(e) : 64;  // the most cu_masks hands out (8 per block of 32 CUs); round 5: 48 = three windows of 16 LZP decoders, a CU each
         }();
         return v;
     }
@@ -1227,18 +1227,29 @@ void decode_group(bz3_state ** sts, u8 ** bufs, const size_t * buffer_sizes, con
     // of 8 on a 128-block batch (profiles/r03_gaps_128x256MiB.txt): no gain there, where the pool's first allocations set the pace.
     s32 tail_slots = n >= 128 ? 4 : 2;
     s32 tail_window = tail_slots == 4 ? 16 : 32;
-    // Round 6: windows of 20 on 64 reserved CUs where 80 swap buffers can be had.  What the ring can hide is the whole-GPU work of the decoders in flight -- one per
-    // reserved CU: 48 x ~20 ms = 0.98 s at 256 MiB against launches of ~1.04 s, 3.9 s of waiting in a full-size tail; 60 in flight on 64 CUs: 2.2 s of waiting, the walks
-    // 3 % slower on 192 CUs, the tail 19.6 -> 18.3 s on the same box (profiles/r06_call4_full_*.progress.txt).  The buffers come out of the kept arena (below) or,
-    // without keep-workspace, out of the pool -- only when the device has the room beside the headroom (lean states; classic states own their swap buffers).
-    if (tail_slots == 4 && n >= 4 * 20 && lead->ctx->reserved_cus_wanted() >= 60) {
+    // Round 6: 64 reserved CUs and wider windows, where the swap buffers can be had.  What the ring can hide is the whole-GPU work of the blocks whose decoders are in flight,
+    // and the tail's whole-GPU kernels do not miss the CUs (they are bound by HBM line fetches).  At 768 x 256 MiB, one step each ("inverse BWTs + LZP launches" + "waiting for a
+    // window's decoders" + "mRLE / CRC"; BZ3_HIP_CU_RESERVE above 64 still reserves 64: cu_masks hands out at most 8 CUs per block of 32):
+    //   16 x 4 on 48 CUs: 12.7 + 3.9 + 3.0 = 19.6 s    20 x 4 on 64: 13.0 + 2.3 + 3.0 = 18.3 s    25 x 4: 12.4 + 1.5 + 3.0 = 16.9 s    30 x 4: 12.7 + 0.9 + 3.0 = 16.6 s    32 x 4: 13.2 + 0.7 + 3.0 = 16.9 s
+    // (profiles/r06_call4_full_*.progress.txt, r06_call6_stdout_tail.txt, r06_tail_ring_full_size.txt): with windows of 30 up to 90 decoders share the 64 CUs, and a CU with two
+    // of them still beats a window that waits.  The buffers come out of the kept arena (below) or, without keep-workspace, out of the pool -- only when the device has the room
+    // beside the headroom (lean states; classic states own their swap buffers).
+    if (tail_slots == 4) {
         size_t cap_max = 0;
         for (s32 i = 0; i < n; i++)
             if (sts[i]->lean && sts[i]->cap > cap_max) cap_max = sts[i]->cap;
+        const size_t cap_al = (cap_max + 255) & ~(size_t)255;
         size_t free_b = 0, total_b = 0;
-        const size_t extra = (size_t)16 * cap_max;  // what four windows of 20 hold beyond four of 16
-        const bool from_arena = keep_workspace() && any_lean && lead->ctx->ws_cap >= need + need / 16 + (size_t)80 * ((cap_max + 255) & ~(size_t)255) + max_round / 64;
-        if (!any_lean || from_arena || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= (size_t)80 * cap_max + extra + ws_headroom() + ((size_t)2 << 30) + max_round)) tail_window = 20;
+        const bool have_info = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+        for (s32 w : {30, 25, 20}) {
+            if (n < 4 * w || lead->ctx->reserved_cus_wanted() < 64) continue;
+            const size_t bufs = (size_t)4 * (size_t)w;
+            const bool from_arena = keep_workspace() && any_lean && lead->ctx->ws_cap >= need + need / 16 + bufs * cap_al + ((size_t)64 << 20);
+            if (!any_lean || from_arena || (have_info && free_b >= bufs * cap_max + ws_headroom() + ((size_t)2 << 30) + max_round)) {
+                tail_window = w;
+                break;
+            }
+        }
     }
     lead->ctx->ensure_aux();
     // With the CU partition the whole-GPU kernels run at their stand-alone pace and the LZP decoders become what the ring has to hide: ~1.0 s per launch

@@ -3,6 +3,7 @@
 # uses the same CM kernels as the full-size one (768 blocks = three per CU), then tools/pmc_traffic.py turns them into profiles/pmc_traffic.json.
 #   bash tools/pmc_pass.sh <output dir under gpurun_out>
 set -e
+trap 'rm -rf "$OUT/FETCH_SIZE" "$OUT/WRITE_SIZE"' EXIT  # whatever happens, the databases stay on the box: gpurun brings back 64 MiB at most
 OUT=$(realpath "$1")
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$OUT"
@@ -10,7 +11,9 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="--blocks 768 --block-mib ${PMC_BLOCK_MIB:-2} --no-cpu-baseline --no-extras --steps 1 --warmup 0"
 for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf "$OUT/$c"
-    rocprofv3 --kernel-trace --pmc $c -d "$OUT/$c" -o pass -- python "$REPO/bench.py" $ARGS > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err" || { tail -5 "$OUT/bench_$c.err"; exit 1; }
+    # (the exit code is not the test: under rocprofv3 the process may die in its exit handlers AFTER bench.py has printed its line and the database is written -- round 6)
+    rocprofv3 --kernel-trace --pmc $c -d "$OUT/$c" -o pass -- python "$REPO/bench.py" $ARGS > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err" || true
+    [ -n "$(find "$OUT/$c" -name '*.db' | head -1)" ] && grep -q '"value"' "$OUT/bench_$c.json" || { tail -5 "$OUT/bench_$c.err"; rm -rf "$OUT/$c"; exit 1; }
 done
 F=$(find "$OUT/FETCH_SIZE" -name "*.db" | head -1)
 W=$(find "$OUT/WRITE_SIZE" -name "*.db" | head -1)
