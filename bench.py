@@ -810,7 +810,7 @@ def run(a):
             lib.bz3_hip_last_bwt_stats(states[0], C.byref(r), C.byref(p), C.byref(e))
             stage["bwt"] = {"rounds": r.value, "radix_passes": p.value, "sorted_elements": e.value}
             ring = lib.bz3_hip_debug_front_end_ring()  # the encoder's front-end pipeline: context slots x blocks per window
-            stage["front_end_ring"] = {"slots": (ring >> 16) & 0xFF, "window": ring & 0xFFFF, "workspace_handed_back": bool(ring >> 30)}
+            stage["front_end_ring"] = {"slots": (ring >> 16) & 0xFF, "window": ring & 0xFFFF, "workspace_handed_back": bool((ring >> 30) & 1), "two_threads": bool((ring >> 29) & 1)}
             if cpu_block == block_size and not coded_kept and not step_s and want_cpu and "coded" not in parity_sample:
                 keep_coded_sample(sizes)  # a few ms of device-to-device copies inside the timed region, first step only (the in-place decode destroys the coded bytes)
         t2 = time.perf_counter()
@@ -970,6 +970,9 @@ def run(a):
 
     if keep_ws:
         lib.bz3_hip_set_keep_workspace(1)
+    front_duo = os.environ.get("BZ3_BENCH_FRONT_DUO", "")  # (experiments: "1" / "0" force the encoder's two-thread front end on / off; unset = the library's default)
+    if front_duo in ("0", "1") and hasattr(lib, "bz3_hip_set_front_end_duo"):
+        lib.bz3_hip_set_front_end_duo(int(front_duo))
     PHASE["name"] = "first timed step"
     inject("step1")
     barrier()

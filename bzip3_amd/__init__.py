@@ -58,6 +58,7 @@ def _declare(L, strict=True):
         "bz3_hip_set_lean_states": (C.c_int, [C.c_int]),
         "bz3_hip_release_cached_memory": (None, []),
         "bz3_hip_set_keep_workspace": (C.c_int, [C.c_int]),
+        "bz3_hip_set_front_end_duo": (C.c_int, [C.c_int]),
         "bz3_hip_set_workspace_headroom": (None, [C.c_longlong]),
         "bz3_hip_workspace_headroom": (sz, []),
         "bz3_hip_debug_headroom_events": (C.c_uint, [C.c_int, C.POINTER(C.c_uint)]),

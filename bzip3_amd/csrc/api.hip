@@ -58,6 +58,7 @@ struct DeviceCtx {
     static constexpr int AUX = 8;           // side streams / ring slots available; the rings use four unless a test or an experiment asks for more
     static constexpr int RING_SLOTS = 4;
     hipStream_t aux[AUX] = {};
+    hipStream_t duo = nullptr;  // round 6: phase A of the encoder's front end when it runs on a thread of its own (encode_group)
     hipEvent_t ev_prep = nullptr, ev_d0[AUX] = {}, ev_d1[AUX] = {};
     bool aux_ready = false;
     // CU partition (round 5).  The serial kernels on the side streams hold a CU each for the better part of a second (an LZP decoder: 1024 lanes, ~0.5 s per
@@ -102,7 +103,7 @@ struct DeviceCtx {
         if (aux_ready) return;
         // built into locals and committed only when everything exists: a failure half way must not leave a context whose first
         // stream is there and whose events are not (every later call would record on null events)
-        hipStream_t st[AUX] = {}, sm[AUX] = {}, rs = nullptr;
+        hipStream_t st[AUX] = {}, sm[AUX] = {}, rs = nullptr, du = nullptr;
         hipEvent_t e0[AUX] = {}, e1[AUX] = {}, ep = nullptr;
         int reserved = 0;
         try {
@@ -136,7 +137,9 @@ struct DeviceCtx {
                 HIP_CHECK(hipEventCreate(&e0[k]));
                 HIP_CHECK(hipEventCreate(&e1[k]));
             }
+            HIP_CHECK(hipStreamCreateWithFlags(&du, hipStreamNonBlocking));
         } catch (...) {
+            if (du) (void)hipStreamDestroy(du);
             if (ep) (void)hipEventDestroy(ep);
             if (rs) (void)hipStreamDestroy(rs);
             for (int k = 0; k < AUX; k++)
@@ -149,6 +152,7 @@ struct DeviceCtx {
             throw;
         }
         ev_prep = ep;
+        duo = du;
         rest = rs;
         for (int k = 0; k < AUX; k++) aux_m[k] = sm[k];
         reserved_cus = reserved;
@@ -308,6 +312,10 @@ int pick_device() {
     return (int)(g_rr.fetch_add(1) % (unsigned)n);
 }
 
+// The two halves of the encoder's front end have scratch needs of their own (round 6: they may run on two host threads and two streams, see encode_group):
+// phase A = CRC, mRLE, LZP preparation (hash sort, binned links); phase B = LZP emission and the suffix sort.
+size_t front_a_scratch_bytes(u64 n) { return (size_t)n * 30 + radix_temp_bytes(n, 9) + scan_temp_words(n / 8 + 4096) * 4 + (4u << 20); }
+size_t front_b_scratch_bytes(u64 n) { return bwt_workspace_bytes(n) + (size_t)(n / 1024 + 4096) * 4; }
 size_t workspace_bytes_for(u64 n) {
     size_t a = bwt_workspace_bytes(n), b = unbwt_workspace_bytes(n);
     size_t c = (size_t)n * 30 + radix_temp_bytes(n, 9) + scan_temp_words(n / 8 + 4096) * 4 + (4u << 20);  // LZP: links, mlen, bitmaps, the hash sort's buffers + the binned link records (lzp.hip)
@@ -521,6 +529,7 @@ struct bz3_state {
     const u8 * cm_in = nullptr;
     u32 cm_in_size = 0;
     u8 * side = nullptr;  // lean encode: this block's slice of the in-place coder's side buffer
+    bool hold_swap = false;  // lean encode, two-thread front end: encode_front_b leaves the swap buffer with the state; the window's thread returns it behind an event
     bool skip = false;    // host-buffer API: staging this block failed (on_failure has set the error); the group leaves it alone
     // decode
     size_t buffer_size = 0;
@@ -619,6 +628,9 @@ void enforce_headroom(DeviceCtx * ctx, hipStream_t s);
 // BZ3_HIP_KEEP_WS=1 (experiment, round 5's first measurement): a lean batch's workspace survives the call -- the decode call that follows reuses the
 // encode call's arena and carves the swap buffers of its tail windows from it -- instead of one hipFree and two multi-GB hipMallocs per round trip
 // (30-45 ms per GiB: profiles/r04_first_touch.txt).  Read once.
+#ifndef BZ3_FRONT_DUO_DEFAULT
+#define BZ3_FRONT_DUO_DEFAULT 0
+#endif
 std::atomic<int> g_keep_ws{-1};  // bz3_hip_set_keep_workspace: -1 = the environment decides
 inline bool keep_workspace() {
     static const bool env_on = [] {
@@ -627,6 +639,15 @@ inline bool keep_workspace() {
     }();
     const int v = g_keep_ws.load();
     return v < 0 ? env_on : v != 0;
+}
+std::atomic<int> g_front_duo{-1};  // bz3_hip_set_front_end_duo: -1 = the environment decides (BZ3_HIP_FRONT_DUO, read once)
+inline bool front_end_duo() {
+    static const int env_on = [] {
+        const char * e = getenv("BZ3_HIP_FRONT_DUO");
+        return e ? (atoi(e) != 0 ? 1 : 0) : BZ3_FRONT_DUO_DEFAULT;
+    }();
+    const int v = g_front_duo.load();
+    return v < 0 ? env_on != 0 : v != 0;
 }
 inline void lean_borrow(bz3_state * st) {
     if (st->lean && !st->d_swap) st->d_swap = st->ctx->temp_get(st->cap);
@@ -748,7 +769,7 @@ void encode_front_b(bz3_state * st, Arena & arena, const LzpEncodeCtx & c, float
     // mutex for the whole call and every kernel that touches the buffer, this block's and the next borrower's, is launched on the group's
     // ONE stream (the side streams only run LZP drivers, behind events recorded on it) --, so stream order is what protects it; rounds 1-3
     // waited for the stream here, once per block.
-    if (st->lean) lean_return(st);
+    if (st->lean && !st->hold_swap) lean_return(st);
     st->b1 = b1;
     st->b2 = b2;
     st->n_cm = n;
@@ -848,11 +869,17 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         sts[i]->xs = lead->stream;
         sts[i]->timed = i == 0;  // stage timings (bz3_hip_last_timings) are sampled on the group's first block: timing a stage means waiting for the stream
     }
-    size_t need = 0;
+    size_t need = 0, need_a = 0, need_b = 0;
     for (s32 i = 0; i < n; i++) {
-        const size_t w = workspace_bytes_for((u64)(sizes[i] > 0 ? sizes[i] : 0) + 64);
+        const u64 nb = (u64)(sizes[i] > 0 ? sizes[i] : 0) + 64;
+        const size_t w = workspace_bytes_for(nb), wa = front_a_scratch_bytes(nb), wb = front_b_scratch_bytes(nb);
         if (w > need) need = w;
+        if (wa > need_a) need_a = wa;
+        if (wb > need_b) need_b = wb;
     }
+    // Two-thread front end (round 6, bz3_hip_set_front_end_duo / BZ3_HIP_FRONT_DUO; see below): phase A and phase B have a scratch region each
+    const bool duo_wanted = front_end_duo() && n >= 16;
+    if (duo_wanted) need = need_a + need_b + 65536;
     // LZP drivers are serial single-workgroup kernels (0.75 s for a 256 MiB text block alone, ~1.2 s beside the whole-GPU
     // kernels of other blocks, however many run side by side).  The blocks go through the front end in WINDOWS, software-pipelined
     // over a ring of `ns` context slots with one side stream each: while the drivers of windows k-ns+2 .. k run on their side
@@ -930,57 +957,189 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
     const s32 lag = ns - 1;  // window k is finished in iteration k + lag
     static const bool trace_rings = getenv("BZ3_HIP_TRACE_RINGS") != nullptr;  // (diagnosis, read once: see decode_group)
     double tr_prep = 0, tr_wait = 0, tr_fin = 0, tr_t0 = now_ms();
-    for (s32 k = 0; k < nwin + lag; k++) {
-        const double tr_a = now_ms();
-        if (k < nwin) {  // prepare window k, then start its drivers on the slot's side stream
-            const int q = (int)(k % ns);
-            Window & w = win[q];
-            w.w0 = k * window;
-            w.w1 = (w.w0 + window < n) ? w.w0 + window : n;
-            w.slot.used = 0;  // its previous tenant (window k-ns) was finished one iteration ago, on this stream
-            w.ctxs.assign((size_t)(w.w1 - w.w0), LzpEncodeCtx());
-            w.lz.clear();
-            for (s32 i = w.w0; i < w.w1; i++) {
-                encode_front_a(sts[i], bufs[i], sizes[i], arena, w.slot, w.ctxs[(size_t)(i - w.w0)]);
-                if (sts[i]->pending == bz3_state::ENC_CODED && w.ctxs[(size_t)(i - w.w0)].active) w.lz.push_back(lzp_driver_job(w.ctxs[(size_t)(i - w.w0)]));
-            }
-            if (!w.lz.empty()) {
-                hipStream_t sq = lead->ctx->aux[q];
-                HIP_CHECK(hipEventRecord(lead->ctx->ev_prep, s));  // the prepares above are in flight on the group's stream
-                HIP_CHECK(hipStreamWaitEvent(sq, lead->ctx->ev_prep, 0));
-                HIP_CHECK(hipEventRecord(lead->ctx->ev_d0[q], sq));
-                lzp_driver_batch(w.lz.data(), w.d_lz, (u32)w.lz.size(), sq);
-                HIP_CHECK(hipEventRecord(lead->ctx->ev_d1[q], sq));
-            }
+    // Phase A of window k on stream sp with scratch `scr`: CRC, mRLE, LZP preparation of its blocks, then its drivers on the slot's side stream behind `ev`.
+    auto prepare = [&](s32 k, hipStream_t sp, Arena & scr, hipEvent_t ev) {
+        const int q = (int)(k % ns);
+        Window & w = win[q];
+        w.w0 = k * window;
+        w.w1 = (w.w0 + window < n) ? w.w0 + window : n;
+        w.slot.used = 0;  // its previous tenant (window k-ns) has been finished
+        w.ctxs.assign((size_t)(w.w1 - w.w0), LzpEncodeCtx());
+        w.lz.clear();
+        for (s32 i = w.w0; i < w.w1; i++) {
+            sts[i]->xs = sp;
+            encode_front_a(sts[i], bufs[i], sizes[i], scr, w.slot, w.ctxs[(size_t)(i - w.w0)]);
+            if (sts[i]->pending == bz3_state::ENC_CODED && w.ctxs[(size_t)(i - w.w0)].active) w.lz.push_back(lzp_driver_job(w.ctxs[(size_t)(i - w.w0)]));
         }
-        const double tr_b = now_ms();
-        tr_prep += tr_b - tr_a;
-        if (k >= lag) {  // finish window k-lag: its drivers have had the whole-GPU work of `lag` other windows to hide behind
-            const int q = (int)((k - lag) % ns);
-            Window & w = win[q];
-            float driver_ms = 0.f;
-            if (!w.lz.empty()) {
-                HIP_CHECK(hipEventSynchronize(lead->ctx->ev_d1[q]));
-                (void)hipEventElapsedTime(&driver_ms, lead->ctx->ev_d0[q], lead->ctx->ev_d1[q]);
-                tr_wait += now_ms() - tr_b;
-            }
-            for (s32 i = w.w0; i < w.w1; i++) {
-                encode_front_b(sts[i], arena, w.ctxs[(size_t)(i - w.w0)], driver_ms);
-                if (sts[i]->pending == bz3_state::ENC_CODED) {
-                    CmEncodeJob j{dev_addr(sts[i]->b2), dev_addr(sts[i]->b1 + sts[i]->overhead * 4 + 1), dev_addr(sts[i]->d_words + 2), sts[i]->n_cm, 0u};  // :634-638
-                    if (sts[i]->lean) {  // in place: input at the end of the caller's buffer, output behind the header
-                        sts[i]->side = sides + (size_t)i * CM_SIDE_BYTES;
-                        j.gap = (u32)(sts[i]->b2 - (sts[i]->b1 + sts[i]->overhead * 4 + 1));
-                        j.side = dev_addr(sts[i]->side);
-                        j.side_cap = CM_SIDE_BYTES;
-                    }
-                    jobs.push_back(j);
-                    job_owner.push_back(i);
+        HIP_CHECK(hipEventRecord(ev, sp));  // the prepares above are in flight on sp
+        if (!w.lz.empty()) {
+            hipStream_t sq = lead->ctx->aux[q];
+            HIP_CHECK(hipStreamWaitEvent(sq, ev, 0));
+            HIP_CHECK(hipEventRecord(lead->ctx->ev_d0[q], sq));
+            lzp_driver_batch(w.lz.data(), w.d_lz, (u32)w.lz.size(), sq);
+            HIP_CHECK(hipEventRecord(lead->ctx->ev_d1[q], sq));
+        }
+    };
+    // Phase B of window j on stream sf with scratch `scr`: waits for its drivers, then LZP emission, BWT, header per block; the CM jobs in block order.
+    // held != nullptr: lean states keep their swap buffers (the caller hands them back behind an event: two-thread form).
+    auto finish = [&](s32 j, hipStream_t sf, Arena & scr, std::vector<bz3_state *> * held) {
+        const int q = (int)(j % ns);
+        Window & w = win[q];
+        float driver_ms = 0.f;
+        if (!w.lz.empty()) {
+            const double t0 = now_ms();
+            HIP_CHECK(hipEventSynchronize(lead->ctx->ev_d1[q]));
+            (void)hipEventElapsedTime(&driver_ms, lead->ctx->ev_d0[q], lead->ctx->ev_d1[q]);
+            tr_wait += now_ms() - t0;
+        }
+        for (s32 i = w.w0; i < w.w1; i++) {
+            sts[i]->xs = sf;
+            sts[i]->hold_swap = held != nullptr;
+            encode_front_b(sts[i], scr, w.ctxs[(size_t)(i - w.w0)], driver_ms);
+            sts[i]->hold_swap = false;
+            if (sts[i]->pending == bz3_state::ENC_CODED) {
+                CmEncodeJob j2{dev_addr(sts[i]->b2), dev_addr(sts[i]->b1 + sts[i]->overhead * 4 + 1), dev_addr(sts[i]->d_words + 2), sts[i]->n_cm, 0u};  // :634-638
+                if (sts[i]->lean) {  // in place: input at the end of the caller's buffer, output behind the header
+                    sts[i]->side = sides + (size_t)i * CM_SIDE_BYTES;
+                    j2.gap = (u32)(sts[i]->b2 - (sts[i]->b1 + sts[i]->overhead * 4 + 1));
+                    j2.side = dev_addr(sts[i]->side);
+                    j2.side_cap = CM_SIDE_BYTES;
                 }
+                jobs.push_back(j2);
+                job_owner.push_back(i);
+            }
+            if (held) {
+                if (sts[i]->lean && sts[i]->d_swap) held->push_back(sts[i]);
+            } else {
                 lean_return(sts[i]);  // blocks that left the pipeline early (stored, failed) still hold their swap buffer
             }
         }
-        tr_fin += now_ms() - tr_b;
+    };
+    const bool duo = duo_wanted && nwin >= 3 && lead->ctx->aux_ready && s == lead->stream;  // (aux_ready: ctx->duo exists -- a null handle under the emulator)
+    if (!duo) {
+        for (s32 k = 0; k < nwin + lag; k++) {
+            const double tr_a = now_ms();
+            if (k < nwin) prepare(k, s, arena, lead->ctx->ev_prep);
+            const double tr_b = now_ms();
+            tr_prep += tr_b - tr_a;
+            if (k >= lag) finish(k - lag, s, arena, nullptr);
+            tr_fin += now_ms() - tr_b;
+        }
+    } else {
+        // ---- two-thread front end (round 6).  Phase A (14 ms of whole-GPU kernels per 256 MiB block) and phase B (56 ms) both stop for read-backs the host
+        // needs (mRLE size; LZP size, one per sorter pass), and while one waits nothing of THIS stream runs.  A second host thread takes phase A on a stream of its
+        // own (ctx->duo) with its own scratch region and runs up to ns - 1 windows ahead of this thread's phase B: the kernels of one fill the other's bubbles.
+        //   slot reuse      A prepares window k once B has FINISHED window k - ns (host: `finished`) and behind B's kernels of that window (stream: evB[k - ns]);
+        //   hand-over       B starts window j once A has prepared it (host: `prepared`), behind A's kernels (stream: evA[j]); the drivers' events as before;
+        //   swap buffers    lean states' buffers go back to the pool when B has recorded evB[j] (`held`), and A's stream waits for the latest such event before the
+        //                   kernels of blocks that may have borrowed them: with two streams stream order alone no longer protects a re-borrowed buffer.
+        // Output bytes cannot depend on any of this: every block still runs A then B, each on one stream, B behind A's event.
+        g_front_end_ring.fetch_or(1 << 29);
+        hipStream_t sA = lead->ctx->duo;
+        DrainOnUnwind drain_duo{sA, nullptr, 0};
+        Arena scr_a;
+        scr_a.base = arena.take<char>(need_a);
+        scr_a.cap = need_a;
+        struct Events {
+            std::vector<hipEvent_t> e;
+            ~Events() {
+                for (hipEvent_t x : e)
+                    if (x) (void)hipEventDestroy(x);
+            }
+        } evs;
+        evs.e.assign((size_t)2 * (size_t)nwin, nullptr);
+        for (auto & x : evs.e) HIP_CHECK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+        hipEvent_t * evA = evs.e.data(), * evB = evs.e.data() + nwin;
+        struct Shared {
+            std::mutex m;
+            std::condition_variable cv;
+            s32 prepared = 0, finished = 0;
+            bool abort = false;
+            std::exception_ptr err;
+            std::mutex pool;              // borrowing a window's buffers / returning a window's buffers + publishing the event that covers them
+            hipEvent_t last_return = nullptr;
+            double prep_ms = 0;
+        } sh;
+        const int device = lead->device;
+        std::thread ta([&] {
+            try {
+                DeviceGuard gd(device);
+                for (s32 k = 0; k < nwin; k++) {
+                    {
+                        std::unique_lock<std::mutex> ul(sh.m);
+                        sh.cv.wait(ul, [&] { return sh.abort || sh.finished >= k - ns + 1; });
+                        if (sh.abort) return;
+                    }
+                    const double t0 = now_ms();
+                    if (k >= ns) HIP_CHECK(hipStreamWaitEvent(sA, evB[k - ns], 0));
+                    {
+                        hipEvent_t ev = nullptr;
+                        const s32 w0 = k * window, w1 = (w0 + window < n) ? w0 + window : n;
+                        {
+                            std::lock_guard<std::mutex> pl(sh.pool);
+                            for (s32 i = w0; i < w1; i++) lean_borrow(sts[i]);
+                            ev = sh.last_return;
+                        }
+                        if (ev) HIP_CHECK(hipStreamWaitEvent(sA, ev, 0));
+                    }
+                    prepare(k, sA, scr_a, evA[k]);
+                    {
+                        std::lock_guard<std::mutex> ul(sh.m);
+                        sh.prepared = k + 1;
+                        sh.prep_ms += now_ms() - t0;
+                    }
+                    sh.cv.notify_all();
+                }
+            } catch (...) {
+                {
+                    std::lock_guard<std::mutex> ul(sh.m);
+                    sh.err = std::current_exception();
+                    sh.abort = true;
+                }
+                sh.cv.notify_all();
+            }
+        });
+        struct Joiner {
+            std::thread & t;
+            Shared & sh;
+            ~Joiner() {
+                {
+                    std::lock_guard<std::mutex> ul(sh.m);
+                    if (sh.finished < 0x7FFFFFFF && std::uncaught_exceptions()) sh.abort = true;  // this thread is unwinding: phase A stops at its next window
+                }
+                sh.cv.notify_all();
+                if (t.joinable()) t.join();
+            }
+        } joiner{ta, sh};
+        std::vector<bz3_state *> held;
+        for (s32 j = 0; j < nwin; j++) {
+            const double tr_b = now_ms();
+            {
+                std::unique_lock<std::mutex> ul(sh.m);
+                sh.cv.wait(ul, [&] { return sh.abort || sh.prepared >= j + 1; });
+                if (sh.abort) break;
+            }
+            HIP_CHECK(hipStreamWaitEvent(s, evA[j], 0));
+            held.clear();
+            finish(j, s, arena, &held);
+            HIP_CHECK(hipEventRecord(evB[j], s));
+            {
+                std::lock_guard<std::mutex> pl(sh.pool);
+                for (bz3_state * st : held) lean_return(st);
+                sh.last_return = evB[j];
+            }
+            {
+                std::lock_guard<std::mutex> ul(sh.m);
+                sh.finished = j + 1;
+            }
+            sh.cv.notify_all();
+            tr_fin += now_ms() - tr_b;
+        }
+        ta.join();
+        if (sh.err) std::rethrow_exception(sh.err);
+        HIP_CHECK(hipStreamSynchronize(sA));
+        tr_prep = sh.prep_ms;
+        for (s32 i = 0; i < n; i++) sts[i]->xs = s;
     }
     if (trace_rings)
         fprintf(stderr, "[bz3 rings] encode front end: %d blocks, %d windows of %d x %d slots: %.1f ms = CRC / mRLE / LZP prepare %.1f + waiting for a window's LZP drivers %.1f + LZP emit / BWT / header %.1f\n",
@@ -1841,6 +2000,10 @@ BZIP3_API size_t bz3_hip_debug_cached_bytes(int device) {  // workspace + idle p
     if (!c) return 0;
     std::lock_guard<std::mutex> lk(c->mu);
     return c->ws_cap + c->temp_idle_bytes();
+}
+BZIP3_API int bz3_hip_set_front_end_duo(int on) {
+    g_front_duo.store(on < 0 ? -1 : (on ? 1 : 0));
+    return 0;
 }
 BZIP3_API int bz3_hip_set_keep_workspace(int on) {
     g_keep_ws.store(on < 0 ? -1 : (on ? 1 : 0));

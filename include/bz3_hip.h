@@ -64,6 +64,11 @@ BZIP3_API int bz3_hip_debug_front_end_ring(void);
  * from it -- instead of a hipFree and two multi-GB hipMallocs per round trip (30-45 ms per GiB).  The memory stays with the library until
  * bz3_hip_release_cached_memory(), within the headroom rule below.  bench.py turns it on for its timed steps. */
 BZIP3_API int bz3_hip_set_keep_workspace(int on);
+/* Two-thread front end of the encoder (round 6; 1 on, 0 off, -1 back to the environment: BZ3_HIP_FRONT_DUO, read once).  A batch of 16 blocks or more runs the first
+ * half of every block's front end (CRC, mRLE, LZP preparation) on a second host thread and stream, up to ring-slots - 1 windows ahead of the second half (LZP emission,
+ * suffix sort) on the calling thread: each half stops for read-backs the host needs, and the kernels of one fill the other's bubbles.  Costs a second scratch region
+ * (~30 bytes per byte of the largest block).  Output bytes do not depend on it.  bz3_hip_debug_front_end_ring() reports bit 29 when the last call took this form. */
+BZIP3_API int bz3_hip_set_front_end_duo(int on);
 /* Headroom: the device memory the library leaves to the host program (the caller owns its memory; the library's workspace, its pool of swap buffers and --
  * with keep-workspace -- a GPU-filling batch's whole ring are caches).  Rule: when a batch call returns, at least `bytes` of the device are free
  * (hipMemGetInfo), or the library holds nothing cached on that device.  The rings are sized for it and the rule is enforced when a call ends (idle pooled swap

@@ -871,6 +871,59 @@ def test_pipelined_windows_of_a_large_batch(emu, oracle, pipe, monkeypatch):
         emu.bz3_free(s)
 
 
+@pytest.mark.parametrize("pipe", [None, "1,4", "3,3", "5,2"], ids=["auto", "w1s4", "w3s3", "w5s2"])
+def test_two_thread_front_end(emu, oracle, pipe, monkeypatch):
+    """Round 6: bz3_hip_set_front_end_duo(1) -- phase A of the encoder's front end (CRC, mRLE, LZP preparation) on a second host thread and stream, up to
+    slots - 1 windows ahead of phase B (LZP emission, BWT, header) on the calling thread, swap buffers of lean states handed back behind events (api.hip
+    encode_group).  36 blocks (LZP applied, declined, stored; one with an invalid size, which fails alone) through forced ring shapes, classic and lean
+    states, twice in a row (the second call reuses pool and arena): the oracle's bytes, and the ring reports the two-thread form."""
+    if pipe:
+        monkeypatch.setenv("BZ3_HIP_LZP_PIPE", pipe)
+    else:
+        monkeypatch.delenv("BZ3_HIP_LZP_PIPE", raising=False)
+    bs = 65 * 1024
+    t = datagen.shakespeare()
+    blocks = []
+    for i in range(36):
+        if i % 5 == 3:
+            blocks.append((t[i * 400 : i * 400 + 150] * 3) + t[9000:9100])
+        elif i % 7 == 6:
+            blocks.append(b"y" * (20 + i))
+        elif i == 10:
+            blocks.append(datagen.random_bytes(900, seed=5))
+        else:
+            blocks.append(t[i * 400 : i * 400 + 260 + 7 * i])
+    want = [oracle.encode_block(d, bs)[2] for d in blocks]
+    n = len(blocks)
+    try:
+        assert emu.bz3_hip_set_front_end_duo(1) == 0
+        for lean in (0, 1):
+            assert emu.bz3_hip_set_lean_states(lean) == 0
+            states = (C.c_void_p * n)(*[emu.bz3_new(bs) for _ in range(n)])
+            cap = emu.bz3_bound(bs) + 64
+            for trip in range(2):
+                bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+                for b, d in zip(bufs, blocks):
+                    C.memmove(b, d, len(d))
+                ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+                sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+                if trip == 1:
+                    sizes[17] = bs + 1  # larger than the state's block size: BZ3_ERR_DATA_TOO_BIG for this block alone
+                emu.bz3_encode_blocks(states, ptrs, sizes, n)
+                assert (emu.bz3_hip_debug_front_end_ring() >> 29) & 1 == 1, (lean, trip)
+                for i in range(n):
+                    if trip == 1 and i == 17:
+                        assert sizes[i] == -1 and emu.bz3_last_error(states[i]) == bzip3_amd.BZ3_ERR_DATA_TOO_BIG
+                    else:
+                        assert bytes(bufs[i][: sizes[i]]) == want[i], (lean, trip, i)
+            for s_ in states:
+                emu.bz3_free(s_)
+        assert emu.bz3_hip_set_front_end_duo(0) == 0
+    finally:
+        emu.bz3_hip_set_front_end_duo(-1)
+        emu.bz3_hip_set_lean_states(0)
+
+
 SORTER_CASES = datagen.suffix_sorter_cases()
 
 

@@ -805,3 +805,57 @@ def test_kept_workspace_leaves_the_headroom_to_the_host_program(gpu_lib, text):
         gpu_lib.bz3_hip_release_cached_memory()
         gpu_lib.bz3_hip_bind_device(-1)
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("pipe", [None, "1,4", "5,3", "6,2"], ids=["auto", "w1s4", "w5s3", "w6s2"])
+def test_two_thread_front_end_on_gpu(gpu_lib, oracle, text, pipe, monkeypatch):
+    """Round 6: the encoder's front end on two host threads and two streams (bz3_hip_set_front_end_duo(1); api.hip encode_group) -- only on the GPU do the
+    two streams really overlap.  120 blocks of up to 1.5 MiB (LZP applied, declined, stored, random), classic and lean states, three encode calls in a row
+    (the later ones reuse the pool's swap buffers, which phase A may only touch behind phase B's events), forced ring shapes: the oracle's bytes, and the
+    decoder gives the plaintext back."""
+    if pipe:
+        monkeypatch.setenv("BZ3_HIP_LZP_PIPE", pipe)
+    else:
+        monkeypatch.delenv("BZ3_HIP_LZP_PIPE", raising=False)
+    bs = 1536 * 1024
+    distinct = []
+    for i in range(12):
+        if i % 5 == 3:
+            distinct.append(text[i * 50000 : i * 50000 + 60000] * 5 + text[900000:930000])
+        elif i == 6:
+            distinct.append(b"x" * 41)
+        elif i == 4:
+            distinct.append(datagen.random_bytes(300000, seed=4))
+        else:
+            distinct.append(text[i * 90000 : i * 90000 + 400000 + 90000 * i])
+    want = [oracle.encode_block(d, bs)[2] for d in distinct]
+    blocks = [distinct[(7 * k) % 12] for k in range(120)]
+    n = len(blocks)
+    try:
+        assert gpu_lib.bz3_hip_set_front_end_duo(1) == 0
+        for lean in (0, 1):
+            assert gpu_lib.bz3_hip_set_lean_states(lean) == 0
+            states = (C.c_void_p * n)(*[gpu_lib.bz3_new(bs) for _ in range(n)])
+            assert all(states)
+            cap = gpu_lib.bz3_bound(bs) + 64
+            for trip in range(3):
+                bufs = [(C.c_uint8 * cap)() for _ in range(n)]
+                for b, d in zip(bufs, blocks):
+                    C.memmove(b, d, len(d))
+                ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+                sizes = (C.c_int32 * n)(*[len(d) for d in blocks])
+                gpu_lib.bz3_encode_blocks(states, ptrs, sizes, n)
+                assert (gpu_lib.bz3_hip_debug_front_end_ring() >> 29) & 1 == 1
+                for k in range(n):
+                    assert bytes(bufs[k][: sizes[k]]) == want[(7 * k) % 12], (lean, trip, k)
+            bsz = (C.c_size_t * n)(*[cap] * n)
+            orig = (C.c_int32 * n)(*[len(d) for d in blocks])
+            gpu_lib.bz3_decode_blocks(states, ptrs, bsz, sizes, orig, n)
+            for k, d in enumerate(blocks):
+                assert gpu_lib.bz3_last_error(states[k]) == 0 and bytes(bufs[k][: len(d)]) == d, (lean, k)
+            for s_ in states:
+                gpu_lib.bz3_free(s_)
+    finally:
+        gpu_lib.bz3_hip_set_front_end_duo(-1)
+        gpu_lib.bz3_hip_set_lean_states(0)
+        gpu_lib.bz3_hip_release_cached_memory()
