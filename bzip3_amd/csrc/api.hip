@@ -67,7 +67,7 @@ struct DeviceCtx {
     // windows (profiles/r05_rings_256x64MiB.txt: the tail's host thread spent 82 % of its time in the inverse-BWT loop, 0.6 % waiting for LZP decoders).
     // So the side streams are created on `reserve` CUs of their own and the tail's whole-GPU kernels run on a stream masked to the OTHER CUs
     // (hipExtStreamCreateWithCUMask); the CM launches keep the group's unmasked stream (they need every CU).  BZ3_HIP_CU_RESERVE=<CUs> (read once;
-    // default 48, 0 = no partition).  Falls back to plain streams when the runtime refuses.
+    // default 64 since round 6 -- the most cu_masks hands out --, round 5: 48; 0 = no partition).  Falls back to plain streams when the runtime refuses.
     hipStream_t rest = nullptr;   // whole-GPU kernels beside the side streams' serial kernels: every CU but the reserved ones (null: no partition)
     hipStream_t aux_m[AUX] = {};  // the decoder's side streams, on the reserved CUs (the encoder's rings keep the plain ones: call 4 measured its
                                          // front end 6 % SLOWER with its LZP drivers confined to 32 CUs, profiles/r05_cu_partition_256x64MiB.txt)
@@ -968,6 +968,7 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
         w.lz.clear();
         for (s32 i = w.w0; i < w.w1; i++) {
             sts[i]->xs = sp;
+            sts[i]->hold_swap = false;  // (a call that was left by an exception may have left it set)
             encode_front_a(sts[i], bufs[i], sizes[i], scr, w.slot, w.ctxs[(size_t)(i - w.w0)]);
             if (sts[i]->pending == bz3_state::ENC_CODED && w.ctxs[(size_t)(i - w.w0)].active) w.lz.push_back(lzp_driver_job(w.ctxs[(size_t)(i - w.w0)]));
         }
@@ -1099,13 +1100,14 @@ void encode_group(bz3_state ** sts, u8 ** bufs, const s32 * sizes, s32 n) {
                 sh.cv.notify_all();
             }
         });
-        struct Joiner {
+        struct Joiner {  // whatever happens on this thread, phase A's thread is joined before its std::thread object dies
             std::thread & t;
             Shared & sh;
+            int live = std::uncaught_exceptions();
             ~Joiner() {
-                {
+                if (std::uncaught_exceptions() > live) {  // this thread is unwinding: phase A stops at its next window
                     std::lock_guard<std::mutex> ul(sh.m);
-                    if (sh.finished < 0x7FFFFFFF && std::uncaught_exceptions()) sh.abort = true;  // this thread is unwinding: phase A stops at its next window
+                    sh.abort = true;
                 }
                 sh.cv.notify_all();
                 if (t.joinable()) t.join();

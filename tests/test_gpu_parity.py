@@ -610,8 +610,8 @@ def test_lean_states_on_gpu(gpu_lib, oracle, text):
 
 
 def test_large_lean_batch_default_rings_and_kept_workspace_on_gpu(gpu_lib, oracle, text):
-    """Round 5's defaults for GPU-filling batches, at a size a test can afford: 140 lean blocks (>= 128: the decoder's tail takes its four-slot ring -- windows
-    of reserved CUs / 4 blocks on the CU partition, LZP decoders on the reserved CUs, whole-GPU kernels on the others) through the batch API, twice, with the
+    """The defaults for GPU-filling batches, at a size a test can afford: 140 lean blocks (>= 128: the decoder's tail takes its four-slot ring -- windows of 30
+    blocks since round 6 -- on the CU partition, LZP decoders on the 64 reserved CUs, whole-GPU kernels on the others) through the batch API, twice, with the
     workspace KEPT between the calls (bz3_hip_set_keep_workspace(1): the decode call reuses the encode call's arena and carves the swap buffers of its tail
     windows from it).  Blocks of text with long repeats (LZP and mRLE on), a random block (more than a quarter of its bytes outside the 40 most frequent
     values: straight to the whole-model CM kernel when the batch takes a row-cache variant), a tiny and an empty one; on the second trip one payload is
