@@ -16,3 +16,6 @@ print("roofline", json.dumps(d.get("roofline"))); print("stages", json.dumps(d.g
 c = d.get("cpu_baseline", {}); print("cpu", c.get("value"), c.get("gpu_over_cpu"), c.get("parity"), c.get("build_probe_1_thread_8MiB_MiBps"))
 P
 timeout 1500 python3 -m pytest tests -m gpu -q 2>&1 | tail -8 | tee $OUT/pytest_gpu.log
+# SURVEY 8d's "additionally the unmodified CLI wall-clock on tmpfs" (round 2's record refreshed): the reference's main.c linked against the reference and against the product,
+# 256 MiB of text at -b 32 -j 8 -- eight blocks per call cannot fill a GPU, which is the point of the number.
+timeout 900 python3 tools/cli_time.py 256 32 8 2>&1 | tail -1 | tee $OUT/cli_wall_clock_tmpfs.json
