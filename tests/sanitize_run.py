@@ -74,4 +74,12 @@ for lean in (0, 1):
     for pipe in (None, "1,4", "5,3", "3,2"):
         batch(23, pipe)
         print("batch ok", lean, pipe, flush=True)
+# round 6: the encoder's front end on two host threads (its second scratch region, the held swap buffers, the per-window events)
+lib.bz3_hip_set_front_end_duo(1)
+for lean in (0, 1):
+    lib.bz3_hip_set_lean_states(lean)
+    for pipe in (None, "1,4", "3,3"):
+        batch(23, pipe)
+        print("two-thread batch ok", lean, pipe, flush=True)
+lib.bz3_hip_set_front_end_duo(-1)
 print("ok")

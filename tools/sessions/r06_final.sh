@@ -16,6 +16,8 @@ print("roofline", json.dumps(d.get("roofline"))); print("stages", json.dumps(d.g
 c = d.get("cpu_baseline", {}); print("cpu", c.get("value"), c.get("gpu_over_cpu"), c.get("parity"), c.get("build_probe_1_thread_8MiB_MiBps"))
 P
 timeout 1500 python3 -m pytest tests -m gpu -q 2>&1 | tail -8 | tee $OUT/pytest_gpu.log
+# (what the mRLE kernels take per 256 MiB block after round 6's 16-byte stores: the stage probe's host times bracket them)
+timeout 200 python3 tools/stage_probe.py 256 --noise=0.035 2>/dev/null | tee $OUT/stage_probe_256MiB.txt
 # SURVEY 8d's "additionally the unmodified CLI wall-clock on tmpfs" (round 2's record refreshed): the reference's main.c linked against the reference and against the product,
 # 256 MiB of text at -b 32 -j 8 -- eight blocks per call cannot fill a GPU, which is the point of the number.
-timeout 900 python3 tools/cli_time.py 256 32 8 2>&1 | tail -1 | tee $OUT/cli_wall_clock_tmpfs.json
+[ -n "$R06_SKIP_CLI" ] || timeout 900 python3 tools/cli_time.py 256 32 8 2>&1 | tail -1 | tee $OUT/cli_wall_clock_tmpfs.json
